@@ -1,0 +1,190 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from realtimedepthdiffusion_amd/.  See the header of
+rtdd_oracle.c for what pins it (the reference has no golden vectors: "parity unpinned").
+
+All image arguments are numpy arrays whose last axis is contiguous; the row pitch handed to
+C is ``arr.strides[0]`` so pitched (padded-row) views work exactly like the reference's
+``GpuMat.ptr()/.step`` pairs.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("rtdd_oracle.c", "rtdd_cascade_oracle.c", "Makefile")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_residual.restype = C.c_float
+        _lib.orc_solve.restype = C.c_int
+        _lib.orc_max_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _pitch(a):
+    if a.ndim == 2:
+        assert a.strides[1] == a.itemsize, "last axis must be contiguous"
+    else:
+        assert a.strides[2] == a.itemsize and a.strides[1] == a.itemsize * a.shape[2], "pixels must be interleaved"
+    return C.c_size_t(a.strides[0])
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+def load_weights(beta):
+    lut = np.empty(257, np.float32)
+    lib().orc_load_weights(C.c_float(beta), _p(lut))
+    return lut
+
+
+def omega_schedule(n):
+    om = np.empty(max(n, 1), np.float32)
+    lib().orc_omega_schedule(C.c_int(n), _p(om))
+    return om[:n]
+
+
+def index_to_weight(gray, depth, level, max_level):
+    rows, cols = gray.shape
+    idx = np.empty((rows, cols, 2), np.int32)
+    if depth is None:
+        depth = np.zeros((rows, cols), np.float32)
+    lib().orc_index_to_weight(_p(gray), _pitch(gray), _p(depth), _pitch(depth), _p(idx),
+                              C.c_int(level), C.c_int(max_level), C.c_int(rows), C.c_int(cols))
+    return idx
+
+
+def sweep(x, idx, mask, prev, omega, lut, contract, gamma=np.float32(0.99), threads=1):
+    """One K1 sweep on dense arrays; returns out (prev is updated in place).
+
+    Positions with mask==255 are left as in ``x`` (the reference's ping-pong buffers both
+    hold the input there)."""
+    rows, cols = x.shape
+    x = np.ascontiguousarray(x, np.float32)
+    out = x.copy()
+    lib().orc_sweep(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(out), _p(prev),
+                    C.c_float(omega), C.c_float(gamma), _p(lut), C.c_int(contract), C.c_int(threads))
+    return out
+
+
+def solve(depth, mask, gray, max_iterations, level, max_level, lut, contract, threads=1, rows=None, cols=None):
+    """GPUMatrixFreeSolver restatement; ``depth`` is updated in place (and returned)."""
+    r = depth.shape[0] if rows is None else rows
+    c = depth.shape[1] if cols is None else cols
+    rc = lib().orc_solve(_p(depth), _pitch(depth), _p(mask), _pitch(mask), _p(gray), _pitch(gray),
+                         C.c_int(r), C.c_int(c), C.c_int(max_iterations), C.c_int(level), C.c_int(max_level),
+                         _p(lut), C.c_int(contract), C.c_int(threads))
+    if rc != 0:
+        raise MemoryError("orc_solve")
+    return depth
+
+
+def convert_to_float(src, dst, mask):
+    rows, cols = mask.shape
+    lib().orc_convert_to_float(_p(src), _pitch(src), _p(dst), _pitch(dst), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols))
+    return dst
+
+
+def pyrdown_annotation(prev_scribble, prev_edited, curr_scribble, curr_edited):
+    pr, pc = prev_scribble.shape
+    cr, cc = curr_scribble.shape
+    lib().orc_pyrdown_annotation(_p(prev_scribble), _pitch(prev_scribble), _p(prev_edited), _pitch(prev_edited),
+                                 C.c_int(pr), C.c_int(pc), _p(curr_scribble), _pitch(curr_scribble),
+                                 _p(curr_edited), _pitch(curr_edited), C.c_int(cr), C.c_int(cc))
+
+
+def paint_image(x, y, color, radius, edited, scribble):
+    rows, cols = scribble.shape
+    lib().orc_paint_image(C.c_int(x), C.c_int(y), C.c_int(color), C.c_int(radius), _p(edited), _pitch(edited),
+                          _p(scribble), _pitch(scribble), C.c_int(rows), C.c_int(cols))
+
+
+def desaturate(orig, gray, depth, contract):
+    rows, cols = gray.shape
+    art = np.zeros_like(orig)
+    lib().orc_desaturate(_p(orig), _pitch(orig), _p(gray), _pitch(gray), _p(depth), _pitch(depth), _p(art), _pitch(art),
+                         C.c_int(rows), C.c_int(cols), C.c_int(contract))
+    return art
+
+
+def defocus(orig, depth, threads=1):
+    rows, cols = depth.shape
+    art = np.zeros_like(orig)
+    lib().orc_defocus(_p(orig), _pitch(orig), _p(depth), _pitch(depth), _p(art), _pitch(art),
+                      C.c_int(rows), C.c_int(cols), C.c_int(threads))
+    return art
+
+
+def haze(orig, depth, contract):
+    rows, cols = depth.shape
+    art = np.zeros_like(orig)
+    lib().orc_haze(_p(orig), _pitch(orig), _p(depth), _pitch(depth), _p(art), _pitch(art),
+                   C.c_int(rows), C.c_int(cols), C.c_int(contract))
+    return art
+
+
+def residual(x, idx, mask, lut, contract):
+    rows, cols = x.shape
+    x = np.ascontiguousarray(x, np.float32)
+    return float(lib().orc_residual(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract)))
+
+
+def rbgs_sweep(x, idx, mask, lut, contract):
+    rows, cols = x.shape
+    assert x.flags.c_contiguous and x.dtype == np.float32
+    lib().orc_rbgs_sweep(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract))
+    return x
+
+
+# ---- third-party (OpenCV) restatements used by the cascade harness --------------------------
+def bgr2gray(bgr):
+    rows, cols = bgr.shape[:2]
+    g = np.empty((rows, cols), np.uint8)
+    lib().orc_bgr2gray(_p(bgr), _pitch(bgr), _p(g), _pitch(g), C.c_int(rows), C.c_int(cols))
+    return g
+
+
+def pyrdown_u8(src):
+    rows, cols = src.shape
+    d = np.empty(((rows + 1) // 2, (cols + 1) // 2), np.uint8)
+    lib().orc_pyrdown_u8(_p(src), _pitch(src), C.c_int(rows), C.c_int(cols), _p(d), _pitch(d))
+    return d
+
+
+def pyrup_f32(src, drows, dcols, rows=None, cols=None):
+    r = src.shape[0] if rows is None else rows
+    c = src.shape[1] if cols is None else cols
+    d = np.empty((drows, dcols), np.float32)
+    lib().orc_pyrup_f32(_p(src), _pitch(src), C.c_int(r), C.c_int(c), _p(d), _pitch(d), C.c_int(drows), C.c_int(dcols))
+    return d
+
+
+def depth_to_u8(src):
+    rows, cols = src.shape
+    d = np.empty((rows, cols), np.uint8)
+    lib().orc_depth_to_u8(_p(src), _pitch(src), _p(d), _pitch(d), C.c_int(rows), C.c_int(cols))
+    return d

@@ -1,0 +1,377 @@
+/*
+ * rtdd_oracle.c -- CPU restatement of the RealTimeDepthDiffusion GPU hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (realtimedepthdiffusion_amd/)
+ * never links, imports or falls back to anything in oracle/.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: the reference ships no tests, golden vectors or
+ * known-answer fixtures for this path, and its CUDA/OpenCV sources cannot be built here
+ * (no nvcc, no OpenCV).  This file is pinned instead by (1) hand-computable known-answer
+ * cases, (2) an independent numpy restatement (tests/np_restatement.py) that must agree
+ * bit-for-bit in both FP-contraction variants, (3) scipy spsolve of the underlying linear
+ * system, and (4) committed goldens produced by this file (tests/golden/).
+ *
+ * Every function cites the reference lines it follows (paths relative to /root/reference).
+ * Arithmetic is IEEE binary32 with denormals preserved; build with
+ *   gcc -O2 -ffp-contract=off -fno-fast-math -march=x86-64-v3 -fopenmp
+ * so that the only fused multiply-adds are the explicit fmaf() calls of the
+ * "contracted" variant (what nvcc's default -fmad=true would most plausibly emit).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ---- float -> u8 store.  The reference relies on an out-of-range float->uchar cast
+ * (UB in C++; src/GPUSolver.cu:168, src/GPUDepthEffect.cu:23,89).  We DEFINE it as
+ * saturate-then-truncate; identical to the reference for in-range values. */
+static inline uint8_t sat_u8(float v) {
+    if (!(v >= 0.0f)) return 0;      /* negatives and NaN */
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;               /* truncation toward zero */
+}
+
+/* ---- clamp of the weighted mean, src/GPUSolver.cu:104 `min(max(sum/count, 0.0), 255.0)`
+ * (fmax/fmin semantics: NaN -> 0). */
+static inline float clamp255(float q) {
+    float r = q;
+    if (!(r >= 0.0f)) r = 0.0f;
+    if (r > 255.0f) r = 255.0f;
+    return r;
+}
+
+/* =====================================================================================
+ * a5  GPULoadWeights  -- src/GPUSolver.cu:264-272
+ * ===================================================================================*/
+ORC_API void orc_load_weights(float beta, float *lut /*[257]*/) {
+    for (int w = 0; w < 256; w++) lut[w] = expf(-beta * (float)w);   /* f32 product, host libm */
+    lut[256] = 0.0f;
+}
+
+/* =====================================================================================
+ * a4  loadIndexToWeight (K2) -- src/GPUSolver.cu:136-224
+ * Output is the reference's int2 per pixel, dense y*cols+x: {left*1000+right, up*1000+down}.
+ * ===================================================================================*/
+static inline int sad_u8(uint8_t a, uint8_t b) { return a > b ? a - b : b - a; }   /* __sad(a,b,0) */
+
+ORC_API void orc_index_to_weight(const uint8_t *gray, size_t grayPitch,
+                                 const float *depth, size_t depthPitch,
+                                 int32_t *index2 /*[rows*cols*2]*/,
+                                 int level, int maxLevel, int rows, int cols) {
+    for (int y = 0; y < rows; y++) {
+        for (int x = 0; x < cols; x++) {
+            int left = 256, right = 256, up = 256, down = 256;          /* :183-186 */
+#define G(yy, xx) (gray[(size_t)(yy) * grayPitch + (xx)])
+#define D(yy, xx) sat_u8(((const float *)((const char *)depth + (size_t)(yy) * depthPitch))[xx]) /* :168 */
+            uint8_t g = G(y, x);
+            if (level == maxLevel) {                                     /* :188-194 */
+                if (x - 1 >= 0) left = sad_u8(g, G(y, x - 1));
+                if (x + 1 < cols) right = sad_u8(g, G(y, x + 1));
+                if (y - 1 >= 0) up = sad_u8(g, G(y - 1, x));
+                if (y + 1 < rows) down = sad_u8(g, G(y + 1, x));
+            } else {                                                     /* :196-218 */
+                uint8_t d = D(y, x);
+                int threshold = 4;
+                if (level == 0) threshold = 0;
+                if (x - 1 >= 0) left = sad_u8(d, D(y, x - 1)) > threshold ? sad_u8(g, G(y, x - 1)) : 0;
+                if (x + 1 < cols) right = sad_u8(d, D(y, x + 1)) > threshold ? sad_u8(g, G(y, x + 1)) : 0;
+                if (y - 1 >= 0) up = sad_u8(d, D(y - 1, x)) > threshold ? sad_u8(g, G(y - 1, x)) : 0;
+                if (y + 1 < rows) down = sad_u8(d, D(y + 1, x)) > threshold ? sad_u8(g, G(y + 1, x)) : 0;
+            }
+#undef G
+#undef D
+            size_t p = (size_t)y * cols + x;
+            index2[2 * p + 0] = left * 1000 + right;                     /* :222 */
+            index2[2 * p + 1] = up * 1000 + down;
+        }
+    }
+}
+
+/* =====================================================================================
+ * a2/a3  matrixFreeSolver (K1) + solveDiffusion (K1a) -- src/GPUSolver.cu:226-262, :73-106
+ * One Chebyshev-Jacobi sweep over dense buffers.  `contract` selects the FP-contraction
+ * variant: 0 = every mul/add rounded separately; 1 = fmaf where nvcc -fmad=true would
+ * fuse (sum += w*x ; gamma*(r-x)+x ; omega*(..)+prev).
+ * ===================================================================================*/
+static inline float mean4(int left, int right, int up, int down, const float *lut,
+                          const float *in, int x, int y, int cols, int contract) {
+    float sum = 0.0f, count = 0.0f, weight;
+    size_t p = (size_t)y * cols + x;
+    if (left != 256) {                                                   /* :79-83 */
+        weight = lut[left];
+        sum = contract ? fmaf(weight, in[p - 1], sum) : sum + weight * in[p - 1];
+        count += weight;
+    }
+    if (right != 256) {                                                  /* :85-89 */
+        weight = lut[right];
+        sum = contract ? fmaf(weight, in[p + 1], sum) : sum + weight * in[p + 1];
+        count += weight;
+    }
+    if (up != 256) {                                                     /* :91-95 */
+        weight = lut[up];
+        sum = contract ? fmaf(weight, in[p - cols], sum) : sum + weight * in[p - cols];
+        count += weight;
+    }
+    if (down != 256) {                                                   /* :97-101 */
+        weight = lut[down];
+        sum = contract ? fmaf(weight, in[p + cols], sum) : sum + weight * in[p + cols];
+        count += weight;
+    }
+    if (count == 0.0f) return 0.0f;                                      /* :103 */
+    return clamp255(sum / count);                                        /* :104 */
+}
+
+ORC_API void orc_sweep(const float *in, const int32_t *index2,
+                       const uint8_t *mask, size_t maskPitch, int rows, int cols,
+                       float *out, float *prev, float omega, float gamma,
+                       const float *lut, int contract, int threads) {
+    (void)threads;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (int y = 0; y < rows; y++) {
+        const uint8_t *mrow = mask + (size_t)y * maskPitch;
+        for (int x = 0; x < cols; x++) {
+            if (mrow[x] == 255) continue;                                /* :247-248 */
+            size_t p = (size_t)y * cols + x;
+            int left = index2[2 * p] / 1000, right = index2[2 * p] % 1000;       /* :250-254 */
+            int up = index2[2 * p + 1] / 1000, down = index2[2 * p + 1] % 1000;
+            float r = mean4(left, right, up, down, lut, in, x, y, cols, contract);
+            float pc = prev[p];                                          /* :257 */
+            float xc = in[p];                                            /* :258 */
+            float o;                                                     /* :259 */
+            if (contract) o = fmaf(omega, fmaf(gamma, r - xc, xc) - pc, pc);
+            else o = (omega * (gamma * (r - xc) + xc - pc)) + pc;
+            out[p] = o;
+            prev[p] = xc;                                                /* :260 */
+        }
+    }
+}
+
+/* omega schedule of GPUMatrixFreeSolver -- src/GPUSolver.cu:282-299 */
+ORC_API void orc_omega_schedule(int n, float *omegas) {
+    const int S = 10;
+    float omega = 0.0f;
+    float rho = 0.99;        /* double literal narrowed to float, as in the reference */
+    for (int it = 0; it < n; it++) {
+        if (it < S) omega = 1;
+        else if (it == S) omega = 2.0 / (2.0 - rho * rho);
+        else omega = 4.0 / (4.0 - rho * rho * omega);
+        omegas[it] = omega;
+    }
+}
+
+/* =====================================================================================
+ * a1  GPUMatrixFreeSolver -- src/GPUSolver.cu:274-316 (driver, ping-pong parity, copy-back)
+ * `lut` plays the role of deviceWeights[]; maxLevel the global set by GPUAllocateDeviceMemory.
+ * beta/tolerance are ignored by the reference (:274-275) and therefore absent here.
+ * ===================================================================================*/
+ORC_API int orc_solve(float *depth, size_t depthPitch, const uint8_t *mask, size_t maskPitch,
+                      const uint8_t *gray, size_t grayPitch, int rows, int cols,
+                      int maxIterations, int level, int maxLevel, const float *lut,
+                      int contract, int threads) {
+    size_t n = (size_t)rows * cols;
+    float *prev = (float *)calloc(n ? n : 1, sizeof(float));            /* :290 */
+    float *next = (float *)malloc((n ? n : 1) * sizeof(float));
+    float *cur = (float *)malloc((n ? n : 1) * sizeof(float));
+    int32_t *index2 = (int32_t *)malloc((n ? n : 1) * 2 * sizeof(int32_t));
+    if (!prev || !next || !cur || !index2) { free(prev); free(next); free(cur); free(index2); return -1; }
+    for (int y = 0; y < rows; y++) {                                     /* :291-292 */
+        const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
+        memcpy(next + (size_t)y * cols, drow, (size_t)cols * sizeof(float));
+        memcpy(cur + (size_t)y * cols, drow, (size_t)cols * sizeof(float));
+    }
+    orc_index_to_weight(gray, grayPitch, depth, depthPitch, index2, level, maxLevel, rows, cols); /* :293 */
+
+    const int S = 10;
+    float omega = 0.0f;
+    float rho = 0.99;
+    float gamma = 0.99;
+    int iteration;
+    for (iteration = 0; iteration < maxIterations; iteration++) {        /* :295-309 */
+        if (iteration < S) omega = 1;
+        else if (iteration == S) omega = 2.0 / (2.0 - rho * rho);
+        else omega = 4.0 / (4.0 - rho * rho * omega);
+        if (iteration % 2 == 0) orc_sweep(cur, index2, mask, maskPitch, rows, cols, next, prev, omega, gamma, lut, contract, threads);
+        else orc_sweep(next, index2, mask, maskPitch, rows, cols, cur, prev, omega, gamma, lut, contract, threads);
+    }
+    /* :311-312 -- C's % on (iteration-1) == -1 gives -1, so maxIterations == 0 copies `next` (== input) */
+    const float *res = ((iteration - 1) % 2 == 1) ? cur : next;
+    for (int y = 0; y < rows; y++) {
+        float *drow = (float *)((char *)depth + (size_t)y * depthPitch);
+        memcpy(drow, res + (size_t)y * cols, (size_t)cols * sizeof(float));
+    }
+    free(prev); free(next); free(cur); free(index2);
+    return 0;
+}
+
+/* =====================================================================================
+ * a8  GPUConvertToFloat / convert (K5) -- src/GPUImageProcessing.cu:8-21
+ * ===================================================================================*/
+ORC_API void orc_convert_to_float(const uint8_t *src, size_t srcPitch, float *dst, size_t dstPitch,
+                                  const uint8_t *mask, size_t maskPitch, int rows, int cols) {
+    for (int y = 0; y < rows; y++) {
+        float *drow = (float *)((char *)dst + (size_t)y * dstPitch);
+        const uint8_t *srow = src + (size_t)y * srcPitch;
+        const uint8_t *mrow = mask + (size_t)y * maskPitch;
+        for (int x = 0; x < cols; x++)
+            if (mrow[x] == 255) drow[x] = srow[x * 3 + 0];               /* :19 */
+    }
+}
+
+/* =====================================================================================
+ * a9  GPUPyrDownAnnotation / pyrDown (K6) -- src/GPUImageProcessing.cu:23-49
+ * ===================================================================================*/
+ORC_API void orc_pyrdown_annotation(const uint8_t *prevScribble, size_t prevScribblePitch,
+                                    const uint8_t *prevEdited, size_t prevEditedPitch,
+                                    int previousRows, int previousCols,
+                                    uint8_t *currScribble, size_t currScribblePitch,
+                                    uint8_t *currEdited, size_t currEditedPitch,
+                                    int currentRows, int currentCols) {
+    for (int y = 0; y < currentRows; y++)
+        for (int x = 0; x < currentCols; x++) {
+            const int kernelSize = 2;                                    /* :31 */
+            for (int py = 2 * y - kernelSize / 2; py < 2 * y + kernelSize / 2; py++)
+                for (int px = 2 * x - kernelSize / 2; px < 2 * x + kernelSize / 2; px++)
+                    if (px >= 0 && py >= 0 && px < previousCols && py < previousRows)
+                        if (prevScribble[(size_t)py * prevScribblePitch + px] == 255) {   /* :38 */
+                            currScribble[(size_t)y * currScribblePitch + x] = 255;
+                            currEdited[(size_t)y * currEditedPitch + x * 3 + 0] =
+                                prevEdited[(size_t)py * prevEditedPitch + px * 3 + 0];   /* last hit wins */
+                        }
+        }
+}
+
+/* =====================================================================================
+ * a10  GPUPaintImage / paintImage (K7) -- src/GPUImageProcessing.cu:51-70
+ * ===================================================================================*/
+ORC_API void orc_paint_image(int x, int y, int scribbleColor, int scribbleRadius,
+                             uint8_t *edited, size_t editedPitch,
+                             uint8_t *scribble, size_t scribblePitch, int rows, int cols) {
+    for (int ty = 0; ty < rows; ty++)
+        for (int tx = 0; tx < cols; tx++) {
+            if (tx < x - scribbleRadius / 2 || tx > x + scribbleRadius / 2) continue;    /* :58 */
+            if (ty < y - scribbleRadius / 2 || ty > y + scribbleRadius / 2) continue;    /* :59 */
+            uint8_t *e = edited + (size_t)ty * editedPitch + tx * 3;
+            e[0] = (uint8_t)scribbleColor; e[1] = (uint8_t)scribbleColor; e[2] = (uint8_t)scribbleColor;
+            scribble[(size_t)ty * scribblePitch + tx] = 255;
+        }
+}
+
+/* =====================================================================================
+ * a11  GPUSimulateDesaturation (K8) -- src/GPUDepthEffect.cu:8-27
+ * contracted variant: fma(f, gray, (1-f)*orig)   (left product fused, LLVM/NVVM order)
+ * ===================================================================================*/
+ORC_API void orc_desaturate(const uint8_t *orig, size_t origPitch, const uint8_t *gray, size_t grayPitch,
+                            const float *depth, size_t depthPitch, uint8_t *art, size_t artPitch,
+                            int rows, int cols, int contract) {
+    for (int y = 0; y < rows; y++) {
+        const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
+        for (int x = 0; x < cols; x++) {
+            float f = (float)((double)drow[x] / 255.0);                  /* :22 */
+            float g = (float)gray[(size_t)y * grayPitch + x];
+            for (int c = 0; c < 3; c++) {                                /* :23-25 */
+                float o = (float)orig[(size_t)y * origPitch + x * 3 + c];
+                float t = (1 - f) * o;
+                float v = contract ? fmaf(f, g, t) : f * g + t;
+                art[(size_t)y * artPitch + x * 3 + c] = sat_u8(v);
+            }
+        }
+    }
+}
+
+/* =====================================================================================
+ * a13  GPUSimulateDefocus (K9) -- src/GPUDepthEffect.cu:29-72 (literal O(k^2) gather)
+ * ===================================================================================*/
+ORC_API void orc_defocus(const uint8_t *orig, size_t origPitch, const float *depth, size_t depthPitch,
+                         uint8_t *art, size_t artPitch, int rows, int cols, int threads) {
+    int kernelSize = 0.025 * sqrtf(rows * rows + cols * cols);           /* :42 */
+    (void)threads;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads > 0 ? threads : 1)
+    for (int y = 0; y < rows; y++) {
+        const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
+        for (int x = 0; x < cols; x++) {
+            int k = kernelSize * drow[x] / 255.0;                        /* :43 int*float -> float, /double, trunc */
+            float sum[3] = {0, 0, 0};
+            int count = 0;
+            for (int py = y - k / 2; py < y + k / 2; py++)               /* :47-60 */
+                for (int px = x - k / 2; px < x + k / 2; px++)
+                    if (px >= 0 && py >= 0 && px < cols && py < rows) {
+                        const uint8_t *o = orig + (size_t)py * origPitch + px * 3;
+                        sum[0] += o[0]; sum[1] += o[1]; sum[2] += o[2];
+                        count++;
+                    }
+            uint8_t *a = art + (size_t)y * artPitch + x * 3;
+            const uint8_t *o = orig + (size_t)y * origPitch + x * 3;
+            if (count == 0) { a[0] = o[0]; a[1] = o[1]; a[2] = o[2]; }  /* :62-66 */
+            else { a[0] = sat_u8(sum[0] / count); a[1] = sat_u8(sum[1] / count); a[2] = sat_u8(sum[2] / count); }
+        }
+    }
+}
+
+/* =====================================================================================
+ * a12  GPUSimulateHaze (K10) -- src/GPUDepthEffect.cu:74-93
+ * expf here is host libm; the CUDA device expf (<= 2 ulp) is not reproducible anywhere.
+ * ===================================================================================*/
+ORC_API void orc_haze(const uint8_t *orig, size_t origPitch, const float *depth, size_t depthPitch,
+                      uint8_t *art, size_t artPitch, int rows, int cols, int contract) {
+    for (int y = 0; y < rows; y++) {
+        const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
+        for (int x = 0; x < cols; x++) {
+            float beta = 2;
+            float t = expf((float)((double)(-beta * drow[x]) / 255.0)); /* :88 */
+            for (int c = 0; c < 3; c++) {                                /* :89-91 */
+                float o = (float)orig[(size_t)y * origPitch + x * 3 + c];
+                float w = (1 - t) * 255;
+                float v = contract ? fmaf(t, o, w) : t * o + w;
+                art[(size_t)y * artPitch + x * 3 + c] = sat_u8(v);
+            }
+        }
+    }
+}
+
+/* =====================================================================================
+ * Extension oracles (NO reference behaviour): residual of the
+ * Jacobi fixed point, max over free pixels of |J(x) - x| with J = the clamped weighted mean.
+ * Used to pin the residual-stop / red-black / multigrid extensions.
+ * ===================================================================================*/
+ORC_API float orc_residual(const float *in, const int32_t *index2, const uint8_t *mask, size_t maskPitch,
+                           int rows, int cols, const float *lut, int contract) {
+    float worst = 0.0f;
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            if (mask[(size_t)y * maskPitch + x] == 255) continue;
+            size_t p = (size_t)y * cols + x;
+            float r = mean4(index2[2 * p] / 1000, index2[2 * p] % 1000, index2[2 * p + 1] / 1000,
+                            index2[2 * p + 1] % 1000, lut, in, x, y, cols, contract);
+            float d = fabsf(r - in[p]);
+            if (d > worst) worst = d;
+        }
+    return worst;
+}
+
+/* One red-black Gauss-Seidel sweep (extension): colour 0 = (x+y) even first, then colour 1,
+ * in place; x_i <- clamp(sum w x_j / sum w) for free pixels. */
+ORC_API void orc_rbgs_sweep(float *x, const int32_t *index2, const uint8_t *mask, size_t maskPitch,
+                            int rows, int cols, const float *lut, int contract) {
+    for (int colour = 0; colour < 2; colour++)
+        for (int y = 0; y < rows; y++)
+            for (int xx = (y + colour) & 1; xx < cols; xx += 2) {
+                if (mask[(size_t)y * maskPitch + xx] == 255) continue;
+                size_t p = (size_t)y * cols + xx;
+                x[p] = mean4(index2[2 * p] / 1000, index2[2 * p] % 1000, index2[2 * p + 1] / 1000,
+                             index2[2 * p + 1] % 1000, lut, x, xx, y, cols, contract);
+            }
+}
+
+ORC_API int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
