@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py -- solver-sweep throughput of the hot path on MI355X.
+
+A *step* is one GPUMatrixFreeSolver call (edge-weight pass + K sweeps + copy-back) on one
+synthetic image already resident in HBM.  Default workload = BASELINE.json configs[1]:
+a single 1920x1080 image, one pyramid level, exactly 1000 Chebyshev-Jacobi sweeps.
+With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank solves its own
+image of the same size (independent images shard with no collective; the only communication
+is the timing barrier and a MAX-reduce of the elapsed time), so scaling is weak.
+
+Prints ONE JSON line on rank 0; see the task contract for the fields.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "1080p_jacobi1000": dict(rows=1080, cols=1920, iters=1000),
+    "4k_jacobi1000": dict(rows=2160, cols=3840, iters=1000),
+    "8k_jacobi200": dict(rows=4320, cols=7680, iters=200),
+}
+ALGO_BYTES_PER_PX_ITER = 17.0          # x_k 4 + x_{k-1} 4 + x_{k+1} 4 + 4 weight indices 4 + mask 1
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(rows, cols, seconds_target=12.0):
+    """Oracle (CPU port of the reference kernels) on this box's host cores, bounded sample."""
+    import oracle
+    from realtimedepthdiffusion_amd.synth import make_problem
+    p = make_problem(rows, cols, seed=1234)
+    lut = oracle.load_weights(0.4)
+    threads = oracle.max_threads()
+    d = p["depth"].copy()
+    t = time.perf_counter(); oracle.solve(d, p["mask"], p["gray"], 4, 0, 0, lut, 1, threads=threads); per = (time.perf_counter() - t) / 4
+    n = int(max(8, min(400, seconds_target / max(per, 1e-6))))
+    d = p["depth"].copy()
+    t = time.perf_counter(); oracle.solve(d, p["mask"], p["gray"], n, 0, 0, lut, 1, threads=threads); el = time.perf_counter() - t
+    return {"value": rows * cols * n / el / 1e6, "unit": "Mpixel-iterations/s", "cores": threads, "kind": "port",
+            "sample": f"{n} sweeps of the same {cols}x{rows} problem (incl. the edge-weight pass), OpenMP over rows, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="1080p_jacobi1000", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep-kernel", type=int, default=0)
+    ap.add_argument("--temporal-depth", type=int, default=0)
+    ap.add_argument("--rows-per-wave", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=-1)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import realtimedepthdiffusion_amd as rt
+    from realtimedepthdiffusion_amd.synth import make_problem
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    w = WORKLOADS[args.workload]
+    rows, cols, iters = w["rows"], w["cols"], w["iters"]
+    p = make_problem(rows, cols, seed=1234 + rank)
+    dev = f"cuda:{local}"
+    ctx = rt.Context(local)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    ctx.GPULoadWeights(0.4)
+    if args.sweep_kernel: ctx.set_option(rt.OPT_SWEEP_KERNEL, args.sweep_kernel)
+    if args.temporal_depth: ctx.set_option(rt.OPT_TEMPORAL_DEPTH, args.temporal_depth)
+    if args.rows_per_wave: ctx.set_option(rt.OPT_ROWS_PER_WAVE, args.rows_per_wave)
+    if args.graph >= 0: ctx.set_option(rt.OPT_USE_GRAPH, args.graph)
+    mask = rt.device_image(p["mask"], dev); gray = rt.device_image(p["gray"], dev)
+    # one pristine initial-depth image per step, uploaded before the clock starts
+    depths = [rt.device_image(p["depth"], dev) for _ in range(args.steps + args.warmup)]
+
+    def step(i):
+        ctx.GPUMatrixFreeSolver(depths[i], mask, gray, rows, cols, 0.4, iters, 1e-5, 0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.profile_enable(True)               # HIP events around the sweep launches, on the launch stream
+    sweep_ms = 0.0; launches = 0; sweeps = 0
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+        pr = ctx.profile(); sweep_ms += pr.sweep_ms; launches += pr.launches; sweeps += pr.sweeps
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    px_iter_per_step = rows * cols * iters
+    value = world * args.steps * px_iter_per_step / elapsed / 1e6
+    launch_us = sweep_ms * 1e3 / max(launches, 1)
+    sweeps_per_launch = sweeps / max(launches, 1)
+    achieved = ALGO_BYTES_PER_PX_ITER * rows * cols * sweeps_per_launch / (launch_us * 1e-6) / 1e9
+    out = {
+        "metric": "Mpixel-iterations/s (solver sweep)", "value": value, "unit": "Mpixel-iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps "
+                               f"(BASELINE configs[1])" if args.workload == "1080p_jacobi1000" else args.workload,
+                   "images_per_step": world, "sweep_kernel": ctx.get_option(rt.OPT_SWEEP_KERNEL),
+                   "sweeps_per_launch": sweeps_per_launch},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "sweep", "launch_us": launch_us,
+                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX_ITER * rows * cols * sweeps_per_launch},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(rows, cols)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,236 @@
+"""realtimedepthdiffusion_amd -- host-side Python mirror of librtdd.so's C ABI.
+
+The product is the HIP library (csrc/ -> librtdd.so, declared in include/rtdd.h).  This
+module is plumbing: it loads the library with ctypes and mirrors the reference's interface
+for the hot path -- the ten ``GPU*`` functions of /root/reference/include/GPUSolver.h:6-10,
+GPUImageProcessing.h:4-10 and GPUDepthEffect.h:4-9 -- with the same names, argument order
+and meaning, so parity tests read like calls into the reference.  Image arguments are
+*pitched device buffers*: anything with ``data_ptr()`` and ``stride()`` (a torch CUDA tensor
+whose rows may be padded) or an explicit ``(ptr, pitch_bytes)`` pair.
+
+There is NO CPU fallback: if librtdd.so is missing or no HIP device is present every entry
+point raises.  Nothing here imports ``oracle``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librtdd.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+RTDD_OK = 0
+METHOD_CHEBYSHEV_JACOBI = 0
+METHOD_RED_BLACK_GS = 1
+OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, OPT_USE_GRAPH, OPT_ROWS_PER_WAVE = 0, 1, 2, 3, 4
+
+# every symbol include/rtdd.h declares (checked by tests/test_abi.py against the header)
+C_ABI_SYMBOLS = [
+    "rtdd_ctx_create", "rtdd_ctx_destroy", "rtdd_ctx_set_stream", "rtdd_ctx_synchronize", "rtdd_set_option",
+    "rtdd_get_option", "rtdd_last_error", "rtdd_status_string", "rtdd_version", "rtdd_allocate", "rtdd_free",
+    "rtdd_load_weights", "rtdd_matrix_free_solver", "rtdd_solve_ex", "rtdd_index_to_weight", "rtdd_convert_to_float",
+    "rtdd_pyrdown_annotation", "rtdd_paint_image", "rtdd_simulate_defocus", "rtdd_simulate_desaturation",
+    "rtdd_simulate_haze", "rtdd_profile_enable", "rtdd_profile_get",
+]
+# Itanium-mangled names of the reference's ten free functions
+DROPIN_SYMBOLS = [
+    "_Z23GPUAllocateDeviceMemoryiii", "_Z19GPUFreeDeviceMemoryi", "_Z14GPULoadWeightsf",
+    "_Z19GPUMatrixFreeSolverPfmPhmS0_miififi", "_Z17GPUConvertToFloatPhmPfmS_mii",
+    "_Z20GPUPyrDownAnnotationPhmS_miiS_mS_mii", "_Z13GPUPaintImageiiiiPhmS_mii",
+    "_Z18GPUSimulateDefocusPhmPfmS_mii", "_Z23GPUSimulateDesaturationPhmS_mPfmS_mii", "_Z15GPUSimulateHazePhmPfmS_mii",
+]
+
+
+class RtddError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"rtdd status {status}: {message}")
+        self.status = status
+
+
+class SolveParams(C.Structure):
+    _fields_ = [("method", C.c_int), ("maxIterations", C.c_int), ("tolerance", C.c_float), ("checkEvery", C.c_int)]
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("residual", C.c_float)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("sweep_ms", C.c_double), ("launches", C.c_int), ("sweeps", C.c_int),
+                ("prepare_ms", C.c_double), ("finish_ms", C.c_double)]
+
+
+def build(force=False):
+    """Compile librtdd.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    """The loaded librtdd.so.  Raises (never falls back) when the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise RtddError(-1, f"{_SO} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(there is no CPU fallback)")
+        L = C.CDLL(_SO)
+        L.rtdd_last_error.restype = C.c_char_p
+        L.rtdd_status_string.restype = C.c_char_p
+        for name in C_ABI_SYMBOLS:
+            getattr(L, name)        # fail at load time, not at first use, if a symbol is missing
+        _lib = L
+    return _lib
+
+
+def _img(t):
+    """(pointer, pitch in bytes) of a pitched device image."""
+    if isinstance(t, tuple):
+        return C.c_void_p(t[0]), C.c_size_t(t[1])
+    assert t.stride(-1) == 1 or (t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.shape[2]), "pixels must be contiguous within a row"
+    return C.c_void_p(t.data_ptr()), C.c_size_t(t.stride(0) * t.element_size())
+
+
+class Context:
+    """One solver context per GPU (handle of the C ABI).  Methods carry the reference's names."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        rc = lib().rtdd_ctx_create(C.c_int(device), C.byref(self._h))
+        if rc != RTDD_OK:
+            raise RtddError(rc, lib().rtdd_status_string(rc).decode())
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().rtdd_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != RTDD_OK:
+            raise RtddError(rc, lib().rtdd_status_string(rc).decode() + " -- " + lib().rtdd_last_error(self._h).decode())
+
+    # ---- context plumbing
+    def set_stream(self, stream):
+        """stream: a raw hipStream_t value (e.g. torch.cuda.current_stream().cuda_stream) or 0."""
+        self._check(lib().rtdd_ctx_set_stream(self._h, C.c_void_p(int(stream))))
+
+    def synchronize(self):
+        self._check(lib().rtdd_ctx_synchronize(self._h))
+
+    def set_option(self, key, value):
+        self._check(lib().rtdd_set_option(self._h, C.c_int(key), C.c_int(value)))
+
+    def get_option(self, key):
+        v = C.c_int()
+        self._check(lib().rtdd_get_option(self._h, C.c_int(key), C.byref(v)))
+        return v.value
+
+    def profile_enable(self, on=True):
+        self._check(lib().rtdd_profile_enable(self._h, C.c_int(1 if on else 0)))
+
+    def profile(self):
+        p = Profile()
+        self._check(lib().rtdd_profile_get(self._h, C.byref(p)))
+        return p
+
+    # ---- include/GPUSolver.h
+    def GPUAllocateDeviceMemory(self, rows, cols, levels):
+        self._check(lib().rtdd_allocate(self._h, C.c_int(rows), C.c_int(cols), C.c_int(levels)))
+
+    def GPUFreeDeviceMemory(self, levels=0):
+        self._check(lib().rtdd_free(self._h))
+
+    def GPULoadWeights(self, beta):
+        self._check(lib().rtdd_load_weights(self._h, C.c_float(beta)))
+
+    def GPUMatrixFreeSolver(self, depthImage, scribbleImage, grayImage, rows, cols, beta, maxIterations, tolerance, level):
+        dp, dpitch = _img(depthImage); sp, spitch = _img(scribbleImage); gp, gpitch = _img(grayImage)
+        self._check(lib().rtdd_matrix_free_solver(self._h, dp, dpitch, sp, spitch, gp, gpitch, C.c_int(rows), C.c_int(cols),
+                                                  C.c_float(beta), C.c_int(maxIterations), C.c_float(tolerance), C.c_int(level)))
+
+    def solve_ex(self, depthImage, scribbleImage, grayImage, rows, cols, level, method=METHOD_CHEBYSHEV_JACOBI,
+                 maxIterations=1000, tolerance=0.0, checkEvery=0):
+        dp, dpitch = _img(depthImage); sp, spitch = _img(scribbleImage); gp, gpitch = _img(grayImage)
+        params = SolveParams(method, maxIterations, tolerance, checkEvery)
+        info = SolveInfo()
+        self._check(lib().rtdd_solve_ex(self._h, dp, dpitch, sp, spitch, gp, gpitch, C.c_int(rows), C.c_int(cols), C.c_int(level),
+                                        C.byref(params), C.byref(info)))
+        return info.iterations, info.residual
+
+    def index_to_weight(self, grayImage, depthImage, index2, level, rows, cols):
+        gp, gpitch = _img(grayImage); dp, dpitch = _img(depthImage)
+        self._check(lib().rtdd_index_to_weight(self._h, gp, gpitch, dp, dpitch, C.c_void_p(index2.data_ptr()), C.c_int(level),
+                                               C.c_int(rows), C.c_int(cols)))
+
+    # ---- include/GPUImageProcessing.h
+    def GPUConvertToFloat(self, src, dst, mask, rows, cols):
+        s, sp = _img(src); d, dp = _img(dst); m, mp = _img(mask)
+        self._check(lib().rtdd_convert_to_float(self._h, s, sp, d, dp, m, mp, C.c_int(rows), C.c_int(cols)))
+
+    def GPUPyrDownAnnotation(self, prevScribbleImage, prevEditedImage, previousRows, previousCols,
+                             currScribbleImage, currEditedImage, currentRows, currentCols):
+        a, ap = _img(prevScribbleImage); b, bp = _img(prevEditedImage); c, cp = _img(currScribbleImage); d, dp = _img(currEditedImage)
+        self._check(lib().rtdd_pyrdown_annotation(self._h, a, ap, b, bp, C.c_int(previousRows), C.c_int(previousCols),
+                                                  c, cp, d, dp, C.c_int(currentRows), C.c_int(currentCols)))
+
+    def GPUPaintImage(self, x, y, scribbleColor, scribbleRadius, editedImage, scribbleImage, rows, cols):
+        e, ep = _img(editedImage); s, sp = _img(scribbleImage)
+        self._check(lib().rtdd_paint_image(self._h, C.c_int(x), C.c_int(y), C.c_int(scribbleColor), C.c_int(scribbleRadius),
+                                           e, ep, s, sp, C.c_int(rows), C.c_int(cols)))
+
+    # ---- include/GPUDepthEffect.h
+    def GPUSimulateDefocus(self, originalImage, depthImage, artisticImage, rows, cols):
+        o, op = _img(originalImage); d, dp = _img(depthImage); a, ap = _img(artisticImage)
+        self._check(lib().rtdd_simulate_defocus(self._h, o, op, d, dp, a, ap, C.c_int(rows), C.c_int(cols)))
+
+    def GPUSimulateDesaturation(self, originalImage, grayImage, depthImage, artisticImage, rows, cols):
+        o, op = _img(originalImage); g, gp = _img(grayImage); d, dp = _img(depthImage); a, ap = _img(artisticImage)
+        self._check(lib().rtdd_simulate_desaturation(self._h, o, op, g, gp, d, dp, a, ap, C.c_int(rows), C.c_int(cols)))
+
+    def GPUSimulateHaze(self, originalImage, depthImage, artisticImage, rows, cols):
+        o, op = _img(originalImage); d, dp = _img(depthImage); a, ap = _img(artisticImage)
+        self._check(lib().rtdd_simulate_haze(self._h, o, op, d, dp, a, ap, C.c_int(rows), C.c_int(cols)))
+
+
+# ---- pitched device images (torch is plumbing for device memory only) ----------------------------
+def device_image(host, device="cuda:0", align=512):
+    """Upload a numpy image [rows, cols] or [rows, cols, 3] into a PITCHED device tensor whose row
+    stride is padded to `align` bytes, like cudaMallocPitch / cv::cuda::GpuMat in the reference
+    (/root/reference/src/main.cpp:117-137).  Returns the logical view (use .stride(0) for the pitch)."""
+    import numpy as np
+    import torch
+    host = np.ascontiguousarray(host)
+    rows = host.shape[0]
+    row_elems = int(np.prod(host.shape[1:]))
+    item = host.itemsize
+    pitch_elems = ((row_elems * item + align - 1) // align * align) // item
+    base = torch.zeros((rows, pitch_elems), dtype=torch.from_numpy(host[:0]).dtype, device=device)
+    view = base[:, :row_elems]
+    view.copy_(torch.from_numpy(host.reshape(rows, row_elems)).to(device))
+    if host.ndim == 3:
+        view = view.unflatten(1, host.shape[1:])
+    return view
+
+
+def to_host(view):
+    return view.cpu().contiguous().numpy()

@@ -1,0 +1,400 @@
+// api.cpp -- the extern "C" surface of librtdd.so (include/rtdd.h): context management, argument
+// validation, the per-level solve driver (GPUMatrixFreeSolver, /root/reference/src/GPUSolver.cu:274-316)
+// and thin forwards to the kernel launchers.  Host code only; kernels live in the *.hip files.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "rtdd_internal.hpp"
+
+namespace rtdd {
+
+int fail(rtdd_ctx *ctx, int status, const char *what, hipError_t e) {
+    if (ctx) {
+        ctx->last_error = what ? what : "";
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return status;
+}
+
+// omega recurrence of the reference driver (src/GPUSolver.cu:282-299): float state, double
+// intermediates, S = 10, rho = 0.99f.
+void omega_schedule(int n, std::vector<float> &out) {
+    out.resize(n > 0 ? n : 0);
+    const int S = 10;
+    float omega = 0.0f;
+    const float rho = 0.99;
+    for (int it = 0; it < n; it++) {
+        if (it < S) omega = 1;
+        else if (it == S) omega = 2.0 / (2.0 - rho * rho);
+        else omega = 4.0 / (4.0 - rho * rho * omega);
+        out[it] = omega;
+    }
+}
+
+static void free_levels(rtdd_ctx *ctx) {
+    for (auto &L : ctx->levels) {
+        for (auto &p : L.plane)
+            if (p) { (void)hipFree(p); p = nullptr; }
+        if (L.meta) { (void)hipFree(L.meta); L.meta = nullptr; }
+    }
+    ctx->levels.clear();
+    ctx->maxLevel = -1;
+}
+
+}  // namespace rtdd
+
+using namespace rtdd;
+
+#define REQUIRE(ctx, cond, msg) \
+    do { if (!(cond)) return fail((ctx), RTDD_ERR_INVALID, msg); } while (0)
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int rtdd_version(void) { return 100; }
+
+const char *rtdd_status_string(int s) {
+    switch (s) {
+        case RTDD_OK: return "ok";
+        case RTDD_ERR_INVALID: return "invalid argument";
+        case RTDD_ERR_STATE: return "call order violated";
+        case RTDD_ERR_HIP: return "HIP runtime error";
+        case RTDD_ERR_NOMEM: return "out of memory";
+        case RTDD_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+        default: return "unknown status";
+    }
+}
+
+const char *rtdd_last_error(rtdd_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int rtdd_ctx_create(int device, rtdd_ctx **out) {
+    if (!out) return RTDD_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RTDD_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return RTDD_ERR_INVALID;
+    rtdd_ctx *ctx = new (std::nothrow) rtdd_ctx();
+    if (!ctx) return RTDD_ERR_NOMEM;
+    ctx->device = device;
+    DeviceGuard g(device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    bool ok = hipMalloc((void **)&ctx->lut_dev, 257 * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&ctx->residual_dev, 64) == hipSuccess;
+    for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (!ok) { rtdd_ctx_destroy(ctx); return RTDD_ERR_HIP; }
+    *out = ctx;
+    return RTDD_OK;
+}
+
+int rtdd_ctx_destroy(rtdd_ctx *ctx) {
+    if (!ctx) return RTDD_OK;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_levels(ctx);
+    if (ctx->lut_dev) (void)hipFree(ctx->lut_dev);
+    if (ctx->omega_dev) (void)hipFree(ctx->omega_dev);
+    if (ctx->residual_dev) (void)hipFree(ctx->residual_dev);
+    if (ctx->sat) (void)hipFree(ctx->sat);
+    for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    delete ctx;
+    return RTDD_OK;
+}
+
+int rtdd_ctx_set_stream(rtdd_ctx *ctx, rtdd_stream stream) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    ctx->stream = (hipStream_t)stream;
+    return RTDD_OK;
+}
+
+int rtdd_ctx_synchronize(rtdd_ctx *ctx) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTDD_OK;
+}
+
+int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    switch (key) {
+        case RTDD_OPT_FP_CONTRACT: ctx->opt.fp_contract = value ? 1 : 0; break;
+        case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 2, "sweep kernel must be 0..2"); ctx->opt.sweep_kernel = value; break;
+        case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 64, "temporal depth must be 0..64"); ctx->opt.temporal_depth = value; break;
+        case RTDD_OPT_USE_GRAPH: ctx->opt.use_graph = value ? 1 : 0; break;
+        case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
+        default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
+    }
+    return RTDD_OK;
+}
+
+int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
+    if (!ctx || !value) return RTDD_ERR_INVALID;
+    switch (key) {
+        case RTDD_OPT_FP_CONTRACT: *value = ctx->opt.fp_contract; break;
+        case RTDD_OPT_SWEEP_KERNEL: *value = ctx->opt.sweep_kernel; break;
+        case RTDD_OPT_TEMPORAL_DEPTH: *value = ctx->opt.temporal_depth; break;
+        case RTDD_OPT_USE_GRAPH: *value = ctx->opt.use_graph; break;
+        case RTDD_OPT_ROWS_PER_WAVE: *value = ctx->opt.rows_per_wave; break;
+        default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
+    }
+    return RTDD_OK;
+}
+
+int rtdd_profile_enable(rtdd_ctx *ctx, int on) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    ctx->profile_on = on != 0;
+    return RTDD_OK;
+}
+
+int rtdd_profile_get(rtdd_ctx *ctx, rtdd_profile *out) {
+    if (!ctx || !out) return RTDD_ERR_INVALID;
+    *out = ctx->prof;
+    return RTDD_OK;
+}
+
+// ---- solver ------------------------------------------------------------------------------------
+
+int rtdd_allocate(rtdd_ctx *ctx, int rows, int cols, int levels) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, rows > 0 && cols > 0 && levels > 0 && levels <= 30, "rows, cols, levels must be positive");
+    DeviceGuard g(ctx->device);
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_levels(ctx);
+    ctx->levels.resize(levels);
+    for (int l = 0; l < levels; l++) {
+        Level &L = ctx->levels[l];
+        L.rows = (int)(rows / powf(2, l));          // src/GPUSolver.cu:42-43 (float divide, truncation)
+        L.cols = (int)(cols / powf(2, l));
+        L.elems = plane_elems(L.rows > 0 ? L.rows : 1, L.cols > 0 ? L.cols : 1);
+        for (auto &p : L.plane) {
+            hipError_t e = hipMalloc((void **)&p, L.elems * sizeof(float));
+            if (e != hipSuccess) { free_levels(ctx); return fail(ctx, e == hipErrorOutOfMemory ? RTDD_ERR_NOMEM : RTDD_ERR_HIP, "hipMalloc(plane)", e); }
+        }
+        hipError_t e = hipMalloc((void **)&L.meta, L.elems * sizeof(uint32_t));
+        if (e != hipSuccess) { free_levels(ctx); return fail(ctx, e == hipErrorOutOfMemory ? RTDD_ERR_NOMEM : RTDD_ERR_HIP, "hipMalloc(meta)", e); }
+        // guard cells are read (never used); give them a defined value once
+        for (auto &p : L.plane) RTDD_HIP(ctx, hipMemsetAsync(p, 0, L.elems * sizeof(float), ctx->stream));
+        RTDD_HIP(ctx, hipMemsetAsync(L.meta, 0, L.elems * sizeof(uint32_t), ctx->stream));
+    }
+    ctx->maxLevel = levels - 1;                    // :51
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the reference syncs here (:52)
+    return RTDD_OK;
+}
+
+int rtdd_free(rtdd_ctx *ctx) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_levels(ctx);
+    return RTDD_OK;
+}
+
+int rtdd_load_weights(rtdd_ctx *ctx, float beta) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    for (int w = 0; w < 256; w++) ctx->lut_host[w] = expf(-beta * w);      // src/GPUSolver.cu:267, host libm
+    ctx->lut_host[256] = 0;
+    RTDD_HIP(ctx, hipMemcpyAsync(ctx->lut_dev, ctx->lut_host, sizeof(ctx->lut_host), hipMemcpyHostToDevice, ctx->stream));
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));                      // lut_host may be rewritten by the next call
+    ctx->weights_loaded = true;
+    return RTDD_OK;
+}
+
+static int check_solve_args(rtdd_ctx *ctx, const float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
+                            const uint8_t *gray, size_t grayPitch, int rows, int cols, int level) {
+    REQUIRE(ctx, depth && scribble && gray, "null image pointer");
+    REQUIRE(ctx, rows > 0 && cols > 0, "rows and cols must be positive");
+    REQUIRE(ctx, depthPitch >= (size_t)cols * sizeof(float) && depthPitch % sizeof(float) == 0, "depth pitch too small or not a multiple of 4");
+    REQUIRE(ctx, scribblePitch >= (size_t)cols && grayPitch >= (size_t)cols, "u8 pitch smaller than a row");
+    if (ctx->levels.empty()) return fail(ctx, RTDD_ERR_STATE, "rtdd_allocate has not been called");
+    if (!ctx->weights_loaded) return fail(ctx, RTDD_ERR_STATE, "rtdd_load_weights has not been called");
+    REQUIRE(ctx, level >= 0 && level < (int)ctx->levels.size(), "level out of range");
+    const Level &L = ctx->levels[level];
+    REQUIRE(ctx, plane_elems(rows, cols) <= L.elems, "rows x cols exceeds the level's allocation");
+    return RTDD_OK;
+}
+
+int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
+                  const uint8_t *gray, size_t grayPitch, int rows, int cols, int level,
+                  const rtdd_solve_params *params, rtdd_solve_info *info) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, params != nullptr, "null params");
+    REQUIRE(ctx, params->maxIterations >= 0, "maxIterations must be >= 0");
+    REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS, "unknown method");
+    int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
+    if (rc != RTDD_OK) return rc;
+    DeviceGuard g(ctx->device);
+    const Level &L = ctx->levels[level];
+    const size_t ip = plane_pitch(cols);
+    const bool prof = ctx->profile_on;
+    ctx->prof = rtdd_profile{};
+
+    if (prof) RTDD_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    rc = launch_prepare(ctx, L, ip, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
+    if (rc != RTDD_OK) return rc;
+    if (prof) RTDD_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+
+    const bool stop_on_residual = params->tolerance > 0.0f;
+    const int every = params->checkEvery > 0 ? params->checkEvery : 16;
+    int done = 0, result_plane = 0, launches = 0;
+    float residual = NAN;
+
+    if (params->method == RTDD_METHOD_CHEBYSHEV_JACOBI) {
+        std::vector<float> omegas;
+        omega_schedule(params->maxIterations, omegas);
+        if (!stop_on_residual) {
+            rc = launch_sweeps(ctx, L, ip, rows, cols, omegas.data(), params->maxIterations, &result_plane, &launches);
+            if (rc != RTDD_OK) return rc;
+            done = params->maxIterations;
+        } else {
+            // chunks of `every` sweeps; the plane roles continue across chunks because a chunk of
+            // even length returns to plane 0 and odd chunks only occur at the tail
+            const int chunk = every + (every & 1);
+            while (done < params->maxIterations) {
+                int n = params->maxIterations - done < chunk ? params->maxIterations - done : chunk;
+                int rp = 0, ln = 0;
+                rc = launch_sweeps(ctx, L, ip, rows, cols, omegas.data() + done, n, &rp, &ln);
+                if (rc != RTDD_OK) return rc;
+                done += n; launches += ln; result_plane = rp;
+                rc = launch_residual(ctx, L, ip, result_plane, rows, cols, &residual);
+                if (rc != RTDD_OK) return rc;
+                if (residual <= params->tolerance) break;
+            }
+        }
+    } else {
+        const int chunk = stop_on_residual ? every : (params->maxIterations > 0 ? params->maxIterations : 1);
+        while (done < params->maxIterations) {
+            int n = params->maxIterations - done < chunk ? params->maxIterations - done : chunk;
+            rc = launch_rbgs(ctx, L, ip, 0, rows, cols, n);
+            if (rc != RTDD_OK) return rc;
+            done += n; launches += 2 * n;
+            if (stop_on_residual) {
+                rc = launch_residual(ctx, L, ip, 0, rows, cols, &residual);
+                if (rc != RTDD_OK) return rc;
+                if (residual <= params->tolerance) break;
+            }
+        }
+        result_plane = 0;
+    }
+
+    if (prof) RTDD_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    rc = launch_finish(ctx, L, ip, result_plane, depth, depthPitch, rows, cols);
+    if (rc != RTDD_OK) return rc;
+    if (prof) {
+        RTDD_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        RTDD_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+        float a = 0, b = 0, c = 0;
+        RTDD_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+        RTDD_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+        RTDD_HIP(ctx, hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]));
+        ctx->prof.prepare_ms = a; ctx->prof.sweep_ms = b; ctx->prof.finish_ms = c;
+        ctx->prof.launches = launches; ctx->prof.sweeps = done;
+    }
+    if (info) { info->iterations = done; info->residual = residual; }
+    return RTDD_OK;
+}
+
+int rtdd_matrix_free_solver(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
+                            const uint8_t *gray, size_t grayPitch, int rows, int cols, float beta, int maxIterations,
+                            float tolerance, int level) {
+    (void)beta; (void)tolerance;                   // ignored by the reference too (src/GPUSolver.cu:274-275)
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (maxIterations < 0) maxIterations = 0;      // the reference's loop simply does not run (:295)
+    rtdd_solve_params p;
+    p.method = RTDD_METHOD_CHEBYSHEV_JACOBI; p.maxIterations = maxIterations; p.tolerance = 0.0f; p.checkEvery = 0;
+    return rtdd_solve_ex(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, &p, nullptr);
+}
+
+int rtdd_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch, const float *depth, size_t depthPitch,
+                         int32_t *index2, int level, int rows, int cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, gray && depth && index2, "null pointer");
+    REQUIRE(ctx, rows > 0 && cols > 0 && grayPitch >= (size_t)cols && depthPitch >= (size_t)cols * 4, "bad size or pitch");
+    if (ctx->maxLevel < 0) return fail(ctx, RTDD_ERR_STATE, "rtdd_allocate has not been called (maxLevel unknown)");
+    DeviceGuard g(ctx->device);
+    return launch_index_to_weight(ctx, gray, grayPitch, depth, depthPitch, index2, level, rows, cols);
+}
+
+// ---- image processing ---------------------------------------------------------------------------
+
+int rtdd_convert_to_float(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, float *dst, size_t dstPitch,
+                          const uint8_t *mask, size_t maskPitch, int rows, int cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, src && dst && mask, "null image pointer");
+    REQUIRE(ctx, rows >= 0 && cols >= 0, "negative size");
+    if (rows == 0 || cols == 0) return RTDD_OK;
+    REQUIRE(ctx, srcPitch >= (size_t)cols * 3 && dstPitch >= (size_t)cols * 4 && maskPitch >= (size_t)cols, "pitch smaller than a row");
+    DeviceGuard g(ctx->device);
+    return launch_convert(ctx, src, srcPitch, dst, dstPitch, mask, maskPitch, rows, cols);
+}
+
+int rtdd_pyrdown_annotation(rtdd_ctx *ctx, const uint8_t *prevScribble, size_t prevScribblePitch, const uint8_t *prevEdited,
+                            size_t prevEditedPitch, int previousRows, int previousCols, uint8_t *currScribble,
+                            size_t currScribblePitch, uint8_t *currEdited, size_t currEditedPitch, int currentRows, int currentCols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, prevScribble && prevEdited && currScribble && currEdited, "null image pointer");
+    REQUIRE(ctx, previousRows >= 0 && previousCols >= 0 && currentRows >= 0 && currentCols >= 0, "negative size");
+    if (currentRows == 0 || currentCols == 0) return RTDD_OK;
+    REQUIRE(ctx, prevScribblePitch >= (size_t)previousCols && prevEditedPitch >= (size_t)previousCols * 3 &&
+                 currScribblePitch >= (size_t)currentCols && currEditedPitch >= (size_t)currentCols * 3, "pitch smaller than a row");
+    DeviceGuard g(ctx->device);
+    return launch_pyrdown_annotation(ctx, prevScribble, prevScribblePitch, prevEdited, prevEditedPitch, previousRows, previousCols,
+                                     currScribble, currScribblePitch, currEdited, currEditedPitch, currentRows, currentCols);
+}
+
+int rtdd_paint_image(rtdd_ctx *ctx, int x, int y, int scribbleColor, int scribbleRadius, uint8_t *edited, size_t editedPitch,
+                     uint8_t *scribble, size_t scribblePitch, int rows, int cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, edited && scribble, "null image pointer");
+    REQUIRE(ctx, rows >= 0 && cols >= 0, "negative size");
+    if (rows == 0 || cols == 0) return RTDD_OK;
+    REQUIRE(ctx, editedPitch >= (size_t)cols * 3 && scribblePitch >= (size_t)cols, "pitch smaller than a row");
+    DeviceGuard g(ctx->device);
+    return launch_paint(ctx, x, y, scribbleColor, scribbleRadius, edited, editedPitch, scribble, scribblePitch, rows, cols);
+}
+
+// ---- depth effects -------------------------------------------------------------------------------
+
+static int check_effect(rtdd_ctx *ctx, const void *a, const void *b, const void *c, size_t op, size_t dp, size_t ap, int rows, int cols) {
+    REQUIRE(ctx, a && b && c, "null image pointer");
+    REQUIRE(ctx, rows >= 0 && cols >= 0, "negative size");
+    REQUIRE(ctx, (long long)rows * rows + (long long)cols * cols < 2147483647LL, "image too large");
+    REQUIRE(ctx, op >= (size_t)cols * 3 && ap >= (size_t)cols * 3 && dp >= (size_t)cols * 4, "pitch smaller than a row");
+    return RTDD_OK;
+}
+
+int rtdd_simulate_defocus(rtdd_ctx *ctx, const uint8_t *original, size_t originalPitch, const float *depth, size_t depthPitch,
+                          uint8_t *artistic, size_t artisticPitch, int rows, int cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    int rc = check_effect(ctx, original, depth, artistic, originalPitch, depthPitch, artisticPitch, rows, cols);
+    if (rc != RTDD_OK || rows == 0 || cols == 0) return rc;
+    REQUIRE(ctx, original != artistic, "defocus cannot run in place");
+    DeviceGuard g(ctx->device);
+    return launch_defocus(ctx, original, originalPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+}
+
+int rtdd_simulate_desaturation(rtdd_ctx *ctx, const uint8_t *original, size_t originalPitch, const uint8_t *gray, size_t grayPitch,
+                               const float *depth, size_t depthPitch, uint8_t *artistic, size_t artisticPitch, int rows, int cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    int rc = check_effect(ctx, original, depth, artistic, originalPitch, depthPitch, artisticPitch, rows, cols);
+    if (rc != RTDD_OK || rows == 0 || cols == 0) return rc;
+    REQUIRE(ctx, gray && grayPitch >= (size_t)cols, "bad gray image");
+    DeviceGuard g(ctx->device);
+    return launch_desaturate(ctx, original, originalPitch, gray, grayPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+}
+
+int rtdd_simulate_haze(rtdd_ctx *ctx, const uint8_t *original, size_t originalPitch, const float *depth, size_t depthPitch,
+                       uint8_t *artistic, size_t artisticPitch, int rows, int cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    int rc = check_effect(ctx, original, depth, artistic, originalPitch, depthPitch, artisticPitch, rows, cols);
+    if (rc != RTDD_OK || rows == 0 || cols == 0) return rc;
+    DeviceGuard g(ctx->device);
+    return launch_haze(ctx, original, originalPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,132 @@
+// rtdd_internal.hpp -- private declarations shared by the translation units of librtdd.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "rtdd.h"
+
+namespace rtdd {
+
+// ---- internal plane geometry ------------------------------------------------------------------
+// Solver state lives in dense private planes (x_k, x_{k-1}/x_{k+1}, packed per-pixel metadata),
+// NOT in the caller's pitched buffers.  A plane has `ip` elements per row with at least
+// kGuardCols unused elements after the last image column (they double as the left guard of the
+// next row) and kGuardRows unused rows before row 0 and after the last row, so stencil/halo
+// loads never need bounds checks on the ADDRESS -- only on whether the value is used.
+constexpr int kGuardRows = 16;
+constexpr int kGuardCols = 64;
+constexpr int kRowAlign = 64;       // ip is a multiple of 64 elements = 256 B
+
+inline size_t plane_pitch(int cols) { return (size_t)((cols + kRowAlign - 1) / kRowAlign) * kRowAlign + kGuardCols; }
+inline size_t plane_elems(int rows, int cols) { return plane_pitch(cols) * (size_t)(rows + 2 * kGuardRows) + 1024; }
+
+// packed per-pixel metadata: bits 0-7 edge-weight index to the RIGHT neighbour, 8-15 index to the
+// neighbour BELOW, bit 16 = Dirichlet (scribble == 255).  Left/up indices are the right/down
+// indices of the left/upper neighbour (|a-b| and the depth gate are symmetric,
+// /root/reference/src/GPUSolver.cu:188-218); "no neighbour" (256) follows from coordinates.
+constexpr uint32_t kMetaDirichlet = 1u << 16;
+
+struct Level {
+    int rows = 0, cols = 0;         // allocation size (upper bound for solve calls)
+    size_t elems = 0;               // elements per plane
+    float *plane[4] = {nullptr, nullptr, nullptr, nullptr};   // raw allocations (4 f32 planes)
+    uint32_t *meta = nullptr;
+    // views at row 0 (after the guard rows)
+    float *P(int i, size_t ip) const { return plane[i] + (size_t)kGuardRows * ip; }
+    uint32_t *M(size_t ip) const { return meta + (size_t)kGuardRows * ip; }
+};
+
+struct Options {
+    int fp_contract = 1;
+    int sweep_kernel = 0;
+    int temporal_depth = 0;
+    int use_graph = 0;
+    int rows_per_wave = 0;
+};
+
+}  // namespace rtdd
+
+struct rtdd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<rtdd::Level> levels;
+    int maxLevel = -1;
+    bool weights_loaded = false;
+    float lut_host[257];
+    float *lut_dev = nullptr;
+    float *omega_dev = nullptr;     // device copy of the omega schedule (temporally blocked kernel)
+    int omega_cap = 0;
+    float *residual_dev = nullptr;  // extension: residual reduction target
+    uint32_t *sat = nullptr;        // defocus summed-area table scratch
+    size_t sat_elems = 0;
+    int num_cus = 256;
+    rtdd::Options opt;
+    bool profile_on = false;
+    rtdd_profile prof{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string last_error;
+};
+
+namespace rtdd {
+
+int fail(rtdd_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
+
+#define RTDD_HIP(ctx, call)                                                        \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) return ::rtdd::fail((ctx), RTDD_ERR_HIP, #call, e_); \
+    } while (0)
+
+#define RTDD_LAUNCH_CHECK(ctx, name)                                                     \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) return ::rtdd::fail((ctx), RTDD_ERR_HIP, "launch " name, e_); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// ---- solver_kernels.hip -------------------------------------------------------------------------
+int launch_prepare(rtdd_ctx *ctx, const Level &L, size_t ip, const float *depth, size_t depthPitch,
+                   const uint8_t *scribble, size_t scribblePitch, const uint8_t *gray, size_t grayPitch,
+                   int rows, int cols, int level);
+int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas, int n,
+                  int *result_plane, int *launches);
+int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols);
+int launch_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch, const float *depth, size_t depthPitch,
+                           int32_t *index2, int level, int rows, int cols);
+int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, float *host_out);
+int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps);
+
+// ---- image_kernels.hip --------------------------------------------------------------------------
+int launch_convert(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, float *dst, size_t dstPitch,
+                   const uint8_t *mask, size_t maskPitch, int rows, int cols);
+int launch_pyrdown_annotation(rtdd_ctx *ctx, const uint8_t *ps, size_t psp, const uint8_t *pe, size_t pep, int prows, int pcols,
+                              uint8_t *cs, size_t csp, uint8_t *ce, size_t cep, int crows, int ccols);
+int launch_paint(rtdd_ctx *ctx, int x, int y, int color, int radius, uint8_t *edited, size_t editedPitch,
+                 uint8_t *scribble, size_t scribblePitch, int rows, int cols);
+
+// ---- effect_kernels.hip -------------------------------------------------------------------------
+int launch_desaturate(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const uint8_t *gray, size_t gp, const float *depth, size_t dp,
+                      uint8_t *art, size_t ap, int rows, int cols);
+int launch_haze(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *depth, size_t dp, uint8_t *art, size_t ap, int rows, int cols);
+int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *depth, size_t dp, uint8_t *art, size_t ap, int rows, int cols);
+
+// the reference's host-side omega recurrence (src/GPUSolver.cu:282-299)
+void omega_schedule(int n, std::vector<float> &out);
+
+}  // namespace rtdd

@@ -1,0 +1,356 @@
+// solver_kernels.hip -- gfx950 kernels of the diffusion solve.
+//
+// What the reference does per level (/root/reference/src/GPUSolver.cu:290-312): memset prev,
+// two pitched->dense copies, the edge-weight index pass, maxIterations one-sweep launches on
+// 16x16 blocks moving 25 B per pixel-sweep, one dense->pitched copy.  What this file does:
+//
+//   k_prepare   one pass: depth -> x_0 plane, x_{-1} plane (0 on free pixels), and ONE packed
+//               u32 of metadata per pixel (right/down weight index + Dirichlet bit).
+//   k_sweep1    one Chebyshev-Jacobi sweep per launch.  A wave owns a 256-pixel-wide column
+//               strip and walks R rows with a 3-row register window: every x_k row is fetched
+//               once per wave as one 1-KiB dwordx4 instruction, x_{k-1} is read and x_{k+1}
+//               written IN PLACE in the same plane (each pixel touches only its own slot), so a
+//               sweep moves 16 B per pixel (4 x_k + 4 x_{k-1} + 4 x_{k+1} + 4 meta).  The 257-
+//               entry weight LUT sits in LDS (divergent gathers are cheap there; the reference's
+//               __constant__ reads would serialise on AMD's scalar cache).
+//   k_finish    result plane -> caller's pitched buffer.
+//
+// Arithmetic is op-for-op that of oracle/rtdd_oracle.c (same order, same roundings, explicit
+// fmaf only in the contracted variant; the file is compiled with -ffp-contract=off), which is
+// what makes GPU-vs-oracle parity bit-exact rather than merely within 1e-4.
+#include "rtdd_internal.hpp"
+
+namespace rtdd {
+
+__device__ __forceinline__ int sat_u8_dev(float v) {
+    // defined behaviour for the reference's out-of-range float->uchar casts: saturate, then truncate
+    if (!(v >= 0.0f)) return 0;
+    if (v >= 255.0f) return 255;
+    return (int)v;
+}
+
+__device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
+
+// ------------------------------------------------------------------------------------------------
+// k_prepare: edge-weight indices (src/GPUSolver.cu:183-222) + staging (:290-292), fused.
+// gated = (level != maxLevel); thr = (level == 0) ? 0 : 4   (:201-202)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prepare(const float *__restrict__ depth, size_t depthPitch,
+                                                 const uint8_t *__restrict__ scribble, size_t scribblePitch,
+                                                 const uint8_t *__restrict__ gray, size_t grayPitch,
+                                                 float *__restrict__ X0, float *__restrict__ X1,
+                                                 uint32_t *__restrict__ M, int ip, int rows, int cols, int gated, int thr) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
+    const uint8_t *grow = gray + (size_t)y * grayPitch;
+    const float d = drow[x];
+    const int g = grow[x];
+    const bool dirichlet = scribble[(size_t)y * scribblePitch + x] == 255;
+    int right = 0, down = 0;
+    if (x + 1 < cols) {
+        right = iabs(g - (int)grow[x + 1]);
+        if (gated && !(iabs(sat_u8_dev(d) - sat_u8_dev(drow[x + 1])) > thr)) right = 0;
+    }
+    if (y + 1 < rows) {
+        down = iabs(g - (int)grow[x + grayPitch]);
+        if (gated) {
+            const float dd = ((const float *)((const char *)depth + (size_t)(y + 1) * depthPitch))[x];
+            if (!(iabs(sat_u8_dev(d) - sat_u8_dev(dd)) > thr)) down = 0;
+        }
+    }
+    const size_t p = (size_t)y * ip + x;
+    X0[p] = d;
+    X1[p] = dirichlet ? d : 0.0f;     // x_{-1} = 0 on free pixels (cudaMemset, :290); Dirichlet value in both planes (:291-292)
+    M[p] = (uint32_t)right | ((uint32_t)down << 8) | (dirichlet ? kMetaDirichlet : 0u);
+}
+
+// The reference's own index format, for parity tests of the weight pass (src/GPUSolver.cu:136-224).
+__global__ __launch_bounds__(256) void k_index_to_weight(const uint8_t *__restrict__ gray, size_t grayPitch,
+                                                         const float *__restrict__ depth, size_t depthPitch,
+                                                         int32_t *__restrict__ index2, int rows, int cols, int gated, int thr) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const int g = gray[(size_t)y * grayPitch + x];
+    const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
+    const int d = gated ? sat_u8_dev(drow[x]) : 0;
+    int idx[4] = {256, 256, 256, 256};   // left right up down
+    const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int nx = x + dx[k], ny = y + dy[k];
+        if (nx < 0 || ny < 0 || nx >= cols || ny >= rows) continue;
+        int v = iabs(g - (int)gray[(size_t)ny * grayPitch + nx]);
+        if (gated) {
+            const float nd = ((const float *)((const char *)depth + (size_t)ny * depthPitch))[nx];
+            if (!(iabs(d - sat_u8_dev(nd)) > thr)) v = 0;
+        }
+        idx[k] = v;
+    }
+    const size_t p = (size_t)y * cols + x;
+    index2[2 * p + 0] = idx[0] * 1000 + idx[1];
+    index2[2 * p + 1] = idx[2] * 1000 + idx[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// One pixel of one sweep: solveDiffusion (src/GPUSolver.cu:73-106) + the Chebyshev update (:257-260)
+// ------------------------------------------------------------------------------------------------
+template <bool CONTRACT>
+__device__ __forceinline__ float mean4(float xl, float xr, float xu, float xd, float wl, float wr, float wu, float wd,
+                                       bool vl, bool vr, bool vu, bool vd) {
+    float sum = 0.0f, cnt = 0.0f, s2;
+    s2 = CONTRACT ? __builtin_fmaf(wl, xl, sum) : sum + wl * xl;  sum = vl ? s2 : sum;  cnt = vl ? cnt + wl : cnt;
+    s2 = CONTRACT ? __builtin_fmaf(wr, xr, sum) : sum + wr * xr;  sum = vr ? s2 : sum;  cnt = vr ? cnt + wr : cnt;
+    s2 = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;  sum = vu ? s2 : sum;  cnt = vu ? cnt + wu : cnt;
+    s2 = CONTRACT ? __builtin_fmaf(wd, xd, sum) : sum + wd * xd;  sum = vd ? s2 : sum;  cnt = vd ? cnt + wd : cnt;
+    float r = sum / cnt;                      // IEEE correctly-rounded divide (-fhip-fp32-correctly-rounded-divide-sqrt)
+    if (!(r >= 0.0f)) r = 0.0f;               // min(max(.,0),255) with fmax/fmin NaN semantics (:104)
+    if (r > 255.0f) r = 255.0f;
+    if (cnt == 0.0f) r = 0.0f;                // :103
+    return r;
+}
+
+template <bool CONTRACT>
+__device__ __forceinline__ float chebyshev(float r, float x, float prev, float omega, float gamma) {
+    if (CONTRACT) return __builtin_fmaf(omega, __builtin_fmaf(gamma, r - x, x) - prev, prev);
+    return (omega * (gamma * (r - x) + x - prev)) + prev;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sweep1: one sweep per launch.  block = 256 threads = 4 waves stacked vertically; wave w of
+// block (bx,by) owns columns [256*bx, 256*bx+256) and rows [(4*by+w)*R, +R).  Lane l holds the
+// 4 pixels 256*bx+4l .. +3 of each row.  X = x_k (read-only), Y = x_{k-1} in / x_{k+1} out.
+// ------------------------------------------------------------------------------------------------
+template <bool CONTRACT>
+__global__ __launch_bounds__(256) void k_sweep1(const float *__restrict__ X, float *__restrict__ Y,
+                                                const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
+                                                int ip, int rows, int cols, int R, float omega, float gamma) {
+    __shared__ float lut[257];
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 256 + lane * 4;
+    const int ybeg = (blockIdx.y * 4 + wave) * R;
+    const int yend = min(ybeg + R, rows);
+    if (ybeg >= rows) return;
+
+    const bool lane_in = x0 < cols;
+    // per-lane validity of the horizontal neighbours of its 4 pixels
+    const bool vl0 = x0 > 0;
+    bool vr[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) vr[i] = x0 + i + 1 < cols;
+
+    const float *xrow = X + (size_t)ybeg * ip + x0;
+    float4 up = *(const float4 *)(xrow - ip);
+    float4 cur = *(const float4 *)(xrow);
+    float wu[4];
+    {
+        const uint4 mu = *(const uint4 *)(M + (size_t)(ybeg - 1) * ip + x0);   // guard row when ybeg == 0 (value unused)
+        wu[0] = lut[(mu.x >> 8) & 255]; wu[1] = lut[(mu.y >> 8) & 255];
+        wu[2] = lut[(mu.z >> 8) & 255]; wu[3] = lut[(mu.w >> 8) & 255];
+    }
+
+    for (int y = ybeg; y < yend; y++) {
+        const size_t rowoff = (size_t)y * ip + x0;
+        const float4 dn = *(const float4 *)(X + rowoff + ip);
+        const uint4 m = *(const uint4 *)(M + rowoff);
+        const float4 pv = *(const float4 *)(Y + rowoff);
+
+        // horizontal halo: neighbours' edge values by wave shuffle, strip edges by scalar load
+        float xl = __shfl_up(cur.w, 1);
+        float xr = __shfl_down(cur.x, 1);
+        uint32_t ml = __shfl_up(m.w, 1);
+        if (lane == 0) { xl = X[rowoff - 1]; ml = M[rowoff - 1]; }
+        if (lane == 63) xr = X[rowoff + 4];
+
+        const float wr[4] = {lut[m.x & 255], lut[m.y & 255], lut[m.z & 255], lut[m.w & 255]};
+        const float wd[4] = {lut[(m.x >> 8) & 255], lut[(m.y >> 8) & 255], lut[(m.z >> 8) & 255], lut[(m.w >> 8) & 255]};
+        const float wl0 = lut[ml & 255];
+        const bool vu = y > 0, vd = y + 1 < rows;
+
+        const float xc[4] = {cur.x, cur.y, cur.z, cur.w};
+        const float xu[4] = {up.x, up.y, up.z, up.w};
+        const float xd[4] = {dn.x, dn.y, dn.z, dn.w};
+        const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+        const uint32_t mm[4] = {m.x, m.y, m.z, m.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float r = mean4<CONTRACT>(i == 0 ? xl : xc[i - 1], i == 3 ? xr : xc[i + 1], xu[i], xd[i],
+                                            i == 0 ? wl0 : wr[i - 1], wr[i], wu[i], wd[i],
+                                            i == 0 ? vl0 : true, vr[i], vu, vd);
+            const float v = chebyshev<CONTRACT>(r, xc[i], pp[i], omega, gamma);
+            o[i] = (mm[i] & kMetaDirichlet) ? xc[i] : v;      // Dirichlet pixels keep their value (:248)
+        }
+        if (lane_in) *(float4 *)(Y + rowoff) = make_float4(o[0], o[1], o[2], o[3]);
+        up = cur; cur = dn;
+#pragma unroll
+        for (int i = 0; i < 4; i++) wu[i] = wd[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finish: dense result plane -> caller's pitched buffer (copyToPitchedData, src/GPUSolver.cu:122-134)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
+                                                int rows, int cols) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    ((float *)((char *)depth + (size_t)y * depthPitch))[x] = X[(size_t)y * ip + x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Extensions (no reference behaviour): residual max|J(x)-x| and red-black Gauss-Seidel.
+// ------------------------------------------------------------------------------------------------
+template <bool CONTRACT>
+__device__ __forceinline__ float mean_at(const float *__restrict__ X, const uint32_t *__restrict__ M, const float *lut,
+                                         int ip, int rows, int cols, int x, int y, uint32_t m) {
+    const size_t p = (size_t)y * ip + x;
+    const bool vl = x > 0, vr = x + 1 < cols, vu = y > 0, vd = y + 1 < rows;
+    const uint32_t ml = M[p - 1], mu = M[p - ip];            // guard cells when invalid (values unused)
+    return mean4<CONTRACT>(X[p - 1], X[p + 1], X[p - ip], X[p + ip],
+                           lut[ml & 255], lut[m & 255], lut[(mu >> 8) & 255], lut[(m >> 8) & 255], vl, vr, vu, vd);
+}
+
+template <bool CONTRACT>
+__global__ __launch_bounds__(256) void k_residual(const float *__restrict__ X, const uint32_t *__restrict__ M,
+                                                  const float *__restrict__ lut_g, int ip, int rows, int cols,
+                                                  unsigned int *__restrict__ out_bits) {
+    __shared__ float lut[257];
+    __shared__ float wmax[4];
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
+    __syncthreads();
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float d = 0.0f;
+    if (x < cols && y < rows) {
+        const uint32_t m = M[(size_t)y * ip + x];
+        if (!(m & kMetaDirichlet)) {
+            const float r = mean_at<CONTRACT>(X, M, lut, ip, rows, cols, x, y, m);
+            d = fabsf(r - X[(size_t)y * ip + x]);
+            if (!(d >= 0.0f)) d = __builtin_inff();            // NaN must not hide
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) d = fmaxf(d, __shfl_xor(d, s));   // wave64 butterfly
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        atomicMax(out_bits, __float_as_uint(d));               // non-negative floats order like their bit patterns
+    }
+}
+
+template <bool CONTRACT>
+__global__ __launch_bounds__(256) void k_rbgs_half(float *__restrict__ X, const uint32_t *__restrict__ M,
+                                                   const float *__restrict__ lut_g, int ip, int rows, int cols, int colour) {
+    __shared__ float lut[257];
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
+    __syncthreads();
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)) + ((y + colour) & 1);
+    if (x >= cols || y >= rows) return;
+    const uint32_t m = M[(size_t)y * ip + x];
+    if (m & kMetaDirichlet) return;
+    X[(size_t)y * ip + x] = mean_at<CONTRACT>(X, M, lut, ip, rows, cols, x, y, m);
+}
+
+// ================================================================================================
+// host-side launchers
+// ================================================================================================
+static inline dim3 grid64x4(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
+
+int launch_prepare(rtdd_ctx *ctx, const Level &L, size_t ip, const float *depth, size_t depthPitch,
+                   const uint8_t *scribble, size_t scribblePitch, const uint8_t *gray, size_t grayPitch,
+                   int rows, int cols, int level) {
+    const int gated = level != ctx->maxLevel;
+    const int thr = level == 0 ? 0 : 4;
+    hipLaunchKernelGGL(k_prepare, grid64x4(rows, cols), dim3(256), 0, ctx->stream, depth, depthPitch, scribble, scribblePitch,
+                       gray, grayPitch, L.P(0, ip), L.P(1, ip), L.M(ip), (int)ip, rows, cols, gated, thr);
+    RTDD_LAUNCH_CHECK(ctx, "k_prepare");
+    return RTDD_OK;
+}
+
+int launch_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch, const float *depth, size_t depthPitch,
+                           int32_t *index2, int level, int rows, int cols) {
+    const int gated = level != ctx->maxLevel;
+    const int thr = level == 0 ? 0 : 4;
+    hipLaunchKernelGGL(k_index_to_weight, grid64x4(rows, cols), dim3(256), 0, ctx->stream, gray, grayPitch, depth, depthPitch,
+                       index2, rows, cols, gated, thr);
+    RTDD_LAUNCH_CHECK(ctx, "k_index_to_weight");
+    return RTDD_OK;
+}
+
+static int pick_rows_per_wave(const rtdd_ctx *ctx, int rows, int cols) {
+    if (ctx->opt.rows_per_wave > 0) return ctx->opt.rows_per_wave;
+    // aim for >= ~16 waves per CU so HBM latency is covered by occupancy, but keep R >= 2 so a
+    // wave's three-row window amortises its two halo rows
+    const long strips = (cols + 255) / 256;
+    const long want_waves = (long)ctx->num_cus * 16;
+    long R = (strips * rows + want_waves - 1) / want_waves;
+    if (R < 2) R = 2;
+    if (R > 16) R = 16;
+    return (int)R;
+}
+
+int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas, int n,
+                  int *result_plane, int *launches) {
+    const float gamma = 0.99;                 // src/GPUSolver.cu:285 (double literal narrowed to float)
+    const int R = pick_rows_per_wave(ctx, rows, cols);
+    const dim3 grid((cols + 255) / 256, (rows + 4 * R - 1) / (4 * R));
+    int a = 0, b = 1;                         // plane a holds x_k, plane b holds x_{k-1} and receives x_{k+1}
+    for (int it = 0; it < n; it++) {
+        if (ctx->opt.fp_contract)
+            hipLaunchKernelGGL(k_sweep1<true>, grid, dim3(256), 0, ctx->stream, L.P(a, ip), L.P(b, ip), L.M(ip), ctx->lut_dev,
+                               (int)ip, rows, cols, R, omegas[it], gamma);
+        else
+            hipLaunchKernelGGL(k_sweep1<false>, grid, dim3(256), 0, ctx->stream, L.P(a, ip), L.P(b, ip), L.M(ip), ctx->lut_dev,
+                               (int)ip, rows, cols, R, omegas[it], gamma);
+        const int t = a; a = b; b = t;
+    }
+    RTDD_LAUNCH_CHECK(ctx, "k_sweep1");
+    *result_plane = a;
+    *launches = n;
+    return RTDD_OK;
+}
+
+int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols) {
+    hipLaunchKernelGGL(k_finish, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols);
+    RTDD_LAUNCH_CHECK(ctx, "k_finish");
+    return RTDD_OK;
+}
+
+int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, float *host_out) {
+    RTDD_HIP(ctx, hipMemsetAsync(ctx->residual_dev, 0, sizeof(float), ctx->stream));
+    if (ctx->opt.fp_contract)
+        hipLaunchKernelGGL(k_residual<true>, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(plane, ip), L.M(ip), ctx->lut_dev,
+                           (int)ip, rows, cols, (unsigned int *)ctx->residual_dev);
+    else
+        hipLaunchKernelGGL(k_residual<false>, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(plane, ip), L.M(ip), ctx->lut_dev,
+                           (int)ip, rows, cols, (unsigned int *)ctx->residual_dev);
+    RTDD_LAUNCH_CHECK(ctx, "k_residual");
+    RTDD_HIP(ctx, hipMemcpyAsync(host_out, ctx->residual_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTDD_OK;
+}
+
+int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps) {
+    const dim3 grid(((cols + 1) / 2 + 63) / 64, (rows + 3) / 4);
+    for (int s = 0; s < nsweeps; s++)
+        for (int colour = 0; colour < 2; colour++) {
+            if (ctx->opt.fp_contract)
+                hipLaunchKernelGGL(k_rbgs_half<true>, grid, dim3(256), 0, ctx->stream, L.P(plane, ip), L.M(ip), ctx->lut_dev, (int)ip, rows, cols, colour);
+            else
+                hipLaunchKernelGGL(k_rbgs_half<false>, grid, dim3(256), 0, ctx->stream, L.P(plane, ip), L.M(ip), ctx->lut_dev, (int)ip, rows, cols, colour);
+        }
+    RTDD_LAUNCH_CHECK(ctx, "k_rbgs_half");
+    return RTDD_OK;
+}
+
+}  // namespace rtdd

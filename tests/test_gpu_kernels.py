@@ -1,0 +1,177 @@
+"""GPU parity for the annotation kernels and the depth effects (-m gpu), through the C ABI."""
+import numpy as np
+import pytest
+
+import realtimedepthdiffusion_amd as rt
+from gpu_util import down, up
+from realtimedepthdiffusion_amd.synth import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rt.Context(0)
+    yield c
+    c.close()
+
+
+def _rgb(rows, cols, seed):
+    return np.random.default_rng(seed).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(9, 11), (64, 64), (67, 120), (135, 240)])
+def test_convert_to_float(ctx, oracle, shape):
+    rows, cols = shape
+    edited = _rgb(rows, cols, 1)
+    mask = np.where(np.random.default_rng(2).random(shape) < 0.2, 255, 32).astype(np.uint8)
+    dst = np.random.default_rng(3).uniform(0, 255, shape).astype(np.float32)
+    want = oracle.convert_to_float(edited, dst.copy(), mask)
+    d = up(dst)
+    ctx.GPUConvertToFloat(up(edited), d, up(mask), rows, cols)
+    assert np.array_equal(down(d), want)
+
+
+@pytest.mark.parametrize("fine", [(8, 8), (9, 11), (135, 240), (624, 672), (853, 1280)])
+def test_pyrdown_annotation(ctx, oracle, fine):
+    rows, cols = fine
+    crows, ccols = rows // 2, cols // 2
+    rng = np.random.default_rng(rows)
+    edited = _rgb(rows, cols, 5)
+    mask = np.where(rng.random(fine) < 0.15, 255, 32).astype(np.uint8)
+    cm = np.zeros((crows, ccols), np.uint8); ce = np.zeros((crows, ccols, 3), np.uint8)
+    cm[0, 0] = 255; ce[0, 0] = 9                        # stale state must survive (never cleared)
+    wm, we = cm.copy(), ce.copy()
+    oracle.pyrdown_annotation(mask, edited, wm, we)
+    gm, ge = up(cm), up(ce)
+    ctx.GPUPyrDownAnnotation(up(mask), up(edited), rows, cols, gm, ge, crows, ccols)
+    assert np.array_equal(down(gm), wm) and np.array_equal(down(ge), we)
+
+
+@pytest.mark.parametrize("x,y,r", [(50, 40, 21), (0, 0, 9), (99, 79, 10), (-5, 30, 20), (300, 300, 8), (10, 10, 0), (10, 10, 1), (20, 20, -6)])
+def test_paint_image(ctx, oracle, x, y, r):
+    rows, cols = 80, 100
+    e = _rgb(rows, cols, 7); m = np.full((rows, cols), 32, np.uint8)
+    we, wm = e.copy(), m.copy()
+    oracle.paint_image(x, y, 192, r, we, wm)
+    ge, gm = up(e), up(m)
+    ctx.GPUPaintImage(x, y, 192, r, ge, gm, rows, cols)
+    assert np.array_equal(down(ge), we) and np.array_equal(down(gm), wm)
+
+
+def _depth(rows, cols, seed):
+    p = make_problem(rows, cols, seed=seed)
+    rng = np.random.default_rng(seed)
+    d = (p["depth"] * rng.uniform(0.0, 1.0, (rows, cols))).astype(np.float32)
+    d[::7, ::5] = 255.0; d[1::7, ::5] = 0.0
+    return d, p["gray"]
+
+
+@pytest.mark.parametrize("contract", [1, 0])
+@pytest.mark.parametrize("shape", [(6, 8), (67, 120), (270, 480), (700, 560)])
+def test_desaturation_bit_exact(ctx, oracle, shape, contract):
+    rows, cols = shape
+    depth, gray = _depth(rows, cols, 31)
+    orig = _rgb(rows, cols, 11)
+    ctx.set_option(rt.OPT_FP_CONTRACT, contract)
+    art = up(np.zeros_like(orig))
+    ctx.GPUSimulateDesaturation(up(orig), up(gray), up(depth), art, rows, cols)
+    assert np.array_equal(down(art), oracle.desaturate(orig, gray, depth, contract))
+
+
+@pytest.mark.parametrize("contract", [1, 0])
+@pytest.mark.parametrize("shape", [(6, 8), (67, 120), (270, 480), (700, 560)])
+def test_haze_within_one_grey_level(ctx, oracle, shape, contract):
+    rows, cols = shape
+    depth, _ = _depth(rows, cols, 37)
+    orig = _rgb(rows, cols, 13)
+    ctx.set_option(rt.OPT_FP_CONTRACT, contract)
+    art = up(np.zeros_like(orig))
+    ctx.GPUSimulateHaze(up(orig), up(depth), art, rows, cols)
+    got = down(art).astype(np.int32); want = oracle.haze(orig, depth, contract).astype(np.int32)
+    diff = np.abs(got - want)
+    assert diff.max() <= 1                                   # stated tolerance: device exp vs host libm expf
+    assert (diff != 0).mean() <= 1e-4
+
+
+@pytest.mark.parametrize("shape", [(6, 8), (80, 80), (67, 120), (270, 480), (700, 560)])
+def test_defocus_bit_exact(ctx, oracle, shape):
+    rows, cols = shape
+    depth, _ = _depth(rows, cols, 41)
+    orig = _rgb(rows, cols, 17)
+    art = up(np.zeros_like(orig))
+    ctx.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+    assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=8))
+
+
+def test_defocus_out_of_range_depth_is_defined(ctx, oracle):
+    rows, cols = 120, 160
+    orig = _rgb(rows, cols, 19)
+    depth = np.random.default_rng(5).uniform(-300, 600, (rows, cols)).astype(np.float32)
+    art = up(np.zeros_like(orig))
+    ctx.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+    assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=8))
+
+
+def test_effects_1080p_properties(ctx):
+    """Full-size, size-independent properties: depth 0 is the identity for all three effects."""
+    rows, cols = 1080, 1920
+    orig = _rgb(rows, cols, 23)
+    gray = np.random.default_rng(29).integers(0, 256, (rows, cols), dtype=np.uint8)
+    zero = up(np.zeros((rows, cols), np.float32))
+    o = up(orig)
+    for call in ("haze", "desat", "defocus"):
+        art = up(np.zeros_like(orig))
+        if call == "haze":
+            ctx.GPUSimulateHaze(o, zero, art, rows, cols)
+        elif call == "desat":
+            ctx.GPUSimulateDesaturation(o, up(gray), zero, art, rows, cols)
+        else:
+            ctx.GPUSimulateDefocus(o, zero, art, rows, cols)
+        assert np.array_equal(down(art), orig), call
+    # depth 255 desaturation is the gray image
+    art = up(np.zeros_like(orig))
+    ctx.GPUSimulateDesaturation(o, up(gray), up(np.full((rows, cols), 255, np.float32)), art, rows, cols)
+    assert np.array_equal(down(art), np.repeat(gray[..., None], 3, 2))
+
+
+def test_error_behaviour(ctx):
+    c = rt.Context(0)
+    d = up(np.zeros((8, 8), np.float32)); m = up(np.zeros((8, 8), np.uint8))
+    with pytest.raises(rt.RtddError) as e:
+        c.GPUMatrixFreeSolver(d, m, m, 8, 8, 0.4, 10, 0.0, 0)            # before allocate
+    assert e.value.status == 2
+    c.GPUAllocateDeviceMemory(8, 8, 1)
+    with pytest.raises(rt.RtddError) as e:
+        c.GPUMatrixFreeSolver(d, m, m, 8, 8, 0.4, 10, 0.0, 0)            # before load_weights
+    assert e.value.status == 2
+    c.GPULoadWeights(0.4)
+    with pytest.raises(rt.RtddError) as e:
+        c.GPUMatrixFreeSolver(d, m, m, 8, 8, 0.4, 10, 0.0, 3)            # level out of range
+    assert e.value.status == 1
+    with pytest.raises(rt.RtddError):
+        c.GPUMatrixFreeSolver(d, m, m, 64, 64, 0.4, 10, 0.0, 0)          # larger than the allocation
+    c.GPUMatrixFreeSolver(d, m, m, 8, 8, 0.4, 10, 0.0, 0)                # and a legal call still works
+    c.synchronize()
+    c.close()
+
+
+def test_dropin_cxx_symbols_run(oracle, lut):
+    """Call the reference's own mangled symbols (what main.cpp links against) through ctypes."""
+    import ctypes as C
+    L = rt.lib()
+    p = make_problem(48, 64, seed=77)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 30, 0, 0, lut, 1)
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    L._Z23GPUAllocateDeviceMemoryiii.restype = None
+    L._Z23GPUAllocateDeviceMemoryiii(i32(48), i32(64), i32(1))
+    L._Z14GPULoadWeightsf.restype = None
+    L._Z14GPULoadWeightsf(f32(0.4))
+    f = L._Z19GPUMatrixFreeSolverPfmPhmS0_miififi
+    f.restype = None
+    f(vp(d.data_ptr()), sz(d.stride(0) * 4), vp(m.data_ptr()), sz(m.stride(0)), vp(g.data_ptr()), sz(g.stride(0)),
+      i32(48), i32(64), f32(0.4), i32(30), f32(1e-5), i32(0))
+    assert np.array_equal(down(d).view(np.uint32), want.view(np.uint32))      # returns synchronised, like the reference
+    L._Z19GPUFreeDeviceMemoryi.restype = None
+    L._Z19GPUFreeDeviceMemoryi(i32(1))
