@@ -79,6 +79,14 @@ def lib():
         if not os.path.exists(_SO):
             raise RtddError(-1, f"{_SO} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(there is no CPU fallback)")
+        try:
+            # torch wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7, NEEDED as plain
+            # "libamdhip64.so").  If librtdd.so pulled in /opt/rocm's copy first, torch would load a
+            # SECOND HIP runtime into the process and find no GPUs.  Loading torch first makes the
+            # dynamic linker satisfy librtdd's libamdhip64.so.7 with the runtime torch already holds.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_SO)
         L.rtdd_last_error.restype = C.c_char_p
         L.rtdd_status_string.restype = C.c_char_p

@@ -25,11 +25,11 @@ def ctx():
     c.close()
 
 
-def _solve_gpu(ctx, p, iters, level, levels, contract, align=512, **opts):
+def _solve_gpu(ctx, p, iters, level, levels, contract, align=512, opts=None):
     rows, cols = p["gray"].shape
     ctx.GPUAllocateDeviceMemory(rows << level, cols << level, levels)
     ctx.set_option(rt.OPT_FP_CONTRACT, contract)
-    for k, v in opts.items():
+    for k, v in (opts or {}).items():
         ctx.set_option(k, v)
     d, m, g = up(p["depth"], align), up(p["mask"], align), up(p["gray"], align)
     ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, iters, 1e-5, level)
@@ -85,7 +85,7 @@ def test_solver_pitch_independent(ctx, oracle, lut, align):
 def test_solver_independent_of_strip_height(ctx, oracle, lut, rows_per_wave):
     p = make_problem(75, 300, seed=17)
     want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 20, 0, 0, lut, 1)
-    got = _solve_gpu(ctx, p, 20, 0, 1, 1, **{rt.OPT_ROWS_PER_WAVE: rows_per_wave})
+    got = _solve_gpu(ctx, p, 20, 0, 1, 1, opts={rt.OPT_ROWS_PER_WAVE: rows_per_wave})
     ctx.set_option(rt.OPT_ROWS_PER_WAVE, 0)
     assert_bit_equal(got, want)
 
