@@ -23,6 +23,10 @@ WORKLOADS = {
     "1080p_jacobi1000": dict(rows=1080, cols=1920, iters=1000),
     "4k_jacobi1000": dict(rows=2160, cols=3840, iters=1000),
     "8k_jacobi200": dict(rows=4320, cols=7680, iters=200),
+    "128x128_jacobi1000": dict(rows=128, cols=128, iters=1000),
+    "120x67_jacobi1000": dict(rows=67, cols=120, iters=1000),
+    "480x270_jacobi250": dict(rows=270, cols=480, iters=250),
+    "960x540_jacobi125": dict(rows=540, cols=960, iters=125),
 }
 ALGO_BYTES_PER_PX_ITER = 17.0          # x_k 4 + x_{k-1} 4 + x_{k+1} 4 + 4 weight indices 4 + mask 1
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -55,6 +59,7 @@ def main():
     ap.add_argument("--temporal-depth", type=int, default=0)
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--graph", type=int, default=-1)
+    ap.add_argument("--tile", type=int, default=0)
     args = ap.parse_args()
 
     import numpy as np
@@ -86,6 +91,7 @@ def main():
     if args.temporal_depth: ctx.set_option(rt.OPT_TEMPORAL_DEPTH, args.temporal_depth)
     if args.rows_per_wave: ctx.set_option(rt.OPT_ROWS_PER_WAVE, args.rows_per_wave)
     if args.graph >= 0: ctx.set_option(rt.OPT_USE_GRAPH, args.graph)
+    if args.tile: ctx.set_option(rt.OPT_TILE, args.tile)
     mask = rt.device_image(p["mask"], dev); gray = rt.device_image(p["gray"], dev)
     # one pristine initial-depth image per step, uploaded before the clock starts
     depths = [rt.device_image(p["depth"], dev) for _ in range(args.steps + args.warmup)]
@@ -126,7 +132,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps "
                                f"(BASELINE configs[1])" if args.workload == "1080p_jacobi1000" else args.workload,
-                   "images_per_step": world, "sweep_kernel": ctx.get_option(rt.OPT_SWEEP_KERNEL),
+                   "images_per_step": world, "sweep_kernel": ctx.get_option(rt.OPT_SWEEP_KERNEL), "tile": ctx.get_option(rt.OPT_TILE), "temporal_depth": ctx.get_option(rt.OPT_TEMPORAL_DEPTH),
                    "sweeps_per_launch": sweeps_per_launch},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "sweep", "launch_us": launch_us,

@@ -53,7 +53,20 @@ def _pitch(a):
 
 
 def max_threads():
-    return int(lib().orc_max_threads())
+    """Threads worth using here: OpenMP's count, capped by the cgroup CPU quota and the affinity mask
+    (a GPU box gives one job a 16-core share of a 128-core host; oversubscribed OpenMP barriers crawl)."""
+    n = int(lib().orc_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("RTDD_ORACLE_THREADS", "16"))))
 
 
 def load_weights(beta):

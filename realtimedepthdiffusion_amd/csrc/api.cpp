@@ -123,9 +123,10 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
     switch (key) {
         case RTDD_OPT_FP_CONTRACT: ctx->opt.fp_contract = value ? 1 : 0; break;
         case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 2, "sweep kernel must be 0..2"); ctx->opt.sweep_kernel = value; break;
-        case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 64, "temporal depth must be 0..64"); ctx->opt.temporal_depth = value; break;
+        case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 16, "temporal depth must be 0..16"); ctx->opt.temporal_depth = value; break;
         case RTDD_OPT_USE_GRAPH: ctx->opt.use_graph = value ? 1 : 0; break;
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
+        case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 8, "tile must be 0..8"); ctx->opt.tile = value; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;
@@ -139,6 +140,7 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_TEMPORAL_DEPTH: *value = ctx->opt.temporal_depth; break;
         case RTDD_OPT_USE_GRAPH: *value = ctx->opt.use_graph; break;
         case RTDD_OPT_ROWS_PER_WAVE: *value = ctx->opt.rows_per_wave; break;
+        case RTDD_OPT_TILE: *value = ctx->opt.tile; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;
@@ -204,6 +206,21 @@ int rtdd_load_weights(rtdd_ctx *ctx, float beta) {
     return RTDD_OK;
 }
 
+// The omega schedule depends only on the iteration index, so one device copy serves every call;
+// it is re-uploaded only when a longer schedule is requested.
+static int ensure_omegas(rtdd_ctx *ctx, int n) {
+    if (n <= ctx->omega_cap) return RTDD_OK;
+    int cap = n < 1024 ? 1024 : n;
+    std::vector<float> om;
+    omega_schedule(cap, om);
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->omega_dev) { RTDD_HIP(ctx, hipFree(ctx->omega_dev)); ctx->omega_dev = nullptr; ctx->omega_cap = 0; }
+    RTDD_HIP(ctx, hipMalloc((void **)&ctx->omega_dev, (size_t)cap * sizeof(float)));
+    RTDD_HIP(ctx, hipMemcpy(ctx->omega_dev, om.data(), (size_t)cap * sizeof(float), hipMemcpyHostToDevice));
+    ctx->omega_cap = cap;
+    return RTDD_OK;
+}
+
 static int check_solve_args(rtdd_ctx *ctx, const float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
                             const uint8_t *gray, size_t grayPitch, int rows, int cols, int level) {
     REQUIRE(ctx, depth && scribble && gray, "null image pointer");
@@ -240,27 +257,30 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
 
     const bool stop_on_residual = params->tolerance > 0.0f;
     const int every = params->checkEvery > 0 ? params->checkEvery : 16;
-    int done = 0, result_plane = 0, launches = 0;
+    int done = 0, launches = 0;
+    int pk = 0, pm = 1;                            // planes holding x_k and x_{k-1}
     float residual = NAN;
 
     if (params->method == RTDD_METHOD_CHEBYSHEV_JACOBI) {
         std::vector<float> omegas;
         omega_schedule(params->maxIterations, omegas);
-        if (!stop_on_residual) {
-            rc = launch_sweeps(ctx, L, ip, rows, cols, omegas.data(), params->maxIterations, &result_plane, &launches);
+        const bool blocked = ctx->opt.sweep_kernel != 1;       // 0 (auto) and 2 -> temporally blocked kernel
+        const float *omegas_dev = nullptr;
+        if (blocked && params->maxIterations > 0) {
+            rc = ensure_omegas(ctx, params->maxIterations);
             if (rc != RTDD_OK) return rc;
-            done = params->maxIterations;
-        } else {
-            // chunks of `every` sweeps; the plane roles continue across chunks because a chunk of
-            // even length returns to plane 0 and odd chunks only occur at the tail
-            const int chunk = every + (every & 1);
-            while (done < params->maxIterations) {
-                int n = params->maxIterations - done < chunk ? params->maxIterations - done : chunk;
-                int rp = 0, ln = 0;
-                rc = launch_sweeps(ctx, L, ip, rows, cols, omegas.data() + done, n, &rp, &ln);
-                if (rc != RTDD_OK) return rc;
-                done += n; launches += ln; result_plane = rp;
-                rc = launch_residual(ctx, L, ip, result_plane, rows, cols, &residual);
+            omegas_dev = ctx->omega_dev;
+        }
+        const int chunk = stop_on_residual ? every : params->maxIterations;
+        while (done < params->maxIterations) {
+            const int n = params->maxIterations - done < chunk ? params->maxIterations - done : chunk;
+            int ln = 0;
+            rc = blocked ? launch_sweeps_blocked(ctx, L, ip, rows, cols, omegas_dev + done, n, &pk, &pm, &ln)
+                         : launch_sweeps(ctx, L, ip, rows, cols, omegas.data() + done, n, &pk, &pm, &ln);
+            if (rc != RTDD_OK) return rc;
+            done += n; launches += ln;
+            if (stop_on_residual) {
+                rc = launch_residual(ctx, L, ip, pk, rows, cols, &residual);
                 if (rc != RTDD_OK) return rc;
                 if (residual <= params->tolerance) break;
             }
@@ -278,8 +298,9 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
                 if (residual <= params->tolerance) break;
             }
         }
-        result_plane = 0;
+        pk = 0;
     }
+    const int result_plane = pk;
 
     if (prof) RTDD_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     rc = launch_finish(ctx, L, ip, result_plane, depth, depthPitch, rows, cols);

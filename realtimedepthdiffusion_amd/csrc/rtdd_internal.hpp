@@ -47,6 +47,7 @@ struct Options {
     int temporal_depth = 0;
     int use_graph = 0;
     int rows_per_wave = 0;
+    int tile = 0;
 };
 
 }  // namespace rtdd
@@ -104,8 +105,13 @@ struct DeviceGuard {
 int launch_prepare(rtdd_ctx *ctx, const Level &L, size_t ip, const float *depth, size_t depthPitch,
                    const uint8_t *scribble, size_t scribblePitch, const uint8_t *gray, size_t grayPitch,
                    int rows, int cols, int level);
-int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas, int n,
-                  int *result_plane, int *launches);
+// Both sweep launchers advance n sweeps from (plane *pk = x_k, plane *pm = x_{k-1}) and update *pk / *pm to
+// the planes holding x_{k+n} / x_{k+n-1}.
+int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_host, int n,
+                  int *pk, int *pm, int *launches);
+// sweep_blocked.hip
+int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
+                          int *pk, int *pm, int *launches);
 int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols);
 int launch_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch, const float *depth, size_t depthPitch,
                            int32_t *index2, int level, int rows, int cols);

@@ -300,11 +300,11 @@ static int pick_rows_per_wave(const rtdd_ctx *ctx, int rows, int cols) {
 }
 
 int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas, int n,
-                  int *result_plane, int *launches) {
+                  int *pk, int *pm, int *launches) {
     const float gamma = 0.99;                 // src/GPUSolver.cu:285 (double literal narrowed to float)
     const int R = pick_rows_per_wave(ctx, rows, cols);
     const dim3 grid((cols + 255) / 256, (rows + 4 * R - 1) / (4 * R));
-    int a = 0, b = 1;                         // plane a holds x_k, plane b holds x_{k-1} and receives x_{k+1}
+    int a = *pk, b = *pm;                     // plane a holds x_k, plane b holds x_{k-1} and receives x_{k+1}
     for (int it = 0; it < n; it++) {
         if (ctx->opt.fp_contract)
             hipLaunchKernelGGL(k_sweep1<true>, grid, dim3(256), 0, ctx->stream, L.P(a, ip), L.P(b, ip), L.M(ip), ctx->lut_dev,
@@ -315,7 +315,7 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
         const int t = a; a = b; b = t;
     }
     RTDD_LAUNCH_CHECK(ctx, "k_sweep1");
-    *result_plane = a;
+    *pk = a; *pm = b;
     *launches = n;
     return RTDD_OK;
 }

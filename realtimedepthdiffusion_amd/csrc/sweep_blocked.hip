@@ -1,0 +1,302 @@
+// sweep_blocked.hip -- temporally blocked Chebyshev-Jacobi sweeps: n sweeps per launch.
+//
+// Why: one sweep per launch moves 16 B/pixel through HBM/L2 and does ~25 flops on it, so the
+// one-sweep kernel (solver_kernels.hip) can never beat bytes/bandwidth, and at 1080p its 7 us
+// of work is the same order as the launch boundary.  Jacobi sweeps are order-independent, so
+// a workgroup can load a tile plus a halo of n pixels ONCE, run n sweeps on it entirely in
+// registers, and write back the part of the tile that is still exact (everything further than
+// n pixels from a tile edge that is not an image border).  Values are bit-identical to n
+// separate sweeps -- only the schedule changes.
+//
+// Layout of one workgroup (template LX lanes per tile row, NT threads, G rows per thread):
+//   * the extended tile is EW = 4*LX pixels wide and EH = (NT/LX)*G rows tall;
+//   * a thread owns a 4-pixel-wide, G-row-tall block: x_k, x_{k-1}, its right/down weights (as
+//     f32, gathered from the LDS copy of the LUT once per launch), and 1/... nothing else;
+//   * horizontal neighbours come from the adjacent lane by DPP wave shifts (no LDS);
+//   * vertical neighbours inside the block are the thread's own registers; only the block's top
+//     and bottom rows go through LDS (two ds_write_b128 + two ds_read_b128 per thread per sweep,
+//     double buffered so one barrier per sweep suffices);
+//   * x_{k+1} overwrites x_{k-1}'s registers (each pixel reads only its own x_{k-1}), and the
+//     sweep loop is unrolled by two so the role swap costs no moves.
+// Outside-image pixels are held at x = 0 with all weights 0, which reproduces the reference's
+// "skip the missing neighbour" (src/GPUSolver.cu:79-101) exactly: fma(0, 0, s) == s up to the
+// sign of a zero sum, and that sign never reaches the output ("Zero-weight borders").
+#include <type_traits>
+
+#include "rtdd_internal.hpp"
+
+namespace rtdd {
+
+__device__ __forceinline__ float lane_from_prev(float v) {   // lane l <- lane l-1  (DPP wave_shr:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_from_next(float v) {   // lane l <- lane l+1  (DPP wave_shl:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+
+// ---- IEEE f32 division with a loop-invariant divisor ---------------------------------------------
+// `sum / cnt` must be the correctly rounded quotient (the reference relies on nvcc's default
+// -prec-div=true).  hipcc expands an IEEE divide into 11 VALU ops (v_div_scale x2, v_rcp, 5 fma,
+// v_mul, v_div_fmas, v_div_fixup): measured 46 cycles per wave-instruction-group, 60 % of a sweep.
+// The divisor cnt is constant for a pixel, so the divisor half of that expansion -- v_div_scale of
+// the denominator, v_rcp, and the two Newton fmas giving the refined reciprocal `y` -- is hoisted
+// out of the sweep loop; what remains per sweep is EXACTLY the tail of hipcc's sequence
+//      mul = n*y; f2 = fma(-d,mul,n); f3 = fma(f2,y,mul); f4 = fma(-d,f3,n); q = fma(f4,y,f3)
+// which is bit-identical to the full expansion whenever neither v_div_scale would rescale and
+// v_div_fixup passes the value through: d normal, n == 0 or |n| >= 2^-103 (biased exponent > 23),
+// and n/d far from over/underflow (it is a weighted mean of bounded values).  Pixels/sweeps outside
+// that regime take the full divide.  (gfx950 ISA, V_DIV_SCALE_F32 / V_DIV_FMAS_F32 / V_DIV_FIXUP_F32.)
+__device__ __forceinline__ float refined_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float f0 = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(f0, r, r);
+}
+__device__ __forceinline__ float div_tail(float n, float d, float y) {
+    const float mul = n * y;
+    const float f2 = __builtin_fmaf(-d, mul, n);
+    const float f3 = __builtin_fmaf(f2, y, mul);
+    const float f4 = __builtin_fmaf(-d, f3, n);
+    return __builtin_fmaf(f4, y, f3);
+}
+
+template <bool CONTRACT, bool FAST>
+__device__ __forceinline__ float relax(float xl, float xr, float xu, float xd, float wl, float wr, float wu, float wd,
+                                       float cnt, float rcp, float x, float prev, float omega, float gamma) {
+    // solveDiffusion, src/GPUSolver.cu:73-106, with absent neighbours carried as (w = 0, x = 0)
+    float sum = 0.0f;
+    sum = CONTRACT ? __builtin_fmaf(wl, xl, sum) : sum + wl * xl;
+    sum = CONTRACT ? __builtin_fmaf(wr, xr, sum) : sum + wr * xr;
+    sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
+    sum = CONTRACT ? __builtin_fmaf(wd, xd, sum) : sum + wd * xd;
+    float r;                                   // cnt == 0 was replaced by 1 (sum is 0 there): r = 0 (:103)
+    if (FAST) {
+        r = div_tail(sum, cnt, rcp);
+        const bool tiny = __builtin_fabsf(sum) < 0x1p-103f && sum != 0.0f;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0, 0)) r = tiny ? sum / cnt : r;   // wave-uniform, rare
+    } else {
+        r = sum / cnt;
+    }
+    r = fminf(fmaxf(r, 0.0f), 255.0f);         // :104
+    // src/GPUSolver.cu:259
+    if (CONTRACT) return __builtin_fmaf(omega, __builtin_fmaf(gamma, r - x, x) - prev, prev);
+    return (omega * (gamma * (r - x) + x - prev)) + prev;
+}
+
+// Register budget: a G = 4 thread holds 6 x 16 + 8 live values; capping it at 128 VGPRs spills into the
+// sweep loop (measured 25 % slower), so G = 4 tiles ask for 3 waves/SIMD (168 VGPRs) unless the
+// workgroup is 1024 threads (which needs 4 waves/SIMD to be launchable at all).  G <= 3 fits 128.
+template <int LX, int NT, int G, bool CONTRACT>
+__global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_blocked(const float *__restrict__ Xk, const float *__restrict__ Xm,
+                                                      float *__restrict__ Yk, float *__restrict__ Ym,
+                                                      const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
+                                                      const float *__restrict__ omegas, int ip, int rows, int cols,
+                                                      int hx, int hy, int nsweeps, float gamma) {
+    constexpr int EW = 4 * LX, NTR = NT / LX, EH = NTR * G;
+    __shared__ float lut[257];
+    __shared__ float4 edge[2][NTR][2][LX];     // [buffer][thread row][0 = its top row, 1 = its bottom row][lane]
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 257; i += NT) lut[i] = lut_g[i];
+    __syncthreads();
+
+    const int lx = tid % LX, tr = tid / LX;
+    const int TW = EW - 2 * hx, TH = EH - 2 * hy;
+    const int x0 = blockIdx.x * TW - hx + 4 * lx;
+    const int y0 = blockIdx.y * TH - hy + tr * G;
+    const bool colok = x0 >= 0 && x0 < cols;
+
+    float a[G][4], b[G][4];                    // a = x_k, b = x_{k-1}; roles alternate every sweep
+    float wr[G][4], wd[G][4], wl0[G], wu0[4], cnt[G][4], rcp[G][4];
+    bool unsafe = false;                       // some pixel of this lane has a denormal divisor
+    uint32_t dirichlet = 0;                    // bit g*4+i
+
+    // ---- load the extended tile once -----------------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int y = y0 + g;
+        const bool ok = colok && y >= 0 && y < rows;
+        float4 vx = make_float4(0, 0, 0, 0), vp = vx;
+        uint4 m = make_uint4(0, 0, 0, 0);
+        if (ok) {
+            const size_t off = (size_t)y * ip + x0;
+            vx = *(const float4 *)(Xk + off);
+            vp = *(const float4 *)(Xm + off);
+            m = *(const uint4 *)(M + off);
+        }
+        const float xv[4] = {vx.x, vx.y, vx.z, vx.w}, pv[4] = {vp.x, vp.y, vp.z, vp.w};
+        const uint32_t mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool in = ok && x0 + i < cols;
+            a[g][i] = in ? xv[i] : 0.0f;
+            b[g][i] = in ? pv[i] : 0.0f;
+            wr[g][i] = (in && x0 + i + 1 < cols) ? lut[mv[i] & 255] : 0.0f;
+            wd[g][i] = (in && y + 1 < rows) ? lut[(mv[i] >> 8) & 255] : 0.0f;
+            if (in && (mv[i] & kMetaDirichlet)) dirichlet |= 1u << (g * 4 + i);
+        }
+        // weight towards the pixel left of the block = the left lane's right-weight of its last pixel
+        const float w = lane_from_prev(wr[g][3]);
+        wl0[g] = (lx > 0 && x0 > 0) ? w : 0.0f;
+    }
+    {   // weights towards the row above the block: the down-weights of row y0-1
+        const int y = y0 - 1;
+        uint4 m = make_uint4(0, 0, 0, 0);
+        const bool ok = colok && y >= 0 && y + 1 < rows;
+        if (ok) m = *(const uint4 *)(M + (size_t)y * ip + x0);
+        const uint32_t mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) wu0[i] = (ok && x0 + i < cols) ? lut[(mv[i] >> 8) & 255] : 0.0f;
+    }
+    // (lane 0 of a tile row that is not at the image border lies in the discarded halo: wl0 = 0 is fine there)
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
+            const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
+            float c = 0.0f;                    // count accumulates left, right, up, down (:82,88,94,100)
+            c += wl; c += wr[g][i]; c += wu; c += wd[g][i];
+            cnt[g][i] = c == 0.0f ? 1.0f : c;
+            rcp[g][i] = refined_rcp(cnt[g][i]);
+            unsafe |= cnt[g][i] < 0x1p-126f;
+        }
+    const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
+
+    // ---- n sweeps in registers -------------------------------------------------------------------
+    auto sweep = [&](float (&cur)[G][4], float (&oth)[G][4], int s, auto fast) {
+        constexpr bool FAST = decltype(fast)::value;
+        const int buf = s & 1;
+        edge[buf][tr][0][lx] = make_float4(cur[0][0], cur[0][1], cur[0][2], cur[0][3]);
+        edge[buf][tr][1][lx] = make_float4(cur[G - 1][0], cur[G - 1][1], cur[G - 1][2], cur[G - 1][3]);
+        __syncthreads();
+        float4 up4 = make_float4(0, 0, 0, 0), dn4 = up4;
+        if (tr > 0) up4 = edge[buf][tr - 1][1][lx];
+        if (tr < NTR - 1) dn4 = edge[buf][tr + 1][0][lx];
+        const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
+        const float omega = omegas[s];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const float xl0 = lane_from_prev(cur[g][3]);
+            const float xr3 = lane_from_next(cur[g][0]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float xl = i == 0 ? xl0 : cur[g][i - 1];
+                const float xr = i == 3 ? xr3 : cur[g][i + 1];
+                const float xu = g == 0 ? up[i] : cur[g - 1][i];
+                const float xd = g == G - 1 ? dn[i] : cur[g + 1][i];
+                const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
+                const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
+                const float v = relax<CONTRACT, FAST>(xl, xr, xu, xd, wl, wr[g][i], wu, wd[g][i], cnt[g][i], rcp[g][i], cur[g][i], oth[g][i], omega, gamma);
+                oth[g][i] = (dirichlet >> (g * 4 + i)) & 1u ? cur[g][i] : v;      // x_{k+1} replaces x_{k-1}
+            }
+        }
+    };
+
+    // every wave executes exactly one barrier per sweep in either branch, so the wave-uniform
+    // choice of divide variant cannot unbalance the workgroup barrier
+    int s = 0;
+    if (!wave_unsafe) {
+        for (; s + 1 < nsweeps; s += 2) {
+            sweep(a, b, s, std::true_type{});
+            sweep(b, a, s + 1, std::true_type{});
+        }
+        if (s < nsweeps) sweep(a, b, s, std::true_type{});
+    } else {
+        for (; s + 1 < nsweeps; s += 2) {
+            sweep(a, b, s, std::false_type{});
+            sweep(b, a, s + 1, std::false_type{});
+        }
+        if (s < nsweeps) sweep(a, b, s, std::false_type{});
+    }
+    const bool odd = (nsweeps & 1) != 0;
+
+    // ---- write back the part that is still exact ---------------------------------------------------
+    const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int y = y0 + g, ty = tr * G + g;
+        if (xin && ty >= hy && ty < EH - hy && y < rows) {
+            const size_t off = (size_t)y * ip + x0;
+            // newest iterate -> Yk, the one before it -> Ym (componentwise selects: a pointer-select would go through scratch)
+            *(float4 *)(Yk + off) = make_float4(odd ? b[g][0] : a[g][0], odd ? b[g][1] : a[g][1], odd ? b[g][2] : a[g][2], odd ? b[g][3] : a[g][3]);
+            *(float4 *)(Ym + off) = make_float4(odd ? a[g][0] : b[g][0], odd ? a[g][1] : b[g][1], odd ? a[g][2] : b[g][2], odd ? a[g][3] : b[g][3]);
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+struct TileCfg { int lx, nt, g; };
+// id -> (lanes per tile row, threads, rows per thread); extended tile = 4*lx wide, nt/lx*g tall
+static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 1024, 4}, {32, 1024, 3}, {32, 512, 3}, {16, 512, 3}, {16, 256, 3}, {32, 1024, 2}};
+constexpr int kNumTiles = 8;
+
+template <int LX, int NT, int G>
+static void launch_cfg(rtdd_ctx *ctx, dim3 grid, const float *Xk, const float *Xm, float *Yk, float *Ym, const uint32_t *M,
+                       const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma) {
+    if (ctx->opt.fp_contract)
+        hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, true>), grid, dim3(NT), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma);
+    else
+        hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, false>), grid, dim3(NT), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma);
+}
+
+// Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
+// holding x_{k+n} / x_{k+n-1}.  omegas_dev[0..n) must already be on the device.
+int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
+                          int *pk, int *pm, int *launches) {
+    const float gamma = 0.99;
+    // Tile / depth choice.  Measured on MI355X (scripts/tile_sweep*.sh, profiles/r01_tile_sweep.txt):
+    // what matters is (a) the number of workgroups against the number of resident slots (a 1080p
+    // image is only ~250 tiles of 128x96: ONE per CU, so one tile too many doubles the time),
+    // (b) redundancy (extended / written-back area) and (c) launches per sweep for the small,
+    // latency-bound pyramid levels.
+    int tile = ctx->opt.tile, T = ctx->opt.temporal_depth;
+    const long px = (long)rows * cols;
+    int auto_tile, auto_T;
+    if (cols <= 128 && rows <= 96) { auto_tile = 4; auto_T = 8; }            // single tile, no spills
+    else if (cols <= 128 && rows <= 128) { auto_tile = 3; auto_T = 8; }      // single tile
+    else if (px < 250000L) { auto_tile = 7; auto_T = 16; }                   // e.g. 480x270: 18 us per 16 sweeps
+    else if (px < 1200000L) { auto_tile = 8; auto_T = 16; }                  // e.g. 960x540
+    else if (px < 3500000L) { auto_tile = 4; auto_T = 8; }                   // 1080p: 252 tiles on 256 CUs
+    else { auto_tile = 6; auto_T = 8; }                                      // 4K / 8K: many rounds, 2 workgroups per CU
+    if (tile == 0) tile = auto_tile;
+    if (T == 0) T = auto_T;
+    if (tile < 1 || tile > kNumTiles) tile = 1;
+    const int EW = 4 * kTiles[tile].lx, EH = kTiles[tile].nt / kTiles[tile].lx * kTiles[tile].g;
+    const bool single = cols <= EW && rows <= EH;
+    if (T > 16) T = 16;
+    while (T > 1 && (EW - 2 * ((T + 3) / 4 * 4) < 16 || EH - 2 * T < 8)) T--;   // keep a non-degenerate written-back region
+    int done = 0;
+    *launches = 0;
+    while (done < n) {
+        const int m = single ? n - done : (n - done < T ? n - done : T);
+        const int hy = single ? 0 : m;
+        const int hx = single ? 0 : (m + 3) / 4 * 4;
+        const int TW = EW - 2 * hx, TH = EH - 2 * hy;
+        const dim3 grid((cols + TW - 1) / TW, (rows + TH - 1) / TH);
+        // outputs go to the two spare planes, then the pairs swap
+        int free0 = -1, free1 = -1;
+        for (int i = 0; i < 4; i++) if (i != *pk && i != *pm) { if (free0 < 0) free0 = i; else free1 = i; }
+        const float *Xk = L.P(*pk, ip), *Xm = L.P(*pm, ip);
+        float *Yk = L.P(free0, ip), *Ym = L.P(free1, ip);
+#define RTDD_TILE_CASE(id, LX_, NT_, G_) \
+    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma); break;
+        switch (tile) {
+            RTDD_TILE_CASE(1, 16, 256, 4)
+            RTDD_TILE_CASE(2, 32, 512, 4)
+            RTDD_TILE_CASE(3, 32, 1024, 4)
+            RTDD_TILE_CASE(4, 32, 1024, 3)
+            RTDD_TILE_CASE(5, 32, 512, 3)
+            RTDD_TILE_CASE(6, 16, 512, 3)
+            RTDD_TILE_CASE(7, 16, 256, 3)
+            RTDD_TILE_CASE(8, 32, 1024, 2)
+        }
+#undef RTDD_TILE_CASE
+        *pk = free0; *pm = free1;
+        done += m;
+        (*launches)++;
+    }
+    RTDD_LAUNCH_CHECK(ctx, "k_sweep_blocked");
+    return RTDD_OK;
+}
+
+}  // namespace rtdd

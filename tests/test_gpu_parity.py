@@ -56,10 +56,67 @@ def test_solver_bit_exact(ctx, oracle, lut, shape, level, levels, iters, contrac
         rng = np.random.default_rng(1)
         free = p["mask"] != 255
         p["depth"][free] = rng.uniform(0, 255, free.sum()).astype(np.float32)
-    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, level, levels - 1, lut, contract, threads=8)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, level, levels - 1, lut, contract, threads=min(8, oracle.max_threads()))
     got = _solve_gpu(ctx, p, iters, level, levels, contract)
     assert np.abs(got - want).max() <= TOL
     assert_bit_equal(got, want, f"solver {shape} level {level}")
+
+
+@pytest.mark.parametrize("tile,depth", [(1, 1), (1, 4), (1, 7), (1, 8), (1, 16), (2, 4), (2, 8), (2, 5), (3, 4), (3, 12), (3, 16)])
+@pytest.mark.parametrize("shape,iters,level,levels", [((200, 333), 37, 0, 1), ((67, 120), 64, 1, 2), ((300, 130), 24, 0, 2), ((129, 129), 19, 0, 1)])
+def test_blocked_kernel_bit_exact(ctx, oracle, lut, tile, depth, shape, iters, level, levels):
+    """Temporal blocking is only a re-schedule: any tile shape / depth must reproduce the oracle bit for bit."""
+    p = make_problem(shape[0], shape[1], seed=shape[0] * 7 + shape[1])
+    if level != levels - 1:
+        rng = np.random.default_rng(2)
+        free = p["mask"] != 255
+        p["depth"][free] = rng.uniform(0, 255, free.sum()).astype(np.float32)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, level, levels - 1, lut, 1, threads=min(8, oracle.max_threads()))
+    got = _solve_gpu(ctx, p, iters, level, levels, 1, opts={rt.OPT_SWEEP_KERNEL: 2, rt.OPT_TILE: tile, rt.OPT_TEMPORAL_DEPTH: depth})
+    for k in (rt.OPT_SWEEP_KERNEL, rt.OPT_TILE, rt.OPT_TEMPORAL_DEPTH):
+        ctx.set_option(k, 0)
+    assert_bit_equal(got, want, f"blocked tile {tile} depth {depth} {shape}")
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("contract", [0, 1])
+def test_both_kernels_both_contractions(ctx, oracle, lut, kernel, contract):
+    p = make_problem(150, 260, seed=8)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 45, 0, 0, lut, contract, threads=min(8, oracle.max_threads()))
+    got = _solve_gpu(ctx, p, 45, 0, 1, contract, opts={rt.OPT_SWEEP_KERNEL: kernel})
+    ctx.set_option(rt.OPT_SWEEP_KERNEL, 0)
+    assert_bit_equal(got, want)
+
+
+def test_residual_stop_and_rbgs_extensions(ctx, oracle, lut):
+    """Extensions (no reference behaviour): residual-stopped Jacobi and red-black Gauss-Seidel."""
+    p = make_problem(96, 128, seed=12)
+    p["gray"] = np.ascontiguousarray(p["gray"] >> 4)             # well-conditioned (see tests/test_oracle.py)
+    rows, cols = 96, 128
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    ctx.set_option(rt.OPT_FP_CONTRACT, 1)
+    idx = oracle.index_to_weight(p["gray"], None, 0, 0)
+    # Chebyshev-Jacobi with a residual stop: stops early, and the reported residual is the oracle's
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_CHEBYSHEV_JACOBI, maxIterations=4000, tolerance=1e-3, checkEvery=20)
+    got = down(d)
+    assert its < 4000 and its % 20 == 0 and res <= 1e-3
+    assert res == np.float32(oracle.residual(got, idx, p["mask"], lut, 1))
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], its, 0, 0, lut, 1)
+    assert_bit_equal(got, want, "residual-stopped solve == fixed-count solve of the same length")
+    # red-black Gauss-Seidel: bit-exact against the oracle's sweep
+    d = up(p["depth"])
+    its, _ = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=25, tolerance=0.0)
+    x = p["depth"].copy()
+    for _ in range(25):
+        oracle.rbgs_sweep(x, idx, p["mask"], lut, 1)
+    assert its == 25
+    assert_bit_equal(down(d), x, "rbgs")
+    # and to a residual
+    d = up(p["depth"])
+    its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=20000, tolerance=1e-4, checkEvery=50)
+    assert res <= 1e-4 and its < 20000
+    assert oracle.residual(down(d), idx, p["mask"], lut, 1) <= 1e-4
 
 
 def test_solver_zero_iterations_returns_input(ctx):
