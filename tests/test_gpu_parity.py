@@ -98,9 +98,9 @@ def test_residual_stop_and_rbgs_extensions(ctx, oracle, lut):
     idx = oracle.index_to_weight(p["gray"], None, 0, 0)
     # Chebyshev-Jacobi with a residual stop: stops early, and the reported residual is the oracle's
     d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
-    its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_CHEBYSHEV_JACOBI, maxIterations=4000, tolerance=1e-3, checkEvery=20)
+    its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_CHEBYSHEV_JACOBI, maxIterations=4000, tolerance=2e-3, checkEvery=20)
     got = down(d)
-    assert its < 4000 and its % 20 == 0 and res <= 1e-3
+    assert its < 4000 and its % 20 == 0 and res <= 2e-3
     assert res == np.float32(oracle.residual(got, idx, p["mask"], lut, 1))
     want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], its, 0, 0, lut, 1)
     assert_bit_equal(got, want, "residual-stopped solve == fixed-count solve of the same length")
