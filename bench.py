@@ -39,11 +39,13 @@ def cpu_baseline(rows, cols, seconds_target=12.0):
     p = make_problem(rows, cols, seed=1234)
     lut = oracle.load_weights(0.4)
     threads = oracle.max_threads()
-    d = p["depth"].copy()
-    t = time.perf_counter(); oracle.solve(d, p["mask"], p["gray"], 4, 0, 0, lut, 1, threads=threads); per = (time.perf_counter() - t) / 4
-    n = int(max(8, min(400, seconds_target / max(per, 1e-6))))
-    d = p["depth"].copy()
-    t = time.perf_counter(); oracle.solve(d, p["mask"], p["gray"], n, 0, 0, lut, 1, threads=threads); el = time.perf_counter() - t
+    n, el = 16, 0.0
+    while True:                               # grow the sample until it is ~seconds_target of CPU work
+        d = p["depth"].copy()
+        t = time.perf_counter(); oracle.solve(d, p["mask"], p["gray"], n, 0, 0, lut, 1, threads=threads); el = time.perf_counter() - t
+        if el >= 0.6 * seconds_target or n >= 200000:
+            break
+        n = int(min(200000, max(2 * n, n * seconds_target / max(el, 1e-3))))
     return {"value": rows * cols * n / el / 1e6, "unit": "Mpixel-iterations/s", "cores": threads, "kind": "port",
             "sample": f"{n} sweeps of the same {cols}x{rows} problem (incl. the edge-weight pass), OpenMP over rows, {el:.1f} s"}
 
@@ -138,6 +140,17 @@ def main():
                      "traffic": None, "kernel": "sweep", "launch_us": launch_us,
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX_ITER * rows * cols * sweeps_per_launch},
     }
+    # HBM-side traffic of the sweep kernel comes from a separate rocprofv3 --pmc pass of this same command
+    # (scripts/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), committed under profiles/.
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        if prof.get("workload") == args.workload and not (args.sweep_kernel or args.tile or args.temporal_depth):
+            for name, k in prof["kernels"].items():
+                if "k_sweep" in name:
+                    out["roofline"]["traffic"] = k["hbm_bytes_per_launch_corrected"]
+                    out["roofline"]["traffic_source"] = prof.get("source", "profiles/traffic_latest.json")
+    except (OSError, ValueError, KeyError):
+        pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rows, cols)
     ctx.close()

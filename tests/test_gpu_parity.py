@@ -171,6 +171,42 @@ def test_solver_denormal_weights_survive(ctx, oracle, lut):
     assert_bit_equal(got, want)
 
 
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_denormal_divisor_takes_the_full_divide(ctx, oracle, lut, kernel):
+    """Checkerboard gray: all four weights of every pixel are the denormal w[255] = 5.6e-45, so the
+    divisor sum(w) is itself denormal and the blocked kernel must leave its hoisted-reciprocal path."""
+    rows, cols = 40, 72
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    gray = (((yy + xx) & 1) * 255).astype(np.uint8)
+    mask = np.full((rows, cols), 32, np.uint8); mask[::9, ::7] = 255
+    rng = np.random.default_rng(6)
+    depth = rng.uniform(0, 255, (rows, cols)).astype(np.float32)
+    p = {"gray": gray, "mask": mask, "depth": depth}
+    assert lut[255] * 4 < 1.2e-38                         # really denormal
+    want = oracle.solve(depth.copy(), mask, gray, 40, 0, 0, lut, 1)
+    got = _solve_gpu(ctx, p, 40, 0, 1, 1, opts={rt.OPT_SWEEP_KERNEL: kernel})
+    ctx.set_option(rt.OPT_SWEEP_KERNEL, 0)
+    assert_bit_equal(got, want, "denormal divisor")
+
+
+@pytest.mark.parametrize("shape", [(24, 24), (60, 200)])
+def test_values_decaying_through_the_denormal_range(ctx, oracle, lut, shape):
+    """All labels 0: the iterate decays towards 0 through 1e-31 .. denormals .. exact zero, which
+    drives the weighted sums below 2^-103 where the divide needs hardware rescaling."""
+    rows, cols = shape
+    rng = np.random.default_rng(3)
+    gray = rng.integers(100, 104, (rows, cols), dtype=np.uint8)
+    mask = np.full((rows, cols), 32, np.uint8); mask[0, :] = mask[-1, :] = 255; mask[:, 0] = mask[:, -1] = 255; mask[::5, ::5] = 255
+    depth = np.where(mask == 255, 0.0, 255.0).astype(np.float32)
+    p = {"gray": gray, "mask": mask, "depth": depth}
+    iters = 1500
+    want = oracle.solve(depth.copy(), mask, gray, iters, 0, 0, lut, 1)
+    tiny = np.abs(want[mask != 255])
+    assert tiny.max() < 1e-30 and (tiny > 0).any()        # the test really is in the tiny regime
+    got = _solve_gpu(ctx, p, iters, 0, 1, 1)
+    assert_bit_equal(got, want, "decay to denormals")
+
+
 @pytest.mark.parametrize("level,levels", [(0, 1), (0, 3), (1, 3), (2, 3)])
 def test_index_to_weight_bit_exact(ctx, oracle, level, levels):
     import torch
