@@ -101,11 +101,10 @@ def main():
     def step(i):
         ctx.GPUMatrixFreeSolver(depths[i], mask, gray, rows, cols, 0.4, iters, 1e-5, 0)
 
+    from realtimedepthdiffusion_amd import shard
+
     def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        shard.fence(dist, torch.cuda.synchronize)
 
     for i in range(args.warmup):
         step(i)
@@ -118,13 +117,9 @@ def main():
         pr = ctx.profile(); sweep_ms += pr.sweep_ms; launches += pr.launches; sweeps += pr.sweeps
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     px_iter_per_step = rows * cols * iters
-    value = world * args.steps * px_iter_per_step / elapsed / 1e6
+    units, elapsed, thr = shard.aggregate(args.steps * px_iter_per_step, elapsed, dist, dev)   # SUM of units, MAX of time
+    value = thr / 1e6
     launch_us = sweep_ms * 1e3 / max(launches, 1)
     sweeps_per_launch = sweeps / max(launches, 1)
     achieved = ALGO_BYTES_PER_PX_ITER * rows * cols * sweeps_per_launch / (launch_us * 1e-6) / 1e9

@@ -156,6 +156,41 @@ int rtdd_simulate_haze(rtdd_ctx *ctx, const uint8_t *original, size_t originalPi
                        const float *depth, size_t depthPitch, uint8_t *artistic, size_t artisticPitch,
                        int rows, int cols);
 
+/* ---- whole-estimate driver ------------------------------------------------
+ * One depth estimate = the loop body of src/main.cpp:232-295, run as a single stream-ordered launch
+ * sequence with the gray pyramid, f32 pyrUp and u8 conversion ON THE DEVICE (the reference round-trips
+ * through the host for cv::pyrDown / cv::pyrUp).  The context owns the pyramid images, like main.cpp
+ * owns its GpuMats (src/main.cpp:117-137).  The OpenCV ops are third party: the formulas used are
+ * stated in oracle/rtdd_cascade_oracle.c. */
+enum rtdd_pyramid_image_kind {
+    RTDD_IMG_ORIGINAL = 0,          /* u8x3, level 0 only */
+    RTDD_IMG_GRAY = 1,              /* u8, ceil-sized chain (cv::pyrDown's default size) */
+    RTDD_IMG_SCRIBBLE = 2,          /* u8, 255 = Dirichlet */
+    RTDD_IMG_EDITED = 3,            /* u8x3 */
+    RTDD_IMG_DEPTH = 4,             /* f32 */
+    RTDD_IMG_DEPTH_U8 = 5,          /* u8, level 0 only */
+    RTDD_IMG_ARTISTIC = 6           /* u8x3, level 0 only: output of the effect calls */
+};
+int rtdd_pyramid_levels(int rows, int cols);             /* src/main.cpp:95 */
+int rtdd_pyramid_create(rtdd_ctx *ctx, int rows, int cols);   /* main.cpp:92-155 minus I/O: images, depth := 255, rtdd_allocate */
+int rtdd_pyramid_destroy(rtdd_ctx *ctx);
+/* image: DEVICE pointer to an interleaved BGR u8 image; builds the gray pyramid, edited[0] := image, scribble[0] := 0 */
+int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch);
+/* annotation: DEVICE pointer to a 1-channel u8 map; decode rule of src/main.cpp:160-168 (value != 32 -> label, mask 255) */
+int rtdd_pyramid_set_annotation(rtdd_ctx *ctx, const uint8_t *annotation, size_t pitch);
+int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *pitch, int *rows, int *cols);
+/* src/main.cpp:239-291; asynchronous; results in RTDD_IMG_DEPTH (all levels) and RTDD_IMG_DEPTH_U8 */
+int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations);
+/* the standalone third-party pieces, exposed for parity tests against the oracle's restatement */
+int rtdd_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bgrPitch, uint8_t *gray, size_t grayPitch, int rows, int cols);
+int rtdd_pyrdown_gray(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, int rows, int cols, uint8_t *dst, size_t dstPitch);
+int rtdd_pyrup_depth(rtdd_ctx *ctx, const float *src, size_t srcPitch, int rows, int cols,
+                     float *dst, size_t dstPitch, int dstRows, int dstCols);
+int rtdd_depth_to_u8(rtdd_ctx *ctx, const float *src, size_t srcPitch, uint8_t *dst, size_t dstPitch, int rows, int cols);
+/* pitched host<->device copies on the context's stream, then a stream sync (harness / binding convenience) */
+int rtdd_upload(rtdd_ctx *ctx, void *dev, size_t devPitch, const void *host, size_t hostPitch, size_t widthBytes, int rows);
+int rtdd_download(rtdd_ctx *ctx, void *host, size_t hostPitch, const void *dev, size_t devPitch, size_t widthBytes, int rows);
+
 /* ---- instrumentation ------------------------------------------------------------------------ */
 
 /* Device time of the solver's sweep launches in the most recent rtdd_matrix_free_solver /

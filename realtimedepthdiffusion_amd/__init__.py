@@ -31,7 +31,11 @@ C_ABI_SYMBOLS = [
     "rtdd_load_weights", "rtdd_matrix_free_solver", "rtdd_solve_ex", "rtdd_index_to_weight", "rtdd_convert_to_float",
     "rtdd_pyrdown_annotation", "rtdd_paint_image", "rtdd_simulate_defocus", "rtdd_simulate_desaturation",
     "rtdd_simulate_haze", "rtdd_profile_enable", "rtdd_profile_get",
+    "rtdd_pyramid_levels", "rtdd_pyramid_create", "rtdd_pyramid_destroy", "rtdd_pyramid_set_image",
+    "rtdd_pyramid_set_annotation", "rtdd_pyramid_image", "rtdd_estimate_depth", "rtdd_bgr2gray", "rtdd_pyrdown_gray",
+    "rtdd_pyrup_depth", "rtdd_depth_to_u8", "rtdd_upload", "rtdd_download",
 ]
+IMG_ORIGINAL, IMG_GRAY, IMG_SCRIBBLE, IMG_EDITED, IMG_DEPTH, IMG_DEPTH_U8, IMG_ARTISTIC = range(7)
 # Itanium-mangled names of the reference's ten free functions
 DROPIN_SYMBOLS = [
     "_Z23GPUAllocateDeviceMemoryiii", "_Z19GPUFreeDeviceMemoryi", "_Z14GPULoadWeightsf",
@@ -218,6 +222,58 @@ class Context:
     def GPUSimulateHaze(self, originalImage, depthImage, artisticImage, rows, cols):
         o, op = _img(originalImage); d, dp = _img(depthImage); a, ap = _img(artisticImage)
         self._check(lib().rtdd_simulate_haze(self._h, o, op, d, dp, a, ap, C.c_int(rows), C.c_int(cols)))
+
+
+    # ---- whole-estimate driver (src/main.cpp:92-155, 232-295)
+    def pyramid_create(self, rows, cols):
+        self._check(lib().rtdd_pyramid_create(self._h, C.c_int(rows), C.c_int(cols)))
+        return int(lib().rtdd_pyramid_levels(C.c_int(rows), C.c_int(cols)))
+
+    def pyramid_destroy(self):
+        self._check(lib().rtdd_pyramid_destroy(self._h))
+
+    def pyramid_set_image(self, bgr):
+        p, pitch = _img(bgr)
+        self._check(lib().rtdd_pyramid_set_image(self._h, p, pitch))
+
+    def pyramid_set_annotation(self, annotation):
+        p, pitch = _img(annotation)
+        self._check(lib().rtdd_pyramid_set_annotation(self._h, p, pitch))
+
+    def pyramid_image(self, kind, level=0):
+        """(ptr, pitch_bytes, rows, cols) of a context-owned pyramid image."""
+        ptr = C.c_void_p(); pitch = C.c_size_t(); rows = C.c_int(); cols = C.c_int()
+        self._check(lib().rtdd_pyramid_image(self._h, C.c_int(kind), C.c_int(level), C.byref(ptr), C.byref(pitch), C.byref(rows), C.byref(cols)))
+        return ptr.value, pitch.value, rows.value, cols.value
+
+    def pyramid_download(self, kind, level=0):
+        import numpy as np
+        ptr, pitch, rows, cols = self.pyramid_image(kind, level)
+        dtype, ch = (np.float32, 1) if kind == IMG_DEPTH else (np.uint8, 3 if kind in (IMG_ORIGINAL, IMG_EDITED, IMG_ARTISTIC) else 1)
+        out = np.empty((rows, cols, ch) if ch == 3 else (rows, cols), dtype)
+        if rows and cols:
+            w = cols * ch * out.itemsize
+            self._check(lib().rtdd_download(self._h, C.c_void_p(out.ctypes.data), C.c_size_t(w), C.c_void_p(ptr), C.c_size_t(pitch), C.c_size_t(w), C.c_int(rows)))
+        return out
+
+    def estimate_depth(self, maxIterations=1000):
+        self._check(lib().rtdd_estimate_depth(self._h, C.c_int(maxIterations)))
+
+    def bgr2gray(self, bgr, gray, rows, cols):
+        b, bp = _img(bgr); g, gp = _img(gray)
+        self._check(lib().rtdd_bgr2gray(self._h, b, bp, g, gp, C.c_int(rows), C.c_int(cols)))
+
+    def pyrdown_gray(self, src, rows, cols, dst):
+        s, sp = _img(src); d, dp = _img(dst)
+        self._check(lib().rtdd_pyrdown_gray(self._h, s, sp, C.c_int(rows), C.c_int(cols), d, dp))
+
+    def pyrup_depth(self, src, rows, cols, dst, drows, dcols):
+        s, sp = _img(src); d, dp = _img(dst)
+        self._check(lib().rtdd_pyrup_depth(self._h, s, sp, C.c_int(rows), C.c_int(cols), d, dp, C.c_int(drows), C.c_int(dcols)))
+
+    def depth_to_u8(self, src, dst, rows, cols):
+        s, sp = _img(src); d, dp = _img(dst)
+        self._check(lib().rtdd_depth_to_u8(self._h, s, sp, d, dp, C.c_int(rows), C.c_int(cols)))
 
 
 # ---- pitched device images (torch is plumbing for device memory only) ----------------------------

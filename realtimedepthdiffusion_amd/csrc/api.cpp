@@ -95,6 +95,7 @@ int rtdd_ctx_destroy(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_OK;
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    pyramid_free(ctx);
     free_levels(ctx);
     if (ctx->lut_dev) (void)hipFree(ctx->lut_dev);
     if (ctx->omega_dev) (void)hipFree(ctx->omega_dev);

@@ -1,0 +1,229 @@
+// cascade_api.cpp -- pyramid state and the whole-estimate driver (include/rtdd.h, "whole-estimate
+// driver").  Follows /root/reference/src/main.cpp:92-155 (setup) and :232-295 (estimate).
+#include <cmath>
+#include <new>
+
+#include "rtdd_internal.hpp"
+
+namespace rtdd {
+
+struct Image {
+    void *ptr = nullptr;
+    size_t pitch = 0;
+    int rows = 0, cols = 0, elem = 1;
+};
+
+struct Pyramid {
+    int levels = 0, rows = 0, cols = 0;
+    Image original, depth_u8, artistic;
+    std::vector<Image> gray, scribble, edited, depth;
+};
+
+static int alloc_image(rtdd_ctx *ctx, Image &im, int rows, int cols, int elem, int fill) {
+    im.rows = rows; im.cols = cols; im.elem = elem;
+    im.pitch = ((size_t)cols * elem + 511) / 512 * 512;       // like cudaMallocPitch: rows padded to 512 B
+    RTDD_HIP(ctx, hipMalloc(&im.ptr, im.pitch * (size_t)(rows > 0 ? rows : 1)));
+    RTDD_HIP(ctx, hipMemsetAsync(im.ptr, fill, im.pitch * (size_t)(rows > 0 ? rows : 1), ctx->stream));
+    return RTDD_OK;
+}
+
+static void free_image(Image &im) {
+    if (im.ptr) (void)hipFree(im.ptr);
+    im = Image();
+}
+
+void pyramid_free(rtdd_ctx *ctx) {
+    if (!ctx->pyr) return;
+    Pyramid *p = ctx->pyr;
+    free_image(p->original); free_image(p->depth_u8); free_image(p->artistic);
+    for (auto *v : {&p->gray, &p->scribble, &p->edited, &p->depth})
+        for (auto &im : *v) free_image(im);
+    delete p;
+    ctx->pyr = nullptr;
+}
+
+}  // namespace rtdd
+
+using namespace rtdd;
+
+#define REQUIRE(ctx, cond, msg) \
+    do { if (!(cond)) return fail((ctx), RTDD_ERR_INVALID, msg); } while (0)
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int rtdd_pyramid_levels(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const int m = rows < cols ? rows : cols;
+    return (int)(log2((double)((m / 45) > 1 ? (m / 45) : 1)) + 1);          // src/main.cpp:95 (integer /45)
+}
+
+int rtdd_pyramid_create(rtdd_ctx *ctx, int rows, int cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, rows > 0 && cols > 0, "rows and cols must be positive");
+    DeviceGuard g(ctx->device);
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pyramid_free(ctx);
+    Pyramid *p = new (std::nothrow) Pyramid();
+    if (!p) return fail(ctx, RTDD_ERR_NOMEM, "pyramid");
+    ctx->pyr = p;
+    p->rows = rows; p->cols = cols; p->levels = rtdd_pyramid_levels(rows, cols);
+    p->gray.resize(p->levels); p->scribble.resize(p->levels); p->edited.resize(p->levels); p->depth.resize(p->levels);
+    int rc;
+    if ((rc = alloc_image(ctx, p->original, rows, cols, 3, 0)) != RTDD_OK) return rc;
+    if ((rc = alloc_image(ctx, p->artistic, rows, cols, 3, 0)) != RTDD_OK) return rc;
+    if ((rc = alloc_image(ctx, p->depth_u8, rows, cols, 1, 255)) != RTDD_OK) return rc;
+    int gr = rows, gc = cols;
+    for (int l = 0; l < p->levels; l++) {
+        const int lr = (int)(rows / powf(2, l)), lc = (int)(cols / powf(2, l));   // src/main.cpp:103,129
+        if ((rc = alloc_image(ctx, p->gray[l], gr, gc, 1, 0)) != RTDD_OK) return rc;          // ceil chain
+        if ((rc = alloc_image(ctx, p->scribble[l], lr, lc, 1, 0)) != RTDD_OK) return rc;      // :132-133
+        if ((rc = alloc_image(ctx, p->edited[l], lr, lc, 3, 0)) != RTDD_OK) return rc;        // :130-131
+        if ((rc = alloc_image(ctx, p->depth[l], lr, lc, 4, 0)) != RTDD_OK) return rc;
+        if (lr > 0 && lc > 0 && (rc = launch_fill_f32(ctx, (float *)p->depth[l].ptr, p->depth[l].pitch, lr, lc, 255.0f)) != RTDD_OK) return rc;   // :136
+        gr = (gr + 1) / 2; gc = (gc + 1) / 2;
+    }
+    rc = rtdd_allocate(ctx, rows, cols, p->levels);                          // :149 (syncs)
+    return rc;
+}
+
+int rtdd_pyramid_destroy(rtdd_ctx *ctx) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pyramid_free(ctx);
+    return RTDD_OK;
+}
+
+int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
+    Pyramid *p = ctx->pyr;
+    REQUIRE(ctx, bgr && pitch >= (size_t)p->cols * 3, "bad image");
+    DeviceGuard g(ctx->device);
+    RTDD_HIP(ctx, hipMemcpy2DAsync(p->original.ptr, p->original.pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+    RTDD_HIP(ctx, hipMemcpy2DAsync(p->edited[0].ptr, p->edited[0].pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));   // :158
+    RTDD_HIP(ctx, hipMemsetAsync(p->scribble[0].ptr, 0, p->scribble[0].pitch * p->rows, ctx->stream));
+    int rc = launch_bgr2gray(ctx, (const uint8_t *)p->original.ptr, p->original.pitch, (uint8_t *)p->gray[0].ptr, p->gray[0].pitch, p->rows, p->cols);
+    // the gray pyramid depends on the image only: built once here instead of once per estimate (:241-247)
+    for (int l = 1; l < p->levels && rc == RTDD_OK; l++)
+        rc = launch_pyrdown_u8(ctx, (const uint8_t *)p->gray[l - 1].ptr, p->gray[l - 1].pitch, p->gray[l - 1].rows, p->gray[l - 1].cols,
+                               (uint8_t *)p->gray[l].ptr, p->gray[l].pitch);
+    return rc;
+}
+
+int rtdd_pyramid_set_annotation(rtdd_ctx *ctx, const uint8_t *annotation, size_t pitch) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
+    Pyramid *p = ctx->pyr;
+    REQUIRE(ctx, annotation && pitch >= (size_t)p->cols, "bad annotation");
+    DeviceGuard g(ctx->device);
+    return launch_decode_annotation(ctx, (const uint8_t *)p->original.ptr, p->original.pitch, annotation, pitch,
+                                    (uint8_t *)p->edited[0].ptr, p->edited[0].pitch, (uint8_t *)p->scribble[0].ptr, p->scribble[0].pitch, p->rows, p->cols);
+}
+
+int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *pitch, int *rows, int *cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
+    Pyramid *p = ctx->pyr;
+    const Image *im = nullptr;
+    REQUIRE(ctx, level >= 0 && level < p->levels, "level out of range");
+    switch (kind) {
+        case RTDD_IMG_ORIGINAL: im = level == 0 ? &p->original : nullptr; break;
+        case RTDD_IMG_DEPTH_U8: im = level == 0 ? &p->depth_u8 : nullptr; break;
+        case RTDD_IMG_ARTISTIC: im = level == 0 ? &p->artistic : nullptr; break;
+        case RTDD_IMG_GRAY: im = &p->gray[level]; break;
+        case RTDD_IMG_SCRIBBLE: im = &p->scribble[level]; break;
+        case RTDD_IMG_EDITED: im = &p->edited[level]; break;
+        case RTDD_IMG_DEPTH: im = &p->depth[level]; break;
+        default: break;
+    }
+    REQUIRE(ctx, im != nullptr, "no such pyramid image");
+    if (ptr) *ptr = im->ptr;
+    if (pitch) *pitch = im->pitch;
+    if (rows) *rows = im->rows;
+    if (cols) *cols = im->cols;
+    return RTDD_OK;
+}
+
+int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
+    REQUIRE(ctx, maxIterations >= 0, "maxIterations must be >= 0");
+    Pyramid *p = ctx->pyr;
+    const int P = p->levels;
+    int rc = RTDD_OK;
+    for (int l = 1; l < P && rc == RTDD_OK; l++)                               // src/main.cpp:249-253
+        rc = rtdd_pyrdown_annotation(ctx, (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch,
+                                     (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch, p->edited[l - 1].rows, p->edited[l - 1].cols,
+                                     (uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch, (uint8_t *)p->edited[l].ptr, p->edited[l].pitch,
+                                     p->edited[l].rows, p->edited[l].cols);
+    if (rc != RTDD_OK) return rc;
+    rc = rtdd_convert_to_float(ctx, (const uint8_t *)p->edited[P - 1].ptr, p->edited[P - 1].pitch, (float *)p->depth[P - 1].ptr, p->depth[P - 1].pitch,
+                               (const uint8_t *)p->scribble[P - 1].ptr, p->scribble[P - 1].pitch, p->edited[P - 1].rows, p->edited[P - 1].cols);   // :257-259
+    for (int l = P - 1; l >= 0 && rc == RTDD_OK; l--) {                        // :261-288
+        const int iters = (int)(maxIterations / powf(2.0, (P - 1) - l));       // :263
+        if (p->depth[l].rows > 0 && p->depth[l].cols > 0)
+            rc = rtdd_matrix_free_solver(ctx, (float *)p->depth[l].ptr, p->depth[l].pitch, (const uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch,
+                                         (const uint8_t *)p->gray[l].ptr, p->gray[l].pitch, p->depth[l].rows, p->depth[l].cols, 0.4f, iters, 1e-5f, l);
+        if (rc == RTDD_OK && l > 0) {
+            DeviceGuard g(ctx->device);
+            rc = launch_pyrup_inject(ctx, (const float *)p->depth[l].ptr, p->depth[l].pitch, p->depth[l].rows, p->depth[l].cols,
+                                     (float *)p->depth[l - 1].ptr, p->depth[l - 1].pitch, p->depth[l - 1].rows, p->depth[l - 1].cols,
+                                     (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch,
+                                     (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch);                                      // :272-283
+        }
+    }
+    if (rc != RTDD_OK) return rc;
+    DeviceGuard g(ctx->device);
+    return launch_depth_to_u8(ctx, (const float *)p->depth[0].ptr, p->depth[0].pitch, (uint8_t *)p->depth_u8.ptr, p->depth_u8.pitch, p->rows, p->cols);   // :290
+}
+
+int rtdd_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bgrPitch, uint8_t *gray, size_t grayPitch, int rows, int cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, bgr && gray && rows > 0 && cols > 0 && bgrPitch >= (size_t)cols * 3 && grayPitch >= (size_t)cols, "bad argument");
+    DeviceGuard g(ctx->device);
+    return launch_bgr2gray(ctx, bgr, bgrPitch, gray, grayPitch, rows, cols);
+}
+
+int rtdd_pyrdown_gray(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, int rows, int cols, uint8_t *dst, size_t dstPitch) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, src && dst && rows > 0 && cols > 0 && srcPitch >= (size_t)cols && dstPitch >= (size_t)((cols + 1) / 2), "bad argument");
+    DeviceGuard g(ctx->device);
+    return launch_pyrdown_u8(ctx, src, srcPitch, rows, cols, dst, dstPitch);
+}
+
+int rtdd_pyrup_depth(rtdd_ctx *ctx, const float *src, size_t srcPitch, int rows, int cols, float *dst, size_t dstPitch, int dstRows, int dstCols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, src && dst && rows > 0 && cols > 0 && dstRows > 0 && dstCols > 0 && srcPitch >= (size_t)cols * 4 && dstPitch >= (size_t)dstCols * 4, "bad argument");
+    DeviceGuard g(ctx->device);
+    return launch_pyrup_inject(ctx, src, srcPitch, rows, cols, dst, dstPitch, dstRows, dstCols, nullptr, 0, nullptr, 0);
+}
+
+int rtdd_depth_to_u8(rtdd_ctx *ctx, const float *src, size_t srcPitch, uint8_t *dst, size_t dstPitch, int rows, int cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, src && dst && rows > 0 && cols > 0 && srcPitch >= (size_t)cols * 4 && dstPitch >= (size_t)cols, "bad argument");
+    DeviceGuard g(ctx->device);
+    return launch_depth_to_u8(ctx, src, srcPitch, dst, dstPitch, rows, cols);
+}
+
+int rtdd_upload(rtdd_ctx *ctx, void *dev, size_t devPitch, const void *host, size_t hostPitch, size_t widthBytes, int rows) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, dev && host && rows >= 0 && devPitch >= widthBytes && hostPitch >= widthBytes, "bad argument");
+    DeviceGuard g(ctx->device);
+    RTDD_HIP(ctx, hipMemcpy2DAsync(dev, devPitch, host, hostPitch, widthBytes, rows, hipMemcpyHostToDevice, ctx->stream));
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTDD_OK;
+}
+
+int rtdd_download(rtdd_ctx *ctx, void *host, size_t hostPitch, const void *dev, size_t devPitch, size_t widthBytes, int rows) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, dev && host && rows >= 0 && devPitch >= widthBytes && hostPitch >= widthBytes, "bad argument");
+    DeviceGuard g(ctx->device);
+    RTDD_HIP(ctx, hipMemcpy2DAsync(host, hostPitch, dev, devPitch, widthBytes, rows, hipMemcpyDeviceToHost, ctx->stream));
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTDD_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -52,8 +52,11 @@ struct Options {
 
 }  // namespace rtdd
 
+namespace rtdd { struct Pyramid; }
+
 struct rtdd_ctx {
     int device = 0;
+    rtdd::Pyramid *pyr = nullptr;       // whole-estimate driver state (cascade_api.cpp)
     hipStream_t stream = nullptr;
     std::vector<rtdd::Level> levels;
     int maxLevel = -1;
@@ -131,6 +134,17 @@ int launch_desaturate(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const uint8
                       uint8_t *art, size_t ap, int rows, int cols);
 int launch_haze(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *depth, size_t dp, uint8_t *art, size_t ap, int rows, int cols);
 int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *depth, size_t dp, uint8_t *art, size_t ap, int rows, int cols);
+
+// ---- cascade.hip -------------------------------------------------------------------------------
+int launch_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, uint8_t *gray, size_t gp, int rows, int cols);
+int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, int cols, uint8_t *dst, size_t dp);
+int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
+                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp);
+int launch_depth_to_u8(rtdd_ctx *ctx, const float *src, size_t sp, uint8_t *dst, size_t dp, int rows, int cols);
+int launch_decode_annotation(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, const uint8_t *ann, size_t ap, uint8_t *edited, size_t ep,
+                             uint8_t *scribble, size_t sp, int rows, int cols);
+int launch_fill_f32(rtdd_ctx *ctx, float *dst, size_t dp, int rows, int cols, float v);
+void pyramid_free(rtdd_ctx *ctx);
 
 // the reference's host-side omega recurrence (src/GPUSolver.cu:282-299)
 void omega_schedule(int n, std::vector<float> &out);

@@ -1,0 +1,108 @@
+"""Whole-estimate driver on the GPU against the oracle-composed cascade (-m gpu)."""
+import numpy as np
+import pytest
+
+import realtimedepthdiffusion_amd as rt
+from cascade_ref import Cascade, pyramid_levels
+from golden_util import NAMES, load
+from gpu_util import assert_bit_equal, down, up
+from realtimedepthdiffusion_amd.synth import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _bgr(rows, cols, seed):
+    p = make_problem(rows, cols, seed=seed)
+    g = p["gray"].astype(np.int32)
+    rng = np.random.default_rng(seed)
+    bgr = np.stack([np.clip(g + rng.integers(-20, 21, g.shape), 0, 255) for _ in range(3)], -1).astype(np.uint8)
+    ann = np.where(p["mask"] == 255, p["edited"][..., 0], 32).astype(np.uint8)
+    ann[ann == 32 + 0] = 32
+    return bgr, ann
+
+
+@pytest.mark.parametrize("shape", [(6, 8), (67, 120), (135, 241), (853, 1280)])
+def test_third_party_pieces_match_the_restatement(oracle, shape):
+    rows, cols = shape
+    bgr, _ = _bgr(rows, cols, 3)
+    with rt.Context(0) as c:
+        g = up(np.zeros((rows, cols), np.uint8))
+        c.bgr2gray(up(bgr), g, rows, cols)
+        gray = oracle.bgr2gray(bgr)
+        assert np.array_equal(down(g), gray)
+        d = up(np.zeros(((rows + 1) // 2, (cols + 1) // 2), np.uint8))
+        c.pyrdown_gray(g, rows, cols, d)
+        assert np.array_equal(down(d), oracle.pyrdown_u8(gray))
+        src = np.random.default_rng(1).uniform(-10, 300, (rows, cols)).astype(np.float32)
+        for drows, dcols in ((2 * rows, 2 * cols), (2 * rows + 1, 2 * cols + 1), (2 * rows + 1, 2 * cols)):
+            dst = up(np.zeros((drows, dcols), np.float32))
+            c.pyrup_depth(up(src), rows, cols, dst, drows, dcols)
+            assert_bit_equal(down(dst), oracle.pyrup_f32(src, drows, dcols), f"pyrUp {shape}->{drows}x{dcols}")
+        u = up(np.zeros((rows, cols), np.uint8))
+        vals = src.copy(); vals[0, :6] = [0.5, 1.5, 2.5, 254.5, 255.5, -0.5][:min(6, cols)] if cols >= 6 else vals[0, :6]
+        c.depth_to_u8(up(vals), u, rows, cols)
+        assert np.array_equal(down(u), oracle.depth_to_u8(vals))
+
+
+def test_pyramid_level_rule():
+    for rows, cols in ((256, 256), (1080, 1920), (2160, 3840), (4320, 7680), (624, 672), (44, 100), (90, 91)):
+        assert rt.lib().rtdd_pyramid_levels(rows, cols) == pyramid_levels(rows, cols)
+    assert pyramid_levels(1080, 1920) == 5 and pyramid_levels(2160, 3840) == 6 and pyramid_levels(4320, 7680) == 7
+
+
+@pytest.mark.parametrize("shape,iters", [((256, 256), 1000), ((135, 241), 300), ((297, 211), 200), ((90, 91), 50)])
+def test_estimate_matches_oracle_cascade(oracle, lut, shape, iters):
+    rows, cols = shape
+    bgr, ann = _bgr(rows, cols, 11)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=min(8, oracle.max_threads()))
+    ref.estimate(iters)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        P = c.pyramid_create(rows, cols)
+        assert P == ref.P
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann))
+        c.estimate_depth(iters)
+        c.synchronize()
+        for l in range(P):
+            assert np.array_equal(c.pyramid_download(rt.IMG_GRAY, l), ref.gray[l]), f"gray {l}"
+            assert np.array_equal(c.pyramid_download(rt.IMG_SCRIBBLE, l), ref.scribble[l]), f"scribble {l}"
+            assert np.array_equal(c.pyramid_download(rt.IMG_EDITED, l)[..., 0], ref.edited[l][..., 0]), f"edited {l}"
+        for l in range(P - 1, -1, -1):
+            assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, l), ref.depth[l], f"depth level {l}")
+        assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), ref.depth_u8)
+        # warm start (--live): a second estimate continues from the first one's coarsest solution
+        ref.estimate(iters)
+        c.estimate_depth(iters); c.synchronize()
+        assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, 0), ref.depth[0], "second estimate (warm start)")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_estimate_reproduces_golden_crops(name):
+    """End to end from the committed decoded crop: gray, annotation decode, pyramid, solves, pyrUp, u8."""
+    g = load(name)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        assert c.pyramid_create(256, 256) == 3
+        c.pyramid_set_image(up(g["bgr"])); c.pyramid_set_annotation(up(g["annotation"]))
+        c.estimate_depth(1000); c.synchronize()
+        for l in range(3):
+            assert np.array_equal(c.pyramid_download(rt.IMG_GRAY, l), g[f"gray{l}"])
+            assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, l), g[f"depth_after_c1_L{l}"], f"{name} level {l}")
+        assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), g["depth_u8"])
+
+
+def test_estimate_1080p_full_cascade(oracle, lut):
+    """Full-size: the 5-level 1080p cascade (250 Mpixel-iterations) against the oracle on the host cores."""
+    rows, cols = 1080, 1920
+    bgr, ann = _bgr(rows, cols, 1234)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads())
+    ref.estimate(1000)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        assert c.pyramid_create(rows, cols) == 5
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann))
+        c.estimate_depth(1000); c.synchronize()
+        got = c.pyramid_download(rt.IMG_DEPTH, 0)
+        assert np.abs(got - ref.depth[0]).max() <= 1e-4
+        assert_bit_equal(got, ref.depth[0], "1080p cascade")
+        assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), ref.depth_u8)
