@@ -91,16 +91,18 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
                                                       const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
                                                       const float *__restrict__ omegas, int ip, int rows, int cols,
                                                       int hx, int hy, int nsweeps, float gamma) {
-    constexpr int EW = 4 * LX, NTR = NT / LX, EH = NTR * G;
+    constexpr int EW = 4 * LX, NTR = NT / LX;
     __shared__ float lut[257];
     __shared__ float4 edge[2][NTR][2][LX];     // [buffer][thread row][0 = its top row, 1 = its bottom row][lane]
 
     const int tid = threadIdx.x;
-    for (int i = tid; i < 257; i += NT) lut[i] = lut_g[i];
+    for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];       // blockDim.x <= NT: small levels launch only the thread rows they need
     __syncthreads();
 
     const int lx = tid % LX, tr = tid / LX;
-    const int TW = EW - 2 * hx, TH = EH - 2 * hy;
+    const int ntr = (int)blockDim.x / LX;          // thread rows actually launched
+    const int eh = ntr * G;                        // rows of the extended tile actually covered
+    const int TW = EW - 2 * hx, TH = eh - 2 * hy;
     const int x0 = blockIdx.x * TW - hx + 4 * lx;
     const int y0 = blockIdx.y * TH - hy + tr * G;
     const bool colok = x0 >= 0 && x0 < cols;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
         __syncthreads();
         float4 up4 = make_float4(0, 0, 0, 0), dn4 = up4;
         if (tr > 0) up4 = edge[buf][tr - 1][1][lx];
-        if (tr < NTR - 1) dn4 = edge[buf][tr + 1][0][lx];
+        if (tr < ntr - 1) dn4 = edge[buf][tr + 1][0][lx];
         const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
         const float omega = omegas[s];
 #pragma unroll
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const int y = y0 + g, ty = tr * G + g;
-        if (xin && ty >= hy && ty < EH - hy && y < rows) {
+        if (xin && ty >= hy && ty < eh - hy && y < rows) {
             const size_t off = (size_t)y * ip + x0;
             // newest iterate -> Yk, the one before it -> Ym (componentwise selects: a pointer-select would go through scratch)
             *(float4 *)(Yk + off) = make_float4(odd ? b[g][0] : a[g][0], odd ? b[g][1] : a[g][1], odd ? b[g][2] : a[g][2], odd ? b[g][3] : a[g][3]);
@@ -227,16 +229,17 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
 // ---- host side ------------------------------------------------------------------------------------
 struct TileCfg { int lx, nt, g; };
 // id -> (lanes per tile row, threads, rows per thread); extended tile = 4*lx wide, nt/lx*g tall
-static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 1024, 4}, {32, 1024, 3}, {32, 512, 3}, {16, 512, 3}, {16, 256, 3}, {32, 1024, 2}};
-constexpr int kNumTiles = 8;
+static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 1024, 4}, {32, 1024, 3}, {32, 512, 3}, {16, 512, 3}, {16, 256, 3}, {32, 1024, 2},
+                                 {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}};
+constexpr int kNumTiles = 11;
 
 template <int LX, int NT, int G>
-static void launch_cfg(rtdd_ctx *ctx, dim3 grid, const float *Xk, const float *Xm, float *Yk, float *Ym, const uint32_t *M,
+static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int nthreads, const float *Xk, const float *Xm, float *Yk, float *Ym, const uint32_t *M,
                        const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma) {
     if (ctx->opt.fp_contract)
-        hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, true>), grid, dim3(NT), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma);
+        hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, true>), grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma);
     else
-        hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, false>), grid, dim3(NT), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma);
+        hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, false>), grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma);
 }
 
 // Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
@@ -252,18 +255,19 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
     int tile = ctx->opt.tile, T = ctx->opt.temporal_depth;
     const long px = (long)rows * cols;
     int auto_tile, auto_T;
-    if (cols <= 128 && rows <= 96) { auto_tile = 4; auto_T = 8; }            // single tile, no spills
-    else if (cols <= 128 && rows <= 128) { auto_tile = 3; auto_T = 8; }      // single tile
-    else if (px < 250000L) { auto_tile = 7; auto_T = 16; }                   // e.g. 480x270: 18 us per 16 sweeps
-    else if (px < 1200000L) { auto_tile = 8; auto_T = 16; }                  // e.g. 960x540
-    else if (px < 3500000L) { auto_tile = 4; auto_T = 8; }                   // 1080p: 252 tiles on 256 CUs
+    if (cols <= 64 && rows <= 64) { auto_tile = 9; auto_T = 8; }             // ONE tile, 4 px/thread: all sweeps in one launch (0.45 us/sweep)
+    else if (cols <= 128 && rows <= 32) { auto_tile = 11; auto_T = 8; }      // ditto
+    else if (px < 40000L) { auto_tile = 9; auto_T = 24; }                    // 120x67, 240x135: idle CUs make halo redundancy free; fewer launches win
+    else if (px < 250000L) { auto_tile = 9; auto_T = 16; }                   // 480x270
+    else if (px < 1200000L) { auto_tile = 9; auto_T = 8; }                   // 960x540
+    else if (px < 3500000L) { auto_tile = 4; auto_T = 8; }                   // 1080p: 252 tiles of 128x96 on 256 CUs
     else { auto_tile = 6; auto_T = 8; }                                      // 4K / 8K: many rounds, 2 workgroups per CU
     if (tile == 0) tile = auto_tile;
     if (T == 0) T = auto_T;
     if (tile < 1 || tile > kNumTiles) tile = 1;
     const int EW = 4 * kTiles[tile].lx, EH = kTiles[tile].nt / kTiles[tile].lx * kTiles[tile].g;
     const bool single = cols <= EW && rows <= EH;
-    if (T > 16) T = 16;
+    if (T > 28) T = 28;
     while (T > 1 && (EW - 2 * ((T + 3) / 4 * 4) < 16 || EH - 2 * T < 8)) T--;   // keep a non-degenerate written-back region
     int done = 0;
     *launches = 0;
@@ -271,7 +275,15 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         const int m = single ? n - done : (n - done < T ? n - done : T);
         const int hy = single ? 0 : m;
         const int hx = single ? 0 : (m + 3) / 4 * 4;
-        const int TW = EW - 2 * hx, TH = EH - 2 * hy;
+        // a single tile launches only the thread rows the image needs (whole waves), e.g. 120x67 -> 23 of 32 rows
+        int nthreads = kTiles[tile].nt;
+        if (single) {
+            const int need = (rows + kTiles[tile].g - 1) / kTiles[tile].g * kTiles[tile].lx;
+            nthreads = (need + 63) / 64 * 64;
+            if (nthreads > kTiles[tile].nt) nthreads = kTiles[tile].nt;
+        }
+        const int eh = nthreads / kTiles[tile].lx * kTiles[tile].g;
+        const int TW = EW - 2 * hx, TH = eh - 2 * hy;
         const dim3 grid((cols + TW - 1) / TW, (rows + TH - 1) / TH);
         // outputs go to the two spare planes, then the pairs swap
         int free0 = -1, free1 = -1;
@@ -279,7 +291,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         const float *Xk = L.P(*pk, ip), *Xm = L.P(*pm, ip);
         float *Yk = L.P(free0, ip), *Ym = L.P(free1, ip);
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) \
-    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma); break;
+    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma); break;
         switch (tile) {
             RTDD_TILE_CASE(1, 16, 256, 4)
             RTDD_TILE_CASE(2, 32, 512, 4)
@@ -289,6 +301,9 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             RTDD_TILE_CASE(6, 16, 512, 3)
             RTDD_TILE_CASE(7, 16, 256, 3)
             RTDD_TILE_CASE(8, 32, 1024, 2)
+            RTDD_TILE_CASE(9, 16, 1024, 1)
+            RTDD_TILE_CASE(10, 16, 512, 2)
+            RTDD_TILE_CASE(11, 32, 1024, 1)
         }
 #undef RTDD_TILE_CASE
         *pk = free0; *pm = free1;
