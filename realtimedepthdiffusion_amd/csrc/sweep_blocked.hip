@@ -85,6 +85,13 @@ __device__ __forceinline__ float relax(float xl, float xr, float xu, float xd, f
 // Register budget: a G = 4 thread holds 6 x 16 + 8 live values; capping it at 128 VGPRs spills into the
 // sweep loop (measured 25 % slower), so G = 4 tiles ask for 3 waves/SIMD (168 VGPRs) unless the
 // workgroup is 1024 threads (which needs 4 waves/SIMD to be launchable at all).  G <= 3 fits 128.
+#ifdef RTDD_STAMPS   // diagnostic build only (scripts/ubench/blocked_phases.hip): per-workgroup phase timestamps
+__device__ unsigned long long g_stamps[4096][4];
+#define RTDD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) g_stamps[blockIdx.y * gridDim.x + blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RTDD_STAMP(k) do {} while (0)
+#endif
+
 template <int LX, int NT, int G, bool CONTRACT>
 __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_blocked(const float *__restrict__ Xk, const float *__restrict__ Xm,
                                                       float *__restrict__ Yk, float *__restrict__ Ym,
@@ -95,6 +102,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     __shared__ float lut[257];
     __shared__ float4 edge[2][NTR][2][LX];     // [buffer][thread row][0 = its top row, 1 = its bottom row][lane]
 
+    RTDD_STAMP(0);
     const int tid = threadIdx.x;
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];       // blockDim.x <= NT: small levels launch only the thread rows they need
     __syncthreads();
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
         }
     const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
 
+    RTDD_STAMP(1);
     // ---- n sweeps in registers -------------------------------------------------------------------
     auto sweep = [&](float (&cur)[G][4], float (&oth)[G][4], int s, auto fast) {
         constexpr bool FAST = decltype(fast)::value;
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
         if (s < nsweeps) sweep(a, b, s, std::false_type{});
     }
     const bool odd = (nsweeps & 1) != 0;
+    RTDD_STAMP(2);
 
     // ---- write back the part that is still exact ---------------------------------------------------
     const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
@@ -224,6 +234,10 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
             *(float4 *)(Ym + off) = make_float4(odd ? a[g][0] : b[g][0], odd ? a[g][1] : b[g][1], odd ? a[g][2] : b[g][2], odd ? a[g][3] : b[g][3]);
         }
     }
+#ifdef RTDD_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    RTDD_STAMP(3);
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------
