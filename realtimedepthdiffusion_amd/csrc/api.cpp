@@ -127,7 +127,7 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 28, "temporal depth must be 0..28"); ctx->opt.temporal_depth = value; break;
         case RTDD_OPT_USE_GRAPH: ctx->opt.use_graph = value ? 1 : 0; break;
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
-        case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 11, "tile must be 0..11"); ctx->opt.tile = value; break;
+        case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 12, "tile must be 0..12"); ctx->opt.tile = value; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;

@@ -34,29 +34,39 @@ __device__ __forceinline__ float lane_from_next(float v) {   // lane l <- lane l
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
+// Result stores.  RTDD_STORE_MODE (diagnostic knob): 0 plain, 1 non-temporal, 2 write-through (sc1).
+#ifndef RTDD_STORE_MODE
+#define RTDD_STORE_MODE 0
+#endif
+__device__ __forceinline__ void store_result(float4 *p, float4 v) {
+#if RTDD_STORE_MODE == 1
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+#elif RTDD_STORE_MODE == 2
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#else
+    *p = v;
+#endif
+}
+
 // ---- IEEE f32 division with a loop-invariant divisor ---------------------------------------------
 // `sum / cnt` must be the correctly rounded quotient (the reference relies on nvcc's default
 // -prec-div=true).  hipcc expands an IEEE divide into 11 VALU ops (v_div_scale x2, v_rcp, 5 fma,
-// v_mul, v_div_fmas, v_div_fixup): measured 46 cycles per wave-instruction-group, 60 % of a sweep.
-// The divisor cnt is constant for a pixel, so the divisor half of that expansion -- v_div_scale of
-// the denominator, v_rcp, and the two Newton fmas giving the refined reciprocal `y` -- is hoisted
-// out of the sweep loop; what remains per sweep is EXACTLY the tail of hipcc's sequence
-//      mul = n*y; f2 = fma(-d,mul,n); f3 = fma(f2,y,mul); f4 = fma(-d,f3,n); q = fma(f4,y,f3)
-// which is bit-identical to the full expansion whenever neither v_div_scale would rescale and
-// v_div_fixup passes the value through: d normal, n == 0 or |n| >= 2^-103 (biased exponent > 23),
-// and n/d far from over/underflow (it is a weighted mean of bounded values).  Pixels/sweeps outside
-// that regime take the full divide.  (gfx950 ISA, V_DIV_SCALE_F32 / V_DIV_FMAS_F32 / V_DIV_FIXUP_F32.)
-__device__ __forceinline__ float refined_rcp(float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    const float f0 = __builtin_fmaf(-d, r, 1.0f);
-    return __builtin_fmaf(f0, r, r);
-}
+// v_mul, v_div_fmas, v_div_fixup): measured 46 cycles per wave-instruction group, 60 % of a sweep.
+// The divisor cnt is constant for a pixel, so its correctly rounded reciprocal y = RN(1/cnt) is
+// computed once per launch (one full divide) and each sweep does Markstein's correction step
+//      q0 = n*y;  r = fma(-d, q0, n);  q = fma(r, y, q0)
+// which IS RN(n/d): verified EXHAUSTIVELY on gfx950 against hipcc's divide for all 2^23 divisor x 2^24
+// numerator significands (scripts/ubench/div_exhaustive.hip, 1.4e14 pairs, 0 mismatches, 71 s; log in
+// profiles/).  Powers of two scale every intermediate exactly, so that covers all operands for which no
+// intermediate under/overflows: d normal (<= 4 here), n == 0 or |n| >= 2^-100 (then q0 is normal and the
+// remainder, a multiple of 2^(e_n - 47), is exactly representable), n/d bounded (a weighted mean).
+// Anything else takes the full divide under a wave-uniform branch.
 __device__ __forceinline__ float div_tail(float n, float d, float y) {
-    const float mul = n * y;
-    const float f2 = __builtin_fmaf(-d, mul, n);
-    const float f3 = __builtin_fmaf(f2, y, mul);
-    const float f4 = __builtin_fmaf(-d, f3, n);
-    return __builtin_fmaf(f4, y, f3);
+    const float q0 = n * y;
+    const float r = __builtin_fmaf(-d, q0, n);
+    return __builtin_fmaf(r, y, q0);
 }
 
 template <bool CONTRACT, bool FAST>
@@ -69,9 +79,12 @@ __device__ __forceinline__ float relax(float xl, float xr, float xu, float xd, f
     sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
     sum = CONTRACT ? __builtin_fmaf(wd, xd, sum) : sum + wd * xd;
     float r;                                   // cnt == 0 was replaced by 1 (sum is 0 there): r = 0 (:103)
+#ifdef RTDD_DIAG_NODIV        // (diagnostic ablation: timing only)
+    if (true) { r = sum * rcp; } else
+#endif
     if (FAST) {
         r = div_tail(sum, cnt, rcp);
-        const bool tiny = __builtin_fabsf(sum) < 0x1p-103f && sum != 0.0f;
+        const bool tiny = __builtin_fabsf(sum) < 0x1p-100f && sum != 0.0f;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0, 0)) r = tiny ? sum / cnt : r;   // wave-uniform, rare
     } else {
         r = sum / cnt;
@@ -87,7 +100,11 @@ __device__ __forceinline__ float relax(float xl, float xr, float xu, float xd, f
 // workgroup is 1024 threads (which needs 4 waves/SIMD to be launchable at all).  G <= 3 fits 128.
 #ifdef RTDD_STAMPS   // diagnostic build only (scripts/ubench/blocked_phases.hip): per-workgroup phase timestamps
 __device__ unsigned long long g_stamps[4096][4];
-#define RTDD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) g_stamps[blockIdx.y * gridDim.x + blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// k = 0: earliest wave (atomicMin would need init; wave 0 starts first in practice); k >= 1: LATEST wave of the workgroup
+// (atomicMax) -- without a barrier the oldest wave of each SIMD runs ahead, so stamping only wave 0 under-reports.
+#define RTDD_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) { \
+        if ((k) == 0) { if (threadIdx.x == 0) g_stamps[blockIdx.y * gridDim.x + blockIdx.x][0] = __builtin_amdgcn_s_memrealtime(); } \
+        else atomicMax(&g_stamps[blockIdx.y * gridDim.x + blockIdx.x][k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } while (0)
 #else
 #define RTDD_STAMP(k) do {} while (0)
 #endif
@@ -101,10 +118,12 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     constexpr int EW = 4 * LX, NTR = NT / LX;
     __shared__ float lut[257];
     __shared__ float4 edge[2][NTR][2][LX];     // [buffer][thread row][0 = its top row, 1 = its bottom row][lane]
+    __shared__ int published[NT / 64];         // per wave: number of sweeps whose edge rows it has published
 
     RTDD_STAMP(0);
     const int tid = threadIdx.x;
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];       // blockDim.x <= NT: small levels launch only the thread rows they need
+    if (tid < NT / 64) published[tid] = 0;
     __syncthreads();
 
     const int lx = tid % LX, tr = tid / LX;
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
             float c = 0.0f;                    // count accumulates left, right, up, down (:82,88,94,100)
             c += wl; c += wr[g][i]; c += wu; c += wd[g][i];
             cnt[g][i] = c == 0.0f ? 1.0f : c;
-            rcp[g][i] = refined_rcp(cnt[g][i]);
+            rcp[g][i] = 1.0f / cnt[g][i];           // correctly rounded reciprocal, once per launch
             unsafe |= cnt[g][i] < 0x1p-126f;
         }
     const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
@@ -177,10 +196,24 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     auto sweep = [&](float (&cur)[G][4], float (&oth)[G][4], int s, auto fast) {
         constexpr bool FAST = decltype(fast)::value;
         const int buf = s & 1;
+        // Vertical halo exchange.  A workgroup barrier here costs as much as the sweep's arithmetic (measured
+        // 0.7 of 1.4 us per sweep for 16 waves: every wave of a SIMD drains and refills together), but a wave
+        // only needs the edge rows of the two ADJACENT waves.  So: publish own edge rows, release-store a per-wave
+        // counter, acquire-spin on the two neighbours' counters.  Waves drift apart by up to one sweep and the
+        // SIMDs stay busy.  Buffer reuse is safe without a second handshake: a neighbour publishes sweep s+1 only
+        // after it has consumed my sweep-s rows, and I overwrite that buffer (sweep s+2) only after waiting for
+        // its sweep-s+1 rows.  All waves of a workgroup are co-resident, so the spin cannot deadlock.
+        float4 up4 = make_float4(0, 0, 0, 0), dn4 = up4;
         edge[buf][tr][0][lx] = make_float4(cur[0][0], cur[0][1], cur[0][2], cur[0][3]);
         edge[buf][tr][1][lx] = make_float4(cur[G - 1][0], cur[G - 1][1], cur[G - 1][2], cur[G - 1][3]);
-        __syncthreads();
-        float4 up4 = make_float4(0, 0, 0, 0), dn4 = up4;
+        {
+            const int wv = tid >> 6, nwv = (int)blockDim.x >> 6;
+            __hip_atomic_store(&published[wv], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wv > 0)
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < s + 1) __builtin_amdgcn_s_sleep(1);
+            if (wv < nwv - 1)
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < s + 1) __builtin_amdgcn_s_sleep(1);
+        }
         if (tr > 0) up4 = edge[buf][tr - 1][1][lx];
         if (tr < ntr - 1) dn4 = edge[buf][tr + 1][0][lx];
         const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
@@ -203,8 +236,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
         }
     };
 
-    // every wave executes exactly one barrier per sweep in either branch, so the wave-uniform
-    // choice of divide variant cannot unbalance the workgroup barrier
+    // (the divide variant is chosen per wave; the neighbour handshake above does not care which one a wave runs)
     int s = 0;
     if (!wave_unsafe) {
         for (; s + 1 < nsweeps; s += 2) {
@@ -230,10 +262,15 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
         if (xin && ty >= hy && ty < eh - hy && y < rows) {
             const size_t off = (size_t)y * ip + x0;
             // newest iterate -> Yk, the one before it -> Ym (componentwise selects: a pointer-select would go through scratch)
-            *(float4 *)(Yk + off) = make_float4(odd ? b[g][0] : a[g][0], odd ? b[g][1] : a[g][1], odd ? b[g][2] : a[g][2], odd ? b[g][3] : a[g][3]);
-            *(float4 *)(Ym + off) = make_float4(odd ? a[g][0] : b[g][0], odd ? a[g][1] : b[g][1], odd ? a[g][2] : b[g][2], odd ? a[g][3] : b[g][3]);
+            const float4 vk = make_float4(odd ? b[g][0] : a[g][0], odd ? b[g][1] : a[g][1], odd ? b[g][2] : a[g][2], odd ? b[g][3] : a[g][3]);
+            const float4 vm = make_float4(odd ? a[g][0] : b[g][0], odd ? a[g][1] : b[g][1], odd ? a[g][2] : b[g][2], odd ? a[g][3] : b[g][3]);
+            store_result((float4 *)(Yk + off), vk);
+            store_result((float4 *)(Ym + off), vm);
         }
     }
+#if RTDD_STORE_MODE == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #ifdef RTDD_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     RTDD_STAMP(3);
@@ -244,8 +281,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
 struct TileCfg { int lx, nt, g; };
 // id -> (lanes per tile row, threads, rows per thread); extended tile = 4*lx wide, nt/lx*g tall
 static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 1024, 4}, {32, 1024, 3}, {32, 512, 3}, {16, 512, 3}, {16, 256, 3}, {32, 1024, 2},
-                                 {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}};
-constexpr int kNumTiles = 11;
+                                 {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}, {32, 768, 4}};
+constexpr int kNumTiles = 12;
 
 template <int LX, int NT, int G>
 static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int nthreads, const float *Xk, const float *Xm, float *Yk, float *Ym, const uint32_t *M,
@@ -318,6 +355,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             RTDD_TILE_CASE(9, 16, 1024, 1)
             RTDD_TILE_CASE(10, 16, 512, 2)
             RTDD_TILE_CASE(11, 32, 1024, 1)
+            RTDD_TILE_CASE(12, 32, 768, 4)
         }
 #undef RTDD_TILE_CASE
         *pk = free0; *pm = free1;

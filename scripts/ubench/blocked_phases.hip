@@ -10,6 +10,7 @@ using namespace rtdd;
 int main(int argc, char **argv) {
     int rows = argc > 1 ? atoi(argv[1]) : 1080, cols = argc > 2 ? atoi(argv[2]) : 1920, tile = argc > 3 ? atoi(argv[3]) : 4, T = argc > 4 ? atoi(argv[4]) : 8;
     rtdd_ctx ctx; ctx.opt.tile = tile; ctx.opt.temporal_depth = T;
+    if (getenv("RTDD_STREAM")) { hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking); printf("using a created stream\n"); }
     Level L; size_t ip = plane_pitch(cols); L.elems = plane_elems(rows, cols);
     std::vector<float> h(L.elems); for (auto &v : h) v = (float)(rand() % 25500) / 100.0f;
     std::vector<uint32_t> hm(L.elems); for (auto &v : hm) v = (rand() % 12) | ((rand() % 12) << 8) | ((rand() % 10 == 0) ? kMetaDirichlet : 0);
@@ -21,7 +22,17 @@ int main(int argc, char **argv) {
     int pk = 0, pm = 1, ln = 0;
     for (int rep = 0; rep < 5; rep++) launch_sweeps_blocked(&ctx, L, ip, rows, cols, om_d, T * 20, &pk, &pm, &ln);
     hipDeviceSynchronize();
-    launch_sweeps_blocked(&ctx, L, ip, rows, cols, om_d, T, &pk, &pm, &ln);   // the stamped launch (last writer wins)
+    // stamps of the LAST launch of a back-to-back train (every launch overwrites them): steady state, not an isolated launch
+    { static unsigned long long z[4096][4]; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, ctx.stream);
+    launch_sweeps_blocked(&ctx, L, ip, rows, cols, om_d, T * 20, &pk, &pm, &ln);
+    hipEventRecord(e1, ctx.stream);
+    hipDeviceSynchronize();
+    float evms = 0; hipEventElapsedTime(&evms, e0, e1);
+    printf("launch interval (events / launches): %.2f us over %d launches\n", evms * 1e3 / ln, ln);
+    { static unsigned long long z[4096][4]; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
+    launch_sweeps_blocked(&ctx, L, ip, rows, cols, om_d, T, &pk, &pm, &ln);      // ONE stamped launch (stamps are max-accumulated)
     hipDeviceSynchronize();
     static unsigned long long st[4096][4];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
