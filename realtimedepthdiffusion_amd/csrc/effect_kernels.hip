@@ -1,117 +1,209 @@
 // effect_kernels.hip -- depth-driven artistic passes (desaturation, haze, defocus).
 //
-// Desaturation and haze are pure streaming (11 / 10 B per pixel).  Defocus in the reference is a
-// per-pixel O(k^2) gather (up to 48 400 taps at 8K, /root/reference/src/GPUDepthEffect.cu:47-60);
-// here it is an exact O(1) lookup in a u32 summed-area table: window sums are < 2^24 so the
-// reference's f32 accumulation is exact, and mod-2^32 subtraction of wrapped prefixes is exact
-// too, so the results are bit-identical while the cost no longer depends on the blur radius.
+// Desaturation and haze are pure streaming (11 / 10 B per pixel).  A thread handles FOUR pixels so
+// the interleaved u8x3 rows move as dwordx3 (12 B/lane, contiguous across the wave) and depth as
+// dwordx4, instead of the reference's one-thread-per-pixel byte accesses
+// (/root/reference/src/GPUDepthEffect.cu:18-25, 83-91); rows that are not 4-byte aligned take a
+// byte-wise path with identical arithmetic.
+//
+// Defocus in the reference is a per-pixel O(k^2) gather (up to 48 400 taps at 8K,
+// src/GPUDepthEffect.cu:47-60); here it is an exact O(1) lookup in a u32 summed-area table: window
+// sums are < 2^24 so the reference's f32 accumulation is exact, and mod-2^32 subtraction of wrapped
+// prefixes is exact too, so results are bit-identical while the cost no longer depends on the blur
+// radius.  The table is built in three passes chosen for parallelism on 256 CUs:
+//   k_sat_rows   one workgroup per image row: each wave scans a quarter of the row 64 pixels at a time
+//                (lane = pixel, shuffle scan), 12-byte {B,G,R} prefixes stored contiguously;
+//   k_sat_bands  column prefixes INSIDE bands of 32 rows (rows/32 x cols/256 workgroups instead of a
+//                1080-step serial walk), band totals on the side;
+//   k_sat_base   exclusive scan of the band totals (tiny);
+// and k_defocus adds the band base while fetching its four corners (one dwordx3 each).
 #include "rtdd_internal.hpp"
 
 namespace rtdd {
 
-__device__ __forceinline__ uint8_t store_u8(float v) {
+__device__ __forceinline__ uint32_t store_u8(float v) {
     // defined behaviour for the reference's out-of-range float->uchar cast: saturate, then truncate
     if (!(v >= 0.0f)) return 0;
     if (v >= 255.0f) return 255;
-    return (uint8_t)(int)v;
+    return (uint32_t)(int)v;
 }
 
 // simulateDesaturation (K8) -- src/GPUDepthEffect.cu:8-27
 template <bool CONTRACT>
-__global__ __launch_bounds__(256) void k_desaturate(const uint8_t *__restrict__ orig, size_t op, const uint8_t *__restrict__ gray, size_t gp,
-                                                    const float *__restrict__ depth, size_t dp, uint8_t *__restrict__ art, size_t ap,
-                                                    int rows, int cols) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    const float d = ((const float *)((const char *)depth + (size_t)y * dp))[x];
-    const float f = (float)((double)d / 255.0);                     // :22 (double divide, narrowed)
-    const float g = (float)gray[(size_t)y * gp + x];
-    const uint8_t *o = orig + (size_t)y * op + 3 * x;
-    uint8_t *a = art + (size_t)y * ap + 3 * x;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float t = (1 - f) * (float)o[c];
-        a[c] = store_u8(CONTRACT ? __builtin_fmaf(f, g, t) : f * g + t);
-    }
+__device__ __forceinline__ uint32_t desat_px(float d, float g, float o) {
+    const float f = (float)((double)d / 255.0);                    // :22 (double divide, narrowed)
+    const float t = (1 - f) * o;
+    return store_u8(CONTRACT ? __builtin_fmaf(f, g, t) : f * g + t);
 }
 
-// simulateHaze (K10) -- src/GPUDepthEffect.cu:74-93.  exp is evaluated in f64 and rounded once to
-// f32: that is the correctly rounded expf in all but ~2^-29 of cases, which is also what the
-// host libm the oracle uses delivers -- so the two agree wherever either is correctly rounded.
+// simulateHaze (K10) -- src/GPUDepthEffect.cu:74-93.  exp is evaluated in f64 and rounded once to f32: the
+// correctly rounded expf in all but ~2^-29 of cases, which is also what the host libm the oracle uses delivers.
+__device__ __forceinline__ float haze_t(float d) {
+    const float arg = (float)((double)(-2.0f * d) / 255.0);        // :88
+    return (float)exp((double)arg);
+}
 template <bool CONTRACT>
-__global__ __launch_bounds__(256) void k_haze(const uint8_t *__restrict__ orig, size_t op, const float *__restrict__ depth, size_t dp,
-                                              uint8_t *__restrict__ art, size_t ap, int rows, int cols) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+__device__ __forceinline__ uint32_t haze_px(float t, float w, float o) {
+    return store_u8(CONTRACT ? __builtin_fmaf(t, o, w) : t * o + w);
+}
+
+// MODE 0 = desaturation, 1 = haze.  VEC: 4 pixels per thread with dword accesses (needs 4-byte aligned rows).
+template <int MODE, bool CONTRACT, bool VEC>
+__global__ __launch_bounds__(256) void k_blend(const uint8_t *__restrict__ orig, size_t op, const uint8_t *__restrict__ gray, size_t gp,
+                                               const float *__restrict__ depth, size_t dp, uint8_t *__restrict__ art, size_t ap,
+                                               int rows, int cols) {
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    const float d = ((const float *)((const char *)depth + (size_t)y * dp))[x];
-    const float arg = (float)((double)(-2.0f * d) / 255.0);         // :88
-    const float t = (float)exp((double)arg);
-    const float w = (1 - t) * 255;
-    const uint8_t *o = orig + (size_t)y * op + 3 * x;
-    uint8_t *a = art + (size_t)y * ap + 3 * x;
+    if (y >= rows) return;
+    const float *drow = (const float *)((const char *)depth + (size_t)y * dp);
+    const uint8_t *orow = orig + (size_t)y * op;
+    uint8_t *arow = art + (size_t)y * ap;
+    if (VEC) {
+        const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+        if (x + 3 < cols) {
+            const float4 d4 = *(const float4 *)(drow + x);
+            const uint32_t *o3 = (const uint32_t *)(orow + 3 * x);
+            const uint32_t w0 = o3[0], w1 = o3[1], w2 = o3[2];
+            uint32_t g4 = 0;
+            if (MODE == 0) g4 = *(const uint32_t *)(gray + (size_t)y * gp + x);
+            const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+            uint32_t ob[12], rb[12];
 #pragma unroll
-    for (int c = 0; c < 3; c++) a[c] = store_u8(CONTRACT ? __builtin_fmaf(t, (float)o[c], w) : t * (float)o[c] + w);
+            for (int i = 0; i < 4; i++) { ob[i] = (w0 >> (8 * i)) & 255; ob[4 + i] = (w1 >> (8 * i)) & 255; ob[8 + i] = (w2 >> (8 * i)) & 255; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (MODE == 0) {
+                    const float g = (float)((g4 >> (8 * i)) & 255);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) rb[3 * i + c] = desat_px<CONTRACT>(dv[i], g, (float)ob[3 * i + c]);
+                } else {
+                    const float t = haze_t(dv[i]);
+                    const float w = (1 - t) * 255;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) rb[3 * i + c] = haze_px<CONTRACT>(t, w, (float)ob[3 * i + c]);
+                }
+            }
+            uint32_t *a3 = (uint32_t *)(arow + 3 * x);
+            a3[0] = rb[0] | (rb[1] << 8) | (rb[2] << 16) | (rb[3] << 24);
+            a3[1] = rb[4] | (rb[5] << 8) | (rb[6] << 16) | (rb[7] << 24);
+            a3[2] = rb[8] | (rb[9] << 8) | (rb[10] << 16) | (rb[11] << 24);
+            return;
+        }
+        // ragged tail of a vectorised row: fall through to the scalar body for the remaining pixels
+        for (int xx = x; xx < cols; xx++) {
+            const float d = drow[xx];
+            if (MODE == 0) { const float g = (float)gray[(size_t)y * gp + xx];
+                for (int c = 0; c < 3; c++) arow[3 * xx + c] = (uint8_t)desat_px<CONTRACT>(d, g, (float)orow[3 * xx + c]); }
+            else { const float t = haze_t(d); const float w = (1 - t) * 255;
+                for (int c = 0; c < 3; c++) arow[3 * xx + c] = (uint8_t)haze_px<CONTRACT>(t, w, (float)orow[3 * xx + c]); }
+        }
+    } else {
+        const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+        if (x >= cols) return;
+        const float d = drow[x];
+        if (MODE == 0) { const float g = (float)gray[(size_t)y * gp + x];
+#pragma unroll
+            for (int c = 0; c < 3; c++) arow[3 * x + c] = (uint8_t)desat_px<CONTRACT>(d, g, (float)orow[3 * x + c]); }
+        else { const float t = haze_t(d); const float w = (1 - t) * 255;
+#pragma unroll
+            for (int c = 0; c < 3; c++) arow[3 * x + c] = (uint8_t)haze_px<CONTRACT>(t, w, (float)orow[3 * x + c]); }
+    }
 }
 
 // ---- defocus: summed-area table ------------------------------------------------------------------
-// S has (rows+1) x (cols+1) entries of 3 x u32 (interleaved), S[0][*] = S[*][0] = 0,
-// S[y+1][x+1][c] = sum over y'<=y, x'<=x of orig[y'][x'][c]   (mod 2^32).
-//
-// pass 1: one workgroup per image row writes the row-wise inclusive prefix into S[y+1][1..].
-__global__ __launch_bounds__(256) void k_sat_rows(const uint8_t *__restrict__ orig, size_t op, uint32_t *__restrict__ S, int rows, int cols) {
-    __shared__ uint32_t part[256][3];
-    const int y = blockIdx.x;
-    const int t = threadIdx.x;
-    const int chunk = (cols + 255) / 256;
-    const int xa = min(t * chunk, cols), xb = min(xa + chunk, cols);
-    const uint8_t *o = orig + (size_t)y * op;
-    uint32_t s0 = 0, s1 = 0, s2 = 0;
-    for (int x = xa; x < xb; x++) { s0 += o[3 * x]; s1 += o[3 * x + 1]; s2 += o[3 * x + 2]; }
-    part[t][0] = s0; part[t][1] = s1; part[t][2] = s2;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 256 chunk sums
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t a0 = 0, a1 = 0, a2 = 0;
-        if (t >= off) { a0 = part[t - off][0]; a1 = part[t - off][1]; a2 = part[t - off][2]; }
-        __syncthreads();
-        part[t][0] += a0; part[t][1] += a1; part[t][2] += a2;
-        __syncthreads();
-    }
-    uint32_t r0 = part[t][0] - s0, r1 = part[t][1] - s1, r2 = part[t][2] - s2;    // exclusive prefix of this chunk
-    uint32_t *srow = S + ((size_t)(y + 1) * (cols + 1)) * 3;
-    if (t == 0) { srow[0] = 0; srow[1] = 0; srow[2] = 0; }
-    for (int x = xa; x < xb; x++) {
-        r0 += o[3 * x]; r1 += o[3 * x + 1]; r2 += o[3 * x + 2];
-        uint32_t *q = srow + (size_t)(x + 1) * 3;
-        q[0] = r0; q[1] = r1; q[2] = r2;
-    }
-    if (y == 0) for (int i = t; i < (cols + 1) * 3; i += 256) S[i] = 0;
+// L has (rows+1) x (cols+1) entries of 3 x u32 {B, G, R} (12 B, moved as dwordx3): L[0][*] = L[*][0] = 0 and, for r >= 1,
+// L[r][c] = sum over rows of r's band up to r-1, columns < c (mod 2^32).  The full prefix is
+// S(r,c) = L[r][c] + base[(r-1)/kBand][c].
+constexpr int kBand = 32;
+
+struct u3 { uint32_t x, y, z; };                                    // 12-byte table entry
+__device__ __forceinline__ u3 ld3(const u3 *p) { return *p; }
+__device__ __forceinline__ void st3(u3 *p, uint32_t a, uint32_t b, uint32_t c) { u3 v; v.x = a; v.y = b; v.z = c; *p = v; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o); if ((int)(threadIdx.x & 63) >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
-// pass 2: column-wise prefix in place; thread per (x, channel) word, consecutive threads on
-// consecutive words so each row step is one coalesced read-modify-write.
-__global__ __launch_bounds__(256) void k_sat_cols(uint32_t *__restrict__ S, int rows, int width3) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= width3) return;
-    uint32_t acc = 0;
-    uint32_t *p = S + (size_t)width3 + i;          // row 1
-    int y = 0;
-    for (; y + 4 <= rows; y += 4) {                // 4 independent loads in flight per step
-        const uint32_t a = p[0], b = p[(size_t)width3], c = p[(size_t)2 * width3], d = p[(size_t)3 * width3];
-        acc += a; p[0] = acc;
-        acc += b; p[(size_t)width3] = acc;
-        acc += c; p[(size_t)2 * width3] = acc;
-        acc += d; p[(size_t)3 * width3] = acc;
-        p += (size_t)4 * width3;
+// pass 1: row-wise inclusive prefix of image row y into L[y+1][1..].  Each of the 4 waves owns a contiguous
+// quarter of the row and walks it 64 pixels at a time with lane = pixel, so the 3-byte loads and the 12-byte
+// stores of a wave are contiguous; quarter totals go through LDS once.
+__global__ __launch_bounds__(256) void k_sat_rows(const uint8_t *__restrict__ orig, size_t op, u3 *__restrict__ L, int rows, int cols) {
+    __shared__ uint32_t qsum[4][3];
+    const int y = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = ((cols + 3) / 4 + 63) / 64 * 64;                  // quarter length, a multiple of 64
+    const int xa = min(w * q, cols), xb = min(xa + q, cols);
+    const uint8_t *o = orig + (size_t)y * op;
+    uint32_t t0 = 0, t1 = 0, t2 = 0;
+    for (int x = xa + lane; x < xb; x += 64) { t0 += o[3 * x]; t1 += o[3 * x + 1]; t2 += o[3 * x + 2]; }
+    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+    if (lane == 0) { qsum[w][0] = t0; qsum[w][1] = t1; qsum[w][2] = t2; }
+    __syncthreads();
+    uint32_t c0 = 0, c1 = 0, c2 = 0;                                // carry into this quarter
+    for (int k = 0; k < w; k++) { c0 += qsum[k][0]; c1 += qsum[k][1]; c2 += qsum[k][2]; }
+    u3 *lrow = L + (size_t)(y + 1) * (cols + 1);
+    if (threadIdx.x == 0) st3(lrow, 0, 0, 0);
+    for (int xs = xa; xs < xb; xs += 64) {
+        const int x = xs + lane;
+        uint32_t v0 = 0, v1 = 0, v2 = 0;
+        if (x < xb) { v0 = o[3 * x]; v1 = o[3 * x + 1]; v2 = o[3 * x + 2]; }
+        v0 = wave_incl_scan(v0) + c0; v1 = wave_incl_scan(v1) + c1; v2 = wave_incl_scan(v2) + c2;
+        if (x < xb) st3(lrow + x + 1, v0, v1, v2);
+        c0 = __shfl(v0, 63); c1 = __shfl(v1, 63); c2 = __shfl(v2, 63);
     }
-    for (; y < rows; y++) { acc += p[0]; p[0] = acc; p += width3; }
+    if (y == 0) for (int i = threadIdx.x; i <= cols; i += 256) st3(L + i, 0, 0, 0);
+}
+
+// pass 2: column prefix inside each band of kBand rows, in place; band totals -> tot[band][c]
+__global__ __launch_bounds__(256) void k_sat_bands(u3 *__restrict__ L, u3 *__restrict__ tot, int rows, int width) {
+    const int c = blockIdx.x * 256 + threadIdx.x, band = blockIdx.y;
+    if (c >= width) return;
+    const int ra = band * kBand + 1, rb = min(ra + kBand, rows + 1);
+    uint32_t a0 = 0, a1 = 0, a2 = 0;
+    u3 *p = L + (size_t)ra * width + c;
+    int r = ra;
+    for (; r + 4 <= rb; r += 4) {                                   // 4 independent loads in flight
+        const u3 a = ld3(p), b = ld3(p + (size_t)width), cc = ld3(p + (size_t)2 * width), d = ld3(p + (size_t)3 * width);
+        a0 += a.x; a1 += a.y; a2 += a.z; st3(p, a0, a1, a2);
+        a0 += b.x; a1 += b.y; a2 += b.z; st3(p + (size_t)width, a0, a1, a2);
+        a0 += cc.x; a1 += cc.y; a2 += cc.z; st3(p + (size_t)2 * width, a0, a1, a2);
+        a0 += d.x; a1 += d.y; a2 += d.z; st3(p + (size_t)3 * width, a0, a1, a2);
+        p += (size_t)4 * width;
+    }
+    for (; r < rb; r++) { const u3 a = ld3(p); a0 += a.x; a1 += a.y; a2 += a.z; st3(p, a0, a1, a2); p += width; }
+    st3(tot + (size_t)band * width + c, a0, a1, a2);
+}
+
+// pass 3: base[b][c] = sum of the totals of bands < b (in place on tot); 8 loads in flight per step
+__global__ __launch_bounds__(256) void k_sat_base(u3 *__restrict__ tot, int nbands, int width) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= width) return;
+    uint32_t a0 = 0, a1 = 0, a2 = 0;
+    for (int b0 = 0; b0 < nbands; b0 += 8) {
+        u3 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (b0 + j < nbands) t[j] = ld3(tot + (size_t)(b0 + j) * width + c);
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (b0 + j < nbands) { st3(tot + (size_t)(b0 + j) * width + c, a0, a1, a2); a0 += t[j].x; a1 += t[j].y; a2 += t[j].z; }
+    }
+}
+
+__device__ __forceinline__ u3 sat_at(const u3 *__restrict__ L, const u3 *__restrict__ base, int width, int r, int c) {
+    u3 v; v.x = 0; v.y = 0; v.z = 0;
+    if (r == 0) return v;
+    const u3 a = ld3(L + (size_t)r * width + c), b = ld3(base + (size_t)((r - 1) / kBand) * width + c);
+    v.x = a.x + b.x; v.y = a.y + b.y; v.z = a.z + b.z;
+    return v;
 }
 
 // simulateDefocus (K9) -- src/GPUDepthEffect.cu:29-72
 __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ orig, size_t op, const float *__restrict__ depth, size_t dp,
-                                                 const uint32_t *__restrict__ S, uint8_t *__restrict__ art, size_t ap,
+                                                 const u3 *__restrict__ L, const u3 *__restrict__ base, uint8_t *__restrict__ art, size_t ap,
                                                  int rows, int cols, int kernelSize) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -130,51 +222,61 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
         return;
     }
     const float count = (float)((yb - ya) * (xb - xa));
-    const size_t w3 = (size_t)(cols + 1) * 3;
-    const uint32_t *s00 = S + (size_t)ya * w3 + (size_t)xa * 3, *s01 = S + (size_t)ya * w3 + (size_t)xb * 3;
-    const uint32_t *s10 = S + (size_t)yb * w3 + (size_t)xa * 3, *s11 = S + (size_t)yb * w3 + (size_t)xb * 3;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const uint32_t sum = s11[c] - s01[c] - s10[c] + s00[c];     // exact: true window sum < 2^24
-        a[c] = store_u8((float)sum / count);                        // :68-70
-    }
+    const int width = cols + 1;
+    const u3 s00 = sat_at(L, base, width, ya, xa), s01 = sat_at(L, base, width, ya, xb);
+    const u3 s10 = sat_at(L, base, width, yb, xa), s11 = sat_at(L, base, width, yb, xb);
+    // exact: the true window sum is < 2^24, so mod-2^32 arithmetic and the f32 conversion lose nothing (:68-70)
+    a[0] = (uint8_t)store_u8((float)(s11.x - s01.x - s10.x + s00.x) / count);
+    a[1] = (uint8_t)store_u8((float)(s11.y - s01.y - s10.y + s00.y) / count);
+    a[2] = (uint8_t)store_u8((float)(s11.z - s01.z - s10.z + s00.z) / count);
 }
 
 static inline dim3 grid64x4(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
 
+template <int MODE>
+static int launch_blend(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const uint8_t *gray, size_t gp, const float *depth, size_t dp,
+                        uint8_t *art, size_t ap, int rows, int cols) {
+    const bool aligned = ((uintptr_t)orig % 4 == 0) && ((uintptr_t)art % 4 == 0) && op % 4 == 0 && ap % 4 == 0 &&
+                         ((uintptr_t)depth % 16 == 0) && dp % 16 == 0 && (MODE == 1 || (((uintptr_t)gray % 4 == 0) && gp % 4 == 0));
+    const bool c = ctx->opt.fp_contract != 0;
+    if (aligned) {
+        const dim3 grid((cols + 255) / 256, (rows + 3) / 4);
+        if (c) hipLaunchKernelGGL((k_blend<MODE, true, true>), grid, dim3(256), 0, ctx->stream, orig, op, gray, gp, depth, dp, art, ap, rows, cols);
+        else hipLaunchKernelGGL((k_blend<MODE, false, true>), grid, dim3(256), 0, ctx->stream, orig, op, gray, gp, depth, dp, art, ap, rows, cols);
+    } else {
+        if (c) hipLaunchKernelGGL((k_blend<MODE, true, false>), grid64x4(rows, cols), dim3(256), 0, ctx->stream, orig, op, gray, gp, depth, dp, art, ap, rows, cols);
+        else hipLaunchKernelGGL((k_blend<MODE, false, false>), grid64x4(rows, cols), dim3(256), 0, ctx->stream, orig, op, gray, gp, depth, dp, art, ap, rows, cols);
+    }
+    RTDD_LAUNCH_CHECK(ctx, "k_blend");
+    return RTDD_OK;
+}
+
 int launch_desaturate(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const uint8_t *gray, size_t gp, const float *depth, size_t dp,
                       uint8_t *art, size_t ap, int rows, int cols) {
-    if (ctx->opt.fp_contract)
-        hipLaunchKernelGGL(k_desaturate<true>, grid64x4(rows, cols), dim3(256), 0, ctx->stream, orig, op, gray, gp, depth, dp, art, ap, rows, cols);
-    else
-        hipLaunchKernelGGL(k_desaturate<false>, grid64x4(rows, cols), dim3(256), 0, ctx->stream, orig, op, gray, gp, depth, dp, art, ap, rows, cols);
-    RTDD_LAUNCH_CHECK(ctx, "k_desaturate");
-    return RTDD_OK;
+    return launch_blend<0>(ctx, orig, op, gray, gp, depth, dp, art, ap, rows, cols);
 }
 
 int launch_haze(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *depth, size_t dp, uint8_t *art, size_t ap, int rows, int cols) {
-    if (ctx->opt.fp_contract)
-        hipLaunchKernelGGL(k_haze<true>, grid64x4(rows, cols), dim3(256), 0, ctx->stream, orig, op, depth, dp, art, ap, rows, cols);
-    else
-        hipLaunchKernelGGL(k_haze<false>, grid64x4(rows, cols), dim3(256), 0, ctx->stream, orig, op, depth, dp, art, ap, rows, cols);
-    RTDD_LAUNCH_CHECK(ctx, "k_haze");
-    return RTDD_OK;
+    return launch_blend<1>(ctx, orig, op, nullptr, 0, depth, dp, art, ap, rows, cols);
 }
 
 int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *depth, size_t dp, uint8_t *art, size_t ap, int rows, int cols) {
-    const size_t need = (size_t)(rows + 1) * (cols + 1) * 3;
+    const int width = cols + 1, nbands = (rows + kBand - 1) / kBand;
+    const size_t need = ((size_t)(rows + 1) * width + (size_t)nbands * width) * 3 + 16;     // in u32 words (3-word entries)
     if (ctx->sat_elems < need) {
         if (ctx->sat) { RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream)); RTDD_HIP(ctx, hipFree(ctx->sat)); ctx->sat = nullptr; ctx->sat_elems = 0; }
         RTDD_HIP(ctx, hipMalloc((void **)&ctx->sat, need * sizeof(uint32_t)));
         ctx->sat_elems = need;
     }
+    u3 *L = (u3 *)ctx->sat, *base = L + (size_t)(rows + 1) * width;
     const int kernelSize = 0.025 * sqrtf(rows * rows + cols * cols);    // :42, evaluated once on the host (sqrtf is correctly rounded on both)
-    hipLaunchKernelGGL(k_sat_rows, dim3(rows), dim3(256), 0, ctx->stream, orig, op, ctx->sat, rows, cols);
+    hipLaunchKernelGGL(k_sat_rows, dim3(rows), dim3(256), 0, ctx->stream, orig, op, L, rows, cols);
     RTDD_LAUNCH_CHECK(ctx, "k_sat_rows");
-    const int width3 = (cols + 1) * 3;
-    hipLaunchKernelGGL(k_sat_cols, dim3((width3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->sat, rows, width3);
-    RTDD_LAUNCH_CHECK(ctx, "k_sat_cols");
-    hipLaunchKernelGGL(k_defocus, grid64x4(rows, cols), dim3(256), 0, ctx->stream, orig, op, depth, dp, ctx->sat, art, ap, rows, cols, kernelSize);
+    hipLaunchKernelGGL(k_sat_bands, dim3((width + 255) / 256, nbands), dim3(256), 0, ctx->stream, L, base, rows, width);
+    RTDD_LAUNCH_CHECK(ctx, "k_sat_bands");
+    hipLaunchKernelGGL(k_sat_base, dim3((width + 255) / 256), dim3(256), 0, ctx->stream, base, nbands, width);
+    RTDD_LAUNCH_CHECK(ctx, "k_sat_base");
+    hipLaunchKernelGGL(k_defocus, grid64x4(rows, cols), dim3(256), 0, ctx->stream, orig, op, depth, dp, L, base, art, ap, rows, cols, kernelSize);
     RTDD_LAUNCH_CHECK(ctx, "k_defocus");
     return RTDD_OK;
 }
