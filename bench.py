@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--graph", type=int, default=-1)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--persistent", type=int, default=-1)
     args = ap.parse_args()
 
     import numpy as np
@@ -118,6 +119,7 @@ def main():
     if args.rows_per_wave: ctx.set_option(rt.OPT_ROWS_PER_WAVE, args.rows_per_wave)
     if args.graph >= 0: ctx.set_option(rt.OPT_USE_GRAPH, args.graph)
     if args.tile: ctx.set_option(rt.OPT_TILE, args.tile)
+    if args.persistent >= 0: ctx.set_option(rt.OPT_PERSISTENT, args.persistent)
     mask = rt.device_image(p["mask"], dev); gray = rt.device_image(p["gray"], dev)
     # one pristine initial-depth image per step, uploaded before the clock starts
     depths = [rt.device_image(p["depth"], dev) for _ in range(args.steps + args.warmup)]
@@ -153,7 +155,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps "
                                f"(BASELINE configs[1])" if args.workload == "1080p_jacobi1000" else args.workload,
-                   "images_per_step": world, "sweep_kernel": ctx.get_option(rt.OPT_SWEEP_KERNEL), "tile": ctx.get_option(rt.OPT_TILE), "temporal_depth": ctx.get_option(rt.OPT_TEMPORAL_DEPTH),
+                   "images_per_step": world, "sweep_kernel": ctx.get_option(rt.OPT_SWEEP_KERNEL), "tile": ctx.get_option(rt.OPT_TILE), "temporal_depth": ctx.get_option(rt.OPT_TEMPORAL_DEPTH), "persistent": ctx.get_option(rt.OPT_PERSISTENT),
                    "sweeps_per_launch": sweeps_per_launch},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "sweep", "launch_us": launch_us,

@@ -39,7 +39,8 @@ enum rtdd_status {
     RTDD_ERR_STATE = 2,             /* call order violated (solve before allocate / load_weights) */
     RTDD_ERR_HIP = 3,               /* a HIP runtime call failed; see rtdd_last_error() */
     RTDD_ERR_NOMEM = 4,
-    RTDD_ERR_NO_DEVICE = 5          /* no usable gfx950 device: there is NO CPU fallback */
+    RTDD_ERR_NO_DEVICE = 5,         /* no usable gfx950 device: there is NO CPU fallback */
+    RTDD_ERR_TIMEOUT = 6            /* reported by rtdd_ctx_synchronize: a persistent sweep launch gave up (GPU shared) */
 };
 
 /* Solver variants.  RTDD_METHOD_CHEBYSHEV_JACOBI is the reference's only scheme
@@ -57,6 +58,8 @@ enum rtdd_option {
     RTDD_OPT_TEMPORAL_DEPTH = 2,    /* sweeps fused per launch by the blocked kernel (0 = auto) */
     RTDD_OPT_USE_GRAPH = 3,         /* 1: replay the sweep sequence from a captured hipGraph */
     RTDD_OPT_ROWS_PER_WAVE = 4,     /* one-sweep kernel: rows each wave walks (0 = auto) */
+    RTDD_OPT_PERSISTENT = 6,        /* 1 (default): levels whose tiles all fit on the chip at once run ALL sweeps in one launch,
+                                       neighbouring workgroups trading halo strips in memory (no kernel boundaries) */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),

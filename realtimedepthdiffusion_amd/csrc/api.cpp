@@ -65,6 +65,7 @@ const char *rtdd_status_string(int s) {
         case RTDD_ERR_HIP: return "HIP runtime error";
         case RTDD_ERR_NOMEM: return "out of memory";
         case RTDD_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+        case RTDD_ERR_TIMEOUT: return "persistent kernel timed out (workgroups not co-resident)";
         default: return "unknown status";
     }
 }
@@ -100,6 +101,7 @@ int rtdd_ctx_destroy(rtdd_ctx *ctx) {
     if (ctx->lut_dev) (void)hipFree(ctx->lut_dev);
     if (ctx->omega_dev) (void)hipFree(ctx->omega_dev);
     if (ctx->residual_dev) (void)hipFree(ctx->residual_dev);
+    if (ctx->sync_words) (void)hipFree(ctx->sync_words);
     if (ctx->sat) (void)hipFree(ctx->sat);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -116,6 +118,18 @@ int rtdd_ctx_synchronize(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     DeviceGuard g(ctx->device);
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->persistent_used && ctx->sync_words) {
+        // a persistent sweep launch gives up (instead of hanging) if a neighbouring workgroup never shows up,
+        // which can only happen when its workgroups were not all co-resident (the GPU was shared with other work)
+        int status = 0;
+        RTDD_HIP(ctx, hipMemcpy(&status, ctx->sync_words, sizeof(int), hipMemcpyDeviceToHost));
+        ctx->persistent_used = false;
+        if (status != 0) {
+            RTDD_HIP(ctx, hipMemset(ctx->sync_words, 0, 64));
+            return fail(ctx, RTDD_ERR_TIMEOUT, "persistent sweep kernel timed out waiting for a neighbouring workgroup: results are invalid; "
+                                               "set RTDD_OPT_PERSISTENT to 0 when the GPU is shared");
+        }
+    }
     return RTDD_OK;
 }
 
@@ -128,6 +142,7 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_USE_GRAPH: ctx->opt.use_graph = value ? 1 : 0; break;
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
         case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 12, "tile must be 0..12"); ctx->opt.tile = value; break;
+        case RTDD_OPT_PERSISTENT: ctx->opt.persistent = value ? 1 : 0; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;
@@ -142,6 +157,7 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_USE_GRAPH: *value = ctx->opt.use_graph; break;
         case RTDD_OPT_ROWS_PER_WAVE: *value = ctx->opt.rows_per_wave; break;
         case RTDD_OPT_TILE: *value = ctx->opt.tile; break;
+        case RTDD_OPT_PERSISTENT: *value = ctx->opt.persistent; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;

@@ -48,6 +48,7 @@ struct Options {
     int use_graph = 0;
     int rows_per_wave = 0;
     int tile = 0;
+    int persistent = 1;
 };
 
 }  // namespace rtdd
@@ -66,6 +67,9 @@ struct rtdd_ctx {
     float *omega_dev = nullptr;     // device copy of the omega schedule (temporally blocked kernel)
     int omega_cap = 0;
     float *residual_dev = nullptr;  // extension: residual reduction target
+    int *sync_words = nullptr;      // persistent sweep kernel: [0] = status, [16..] = per-tile block flags
+    int *sync_status_host = nullptr; // pinned host copy of the status word
+    bool persistent_used = false;   // a persistent launch happened since the last status check
     uint32_t *sat = nullptr;        // defocus summed-area table scratch
     size_t sat_elems = 0;
     int num_cus = 256;

@@ -34,6 +34,13 @@ __device__ __forceinline__ float lane_from_next(float v) {   // lane l <- lane l
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
+// write-through (sc1) 16-byte store for inter-workgroup hand-offs (no release fence needed; the storing wave drains vmcnt itself)
+__device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+
 // Result stores.  RTDD_STORE_MODE (diagnostic knob): 0 plain, 1 non-temporal, 2 write-through (sc1).
 #ifndef RTDD_STORE_MODE
 #define RTDD_STORE_MODE 0
@@ -109,12 +116,16 @@ __device__ unsigned long long g_stamps[4096][4];
 #define RTDD_STAMP(k) do {} while (0)
 #endif
 
-template <int LX, int NT, int G, bool CONTRACT>
-__global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_blocked(const float *__restrict__ Xk, const float *__restrict__ Xm,
-                                                      float *__restrict__ Yk, float *__restrict__ Ym,
+template <int LX, int NT, int G, bool CONTRACT, bool PERSIST>
+__global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_blocked(float *Xk, float *Xm, float *Yk, float *Ym,
                                                       const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
                                                       const float *__restrict__ omegas, int ip, int rows, int cols,
-                                                      int hx, int hy, int nsweeps, float gamma) {
+                                                      int hx, int hy, int nsweeps, float gamma,
+                                                      int block_sweeps, int *sync_words) {
+    // block_sweeps == nsweeps: the plain time-blocked launch (results -> Yk/Ym).
+    // block_sweeps <  nsweeps: PERSISTENT mode -- the workgroup keeps its tile in registers for the whole solve and,
+    // every block_sweeps (= halo width, even) sweeps, trades halo strips with its 8 neighbours through memory instead
+    // of ending the kernel.  Needs every workgroup co-resident (the host only uses it when grid <= #CUs).
     constexpr int EW = 4 * LX, NTR = NT / LX;
     __shared__ float lut[257];
     __shared__ float4 edge[2][NTR][2][LX];     // [buffer][thread row][0 = its top row, 1 = its bottom row][lane]
@@ -237,25 +248,85 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     };
 
     // (the divide variant is chosen per wave; the neighbour handshake above does not care which one a wave runs)
-    int s = 0;
-    if (!wave_unsafe) {
-        for (; s + 1 < nsweeps; s += 2) {
-            sweep(a, b, s, std::true_type{});
-            sweep(b, a, s + 1, std::true_type{});
+    const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
+    const int tile_id = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
+    int s = 0, blk = 0;
+    bool odd = false;
+    for (;; blk++) {
+        const int s_end = min(s + block_sweeps, nsweeps);
+        if (!wave_unsafe) {
+            for (; s + 1 < s_end; s += 2) {
+                sweep(a, b, s, std::true_type{});
+                sweep(b, a, s + 1, std::true_type{});
+            }
+            if (s < s_end) { sweep(a, b, s, std::true_type{}); s++; odd = true; }
+        } else {
+            for (; s + 1 < s_end; s += 2) {
+                sweep(a, b, s, std::false_type{});
+                sweep(b, a, s + 1, std::false_type{});
+            }
+            if (s < s_end) { sweep(a, b, s, std::false_type{}); s++; odd = true; }
         }
-        if (s < nsweeps) sweep(a, b, s, std::true_type{});
-    } else {
-        for (; s + 1 < nsweeps; s += 2) {
-            sweep(a, b, s, std::false_type{});
-            sweep(b, a, s + 1, std::false_type{});
+        if (!PERSIST || s >= nsweeps) break;
+
+        // ---- persistent mode: refresh the halo from the neighbours (block_sweeps is even here, so a = newest) ----
+        // Protocol (cdna_hip_programming.md Guideline 16, R1): write-through (sc1) payload stores; EVERY storing wave
+        // drains vmcnt; workgroup barrier; ONE lane stores the flag (agent-scope atomic); one wave polls the 8
+        // neighbour flags relaxed with s_sleep (bounded); ONE agent acquire; barrier; plain vector loads.
+        // Exchange buffers alternate between (Yk,Ym) and (Xk,Xm) by block parity: a neighbour publishes block b+1 only
+        // after consuming my block-b strips, and I overwrite that buffer (block b+2) only after waiting for its b+1.
+        {
+            float *Ek = (blk & 1) ? Xk : Yk, *Em = (blk & 1) ? Xm : Ym;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int y = y0 + g, ty = tr * G + g;
+                const bool central = xin && ty >= hy && ty < eh - hy && y < rows;
+                const bool band = ty < 2 * hy || ty >= eh - 2 * hy || 4 * lx < 2 * hx || 4 * lx >= EW - 2 * hx;
+                if (central && band) {
+                    const size_t off = (size_t)y * ip + x0;
+                    store_sc1((float4 *)(Ek + off), make_float4(a[g][0], a[g][1], a[g][2], a[g][3]));
+                    store_sc1((float4 *)(Em + off), make_float4(b[g][0], b[g][1], b[g][2], b[g][3]));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
+            __syncthreads();
+            int *flags = sync_words + 16;
+            if (tid == 0) __hip_atomic_store(&flags[tile_id], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < 9 && tid != 4) {                                   // lane i polls neighbour (i%3-1, i/3-1)
+                const int nx = (int)blockIdx.x + tid % 3 - 1, ny = (int)blockIdx.y + tid / 3 - 1;
+                if (nx >= 0 && ny >= 0 && nx < (int)gridDim.x && ny < (int)gridDim.y) {
+                    const int nb = ny * gridDim.x + nx;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(&flags[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < blk + 1) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 22)) { __hip_atomic_store(&sync_words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never hang: flag the solve as failed
+                    }
+                }
+            }
+            if (tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int y = y0 + g, ty = tr * G + g;
+                const bool central = xin && ty >= hy && ty < eh - hy;
+                const bool ok = colok && y >= 0 && y < rows;
+                if (ok && !central) {                                    // a halo pixel inside the image: some neighbour's centre
+                    const size_t off = (size_t)y * ip + x0;
+                    // plain vector loads behind the agent acquire (sc1 scalar loads instead of the acquire measured 2 % slower)
+                    const float4 vx = *(const float4 *)(Ek + off), vp = *(const float4 *)(Em + off);
+                    const float xv[4] = {vx.x, vx.y, vx.z, vx.w}, pv[4] = {vp.x, vp.y, vp.z, vp.w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const bool in = x0 + i < cols; a[g][i] = in ? xv[i] : 0.0f; b[g][i] = in ? pv[i] : 0.0f; }
+                }
+            }
         }
-        if (s < nsweeps) sweep(a, b, s, std::false_type{});
+        (void)ntiles;
     }
-    const bool odd = (nsweeps & 1) != 0;
+    // results of the last block go to the exchange buffer of ITS parity (free by the argument above; blk = 0 -> Yk/Ym)
+    if (PERSIST && (blk & 1)) { Yk = Xk; Ym = Xm; }
     RTDD_STAMP(2);
 
     // ---- write back the part that is still exact ---------------------------------------------------
-    const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const int y = y0 + g, ty = tr * G + g;
@@ -285,12 +356,13 @@ static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 102
 constexpr int kNumTiles = 12;
 
 template <int LX, int NT, int G>
-static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int nthreads, const float *Xk, const float *Xm, float *Yk, float *Ym, const uint32_t *M,
-                       const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma) {
-    if (ctx->opt.fp_contract)
-        hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, true>), grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma);
-    else
-        hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, false>), grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma);
+static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int nthreads, float *Xk, float *Xm, float *Yk, float *Ym, const uint32_t *M,
+                       const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma, int block_sweeps) {
+    const bool persist = block_sweeps < n;
+#define RTDD_LAUNCH(C, P) hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, C, P>), grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma, block_sweeps, ctx->sync_words)
+    if (ctx->opt.fp_contract) { if (persist) RTDD_LAUNCH(true, true); else RTDD_LAUNCH(true, false); }
+    else { if (persist) RTDD_LAUNCH(false, true); else RTDD_LAUNCH(false, false); }
+#undef RTDD_LAUNCH
 }
 
 // Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
@@ -323,9 +395,9 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
     int done = 0;
     *launches = 0;
     while (done < n) {
-        const int m = single ? n - done : (n - done < T ? n - done : T);
-        const int hy = single ? 0 : m;
-        const int hx = single ? 0 : (m + 3) / 4 * 4;
+        int m = single ? n - done : (n - done < T ? n - done : T);
+        const int hy = single ? 0 : (n - done < T ? n - done : T);
+        const int hx = single ? 0 : (hy + 3) / 4 * 4;
         // a single tile launches only the thread rows the image needs (whole waves), e.g. 120x67 -> 23 of 32 rows
         int nthreads = kTiles[tile].nt;
         if (single) {
@@ -336,13 +408,30 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         const int eh = nthreads / kTiles[tile].lx * kTiles[tile].g;
         const int TW = EW - 2 * hx, TH = eh - 2 * hy;
         const dim3 grid((cols + TW - 1) / TW, (rows + TH - 1) / TH);
+        // PERSISTENT mode: all remaining sweeps in ONE launch, neighbouring workgroups trade halo strips every T sweeps.
+        // Only when every workgroup is certainly co-resident (grid <= #CUs), T is even, and there is more than one block.
+        int block_sweeps = m;
+        const bool persistent = !single && ctx->opt.persistent && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= 1000 &&
+                                (T % 2 == 0) && n - done > T && hy == T &&
+                                hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
+        if (persistent) {
+            if (!ctx->sync_words) {
+                RTDD_HIP(ctx, hipMalloc((void **)&ctx->sync_words, 1024 * sizeof(int) + 64));
+                RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words, 0, 64, ctx->stream));
+            }
+            // per-tile flags are zeroed every call; the status word [0] is sticky until rtdd_ctx_synchronize() reads it
+            RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + 16, 0, 1024 * sizeof(int), ctx->stream));
+            ctx->persistent_used = true;
+            block_sweeps = T;
+            m = n - done;
+        }
         // outputs go to the two spare planes, then the pairs swap
         int free0 = -1, free1 = -1;
         for (int i = 0; i < 4; i++) if (i != *pk && i != *pm) { if (free0 < 0) free0 = i; else free1 = i; }
-        const float *Xk = L.P(*pk, ip), *Xm = L.P(*pm, ip);
+        float *Xk = L.P(*pk, ip), *Xm = L.P(*pm, ip);
         float *Yk = L.P(free0, ip), *Ym = L.P(free1, ip);
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) \
-    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma); break;
+    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps); break;
         switch (tile) {
             RTDD_TILE_CASE(1, 16, 256, 4)
             RTDD_TILE_CASE(2, 32, 512, 4)
@@ -358,7 +447,10 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             RTDD_TILE_CASE(12, 32, 768, 4)
         }
 #undef RTDD_TILE_CASE
-        *pk = free0; *pm = free1;
+        // where the results are: the plain launch writes the spare pair; the persistent one the exchange buffer of its
+        // last block's parity (blocks 0,2,.. -> spare pair, 1,3,.. -> the input pair)
+        const int nblocks = (m + block_sweeps - 1) / block_sweeps;
+        if (((nblocks - 1) & 1) == 0) { *pk = free0; *pm = free1; }
         done += m;
         (*launches)++;
     }

@@ -78,6 +78,31 @@ def test_blocked_kernel_bit_exact(ctx, oracle, lut, tile, depth, shape, iters, l
     assert_bit_equal(got, want, f"blocked tile {tile} depth {depth} {shape}")
 
 
+@pytest.mark.parametrize("shape,iters,tile,depth", [
+    ((200, 333), 100, 9, 8),       # 7x5 tiles of 64x64, 12.5 blocks
+    ((200, 333), 37, 1, 4),        # odd tail block
+    ((270, 480), 250, 4, 8),       # 5x4 tiles of 128x96
+    ((135, 240), 500, 9, 16),      # depth 16: 8x5 tiles of 32x32 centres
+    ((540, 960), 125, 4, 8),
+    ((1080, 1920), 200, 4, 8),     # 252 workgroups: the headline configuration
+    ((300, 130), 64, 7, 16),
+])
+def test_persistent_mode_bit_exact(ctx, oracle, lut, shape, iters, tile, depth):
+    """Persistent mode: one launch, tiles stay in registers, neighbouring workgroups trade halo strips through
+    memory every `depth` sweeps (agent-scope flags).  Still only a re-schedule: bit-exact."""
+    p = make_problem(shape[0], shape[1], seed=shape[0] + 3 * shape[1])
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, 0, 0, lut, 1, threads=oracle.max_threads())
+    opts = {rt.OPT_SWEEP_KERNEL: 2, rt.OPT_TILE: tile, rt.OPT_TEMPORAL_DEPTH: depth, rt.OPT_PERSISTENT: 1}
+    ctx.profile_enable(True)
+    for rep in range(3):                       # repeated: flags are re-zeroed per call, L1/L2 are warm on later reps
+        got = _solve_gpu(ctx, p, iters, 0, 1, 1, opts=opts)
+        assert ctx.profile().launches == 1, "not persistent: more than one launch"
+        assert_bit_equal(got, want, f"persistent {shape} tile {tile} depth {depth} rep {rep}")
+    ctx.profile_enable(False)
+    for k in opts:
+        ctx.set_option(k, 0)
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
 @pytest.mark.parametrize("contract", [0, 1])
 def test_both_kernels_both_contractions(ctx, oracle, lut, kernel, contract):
