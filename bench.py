@@ -81,10 +81,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="1080p_jacobi1000", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-estimate", action="store_true", help="skip the whole-cascade timing leg (profiling runs)")
     ap.add_argument("--sweep-kernel", type=int, default=0)
     ap.add_argument("--temporal-depth", type=int, default=0)
     ap.add_argument("--rows-per-wave", type=int, default=0)
-    ap.add_argument("--graph", type=int, default=-1)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--persistent", type=int, default=-1)
     args = ap.parse_args()
@@ -117,7 +117,6 @@ def main():
     if args.sweep_kernel: ctx.set_option(rt.OPT_SWEEP_KERNEL, args.sweep_kernel)
     if args.temporal_depth: ctx.set_option(rt.OPT_TEMPORAL_DEPTH, args.temporal_depth)
     if args.rows_per_wave: ctx.set_option(rt.OPT_ROWS_PER_WAVE, args.rows_per_wave)
-    if args.graph >= 0: ctx.set_option(rt.OPT_USE_GRAPH, args.graph)
     if args.tile: ctx.set_option(rt.OPT_TILE, args.tile)
     if args.persistent >= 0: ctx.set_option(rt.OPT_PERSISTENT, args.persistent)
     mask = rt.device_image(p["mask"], dev); gray = rt.device_image(p["gray"], dev)
@@ -172,7 +171,7 @@ def main():
                     out["roofline"]["traffic_source"] = prof.get("source", "profiles/traffic_latest.json")
     except (OSError, ValueError, KeyError):
         pass
-    if rank == 0 and args.workload == "1080p_jacobi1000":
+    if rank == 0 and args.workload == "1080p_jacobi1000" and not args.no_estimate:
         out["estimate"] = estimate_ms(rt, ctx, p, rows, cols, dev)      # second half of BASELINE's metric; outside the timed region
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rows, cols)

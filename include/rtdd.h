@@ -56,7 +56,7 @@ enum rtdd_option {
     RTDD_OPT_FP_CONTRACT = 0,       /* 1 (default): fused multiply-adds where nvcc -fmad=true fuses; 0: none */
     RTDD_OPT_SWEEP_KERNEL = 1,      /* 0 auto (default), 1 one sweep per launch, 2 temporally blocked */
     RTDD_OPT_TEMPORAL_DEPTH = 2,    /* sweeps fused per launch by the blocked kernel (0 = auto) */
-    RTDD_OPT_USE_GRAPH = 3,         /* 1: replay the sweep sequence from a captured hipGraph */
+    RTDD_OPT_RESERVED_3 = 3,        /* (unused) */
     RTDD_OPT_ROWS_PER_WAVE = 4,     /* one-sweep kernel: rows each wave walks (0 = auto) */
     RTDD_OPT_PERSISTENT = 6,        /* 1 (default): levels whose tiles all fit on the chip at once run ALL sweeps in one launch,
                                        neighbouring workgroups trading halo strips in memory (no kernel boundaries) */

@@ -22,7 +22,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 RTDD_OK = 0
 METHOD_CHEBYSHEV_JACOBI = 0
 METHOD_RED_BLACK_GS = 1
-OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, OPT_USE_GRAPH, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
+OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, _OPT_RESERVED_3, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/rtdd.h declares (checked by tests/test_abi.py against the header)
 C_ABI_SYMBOLS = [

@@ -139,7 +139,6 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_FP_CONTRACT: ctx->opt.fp_contract = value ? 1 : 0; break;
         case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 2, "sweep kernel must be 0..2"); ctx->opt.sweep_kernel = value; break;
         case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 28, "temporal depth must be 0..28"); ctx->opt.temporal_depth = value; break;
-        case RTDD_OPT_USE_GRAPH: ctx->opt.use_graph = value ? 1 : 0; break;
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
         case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 12, "tile must be 0..12"); ctx->opt.tile = value; break;
         case RTDD_OPT_PERSISTENT: ctx->opt.persistent = value ? 1 : 0; break;
@@ -154,7 +153,6 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_FP_CONTRACT: *value = ctx->opt.fp_contract; break;
         case RTDD_OPT_SWEEP_KERNEL: *value = ctx->opt.sweep_kernel; break;
         case RTDD_OPT_TEMPORAL_DEPTH: *value = ctx->opt.temporal_depth; break;
-        case RTDD_OPT_USE_GRAPH: *value = ctx->opt.use_graph; break;
         case RTDD_OPT_ROWS_PER_WAVE: *value = ctx->opt.rows_per_wave; break;
         case RTDD_OPT_TILE: *value = ctx->opt.tile; break;
         case RTDD_OPT_PERSISTENT: *value = ctx->opt.persistent; break;

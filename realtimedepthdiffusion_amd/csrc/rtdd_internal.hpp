@@ -45,7 +45,6 @@ struct Options {
     int fp_contract = 1;
     int sweep_kernel = 0;
     int temporal_depth = 0;
-    int use_graph = 0;
     int rows_per_wave = 0;
     int tile = 0;
     int persistent = 1;

@@ -115,6 +115,14 @@ __device__ unsigned long long g_stamps[4096][4];
 #else
 #define RTDD_STAMP(k) do {} while (0)
 #endif
+#ifdef RTDD_STAMPS
+__device__ unsigned long long g_xphase[4096][6];
+#define RTDD_XT(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); g_xphase[blockIdx.y * gridDim.x + blockIdx.x][k] += t_ - xt_; xt_ = t_; } } while (0)
+#define RTDD_XT_BEGIN unsigned long long xt_ = __builtin_amdgcn_s_memrealtime()
+#else
+#define RTDD_XT(k) do {} while (0)
+#define RTDD_XT_BEGIN do {} while (0)
+#endif
 
 template <int LX, int NT, int G, bool CONTRACT, bool PERSIST>
 __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_blocked(float *Xk, float *Xm, float *Yk, float *Ym,
@@ -252,6 +260,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     const int tile_id = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
     int s = 0, blk = 0;
     bool odd = false;
+    RTDD_XT_BEGIN;
     for (;; blk++) {
         const int s_end = min(s + block_sweeps, nsweeps);
         if (!wave_unsafe) {
@@ -268,6 +277,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
             if (s < s_end) { sweep(a, b, s, std::false_type{}); s++; odd = true; }
         }
         if (!PERSIST || s >= nsweeps) break;
+        RTDD_XT(0);
 
         // ---- persistent mode: refresh the halo from the neighbours (block_sweeps is even here, so a = newest) ----
         // Protocol (cdna_hip_programming.md Guideline 16, R1): write-through (sc1) payload stores; EVERY storing wave
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
             __syncthreads();
+            RTDD_XT(1);
             int *flags = sync_words + 16;
             if (tid == 0) __hip_atomic_store(&flags[tile_id], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tid < 9 && tid != 4) {                                   // lane i polls neighbour (i%3-1, i/3-1)
@@ -303,8 +314,10 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
                     }
                 }
             }
+            RTDD_XT(2);
             if (tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             __syncthreads();
+            RTDD_XT(3);
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const int y = y0 + g, ty = tr * G + g;
@@ -321,6 +334,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
             }
         }
         (void)ntiles;
+        RTDD_XT(4);
     }
     // results of the last block go to the exchange buffer of ITS parity (free by the argument above; blk = 0 -> Yk/Ym)
     if (PERSIST && (blk & 1)) { Yk = Xk; Ym = Xm; }

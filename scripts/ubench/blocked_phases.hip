@@ -41,6 +41,21 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 4096; i++) if (st[i][3] > st[i][0] && st[i][0] != 0) { n++; t0 = std::min(t0, st[i][0]); tend = std::max(tend, st[i][3]); }
     double a = 0, b = 0, c = 0, start = 0;
     for (int i = 0; i < 4096; i++) if (st[i][3] > st[i][0] && st[i][0] != 0) { a += st[i][1] - st[i][0]; b += st[i][2] - st[i][1]; c += st[i][3] - st[i][2]; start += st[i][0] - t0; }
+    if (getenv("RTDD_PERSIST")) {
+        static unsigned long long z6[4096][6]; hipMemcpyToSymbol(HIP_SYMBOL(g_xphase), z6, sizeof(z6));
+        ctx.opt.persistent = 1; ctx.num_cus = 256;
+        hipEvent_t p0, p1; hipEventCreate(&p0); hipEventCreate(&p1);
+        const int nb = 25;
+        hipEventRecord(p0, ctx.stream);
+        launch_sweeps_blocked(&ctx, L, ip, rows, cols, om_d, T * nb, &pk, &pm, &ln);
+        hipEventRecord(p1, ctx.stream); hipDeviceSynchronize();
+        float pms; hipEventElapsedTime(&pms, p0, p1);
+        static unsigned long long xp[4096][6]; hipMemcpyFromSymbol(xp, HIP_SYMBOL(g_xphase), sizeof(xp));
+        double ph[5] = {0, 0, 0, 0, 0}; int nw = 0;
+        for (int i = 0; i < 4096; i++) if (xp[i][0]) { nw++; for (int k = 0; k < 5; k++) ph[k] += xp[i][k]; }
+        printf("PERSISTENT %d launches, %d blocks of %d sweeps: %.2f us per block; wave-0 means per block: sweeps %.2f, publish+drain+barrier %.2f, flag+poll %.2f, acquire+barrier %.2f, halo load %.2f us\n",
+               ln, nb, T, pms * 1e3 / nb, ph[0] / nw / 100 / (nb - 1), ph[1] / nw / 100 / (nb - 1), ph[2] / nw / 100 / (nb - 1), ph[3] / nw / 100 / (nb - 1), ph[4] / nw / 100 / (nb - 1));
+    }
     printf("%dx%d tile %d T %d: %d workgroups; mean per WG: start skew %.2f us, load+setup %.2f us, %d sweeps %.2f us (%.3f us/sweep), store %.2f us; first start -> last end %.2f us\n",
            cols, rows, tile, T, n, start / n / 100, a / n / 100, T, b / n / 100, b / n / 100 / T, c / n / 100, (tend - t0) / 100.0);
     return 0;

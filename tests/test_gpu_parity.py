@@ -103,6 +103,34 @@ def test_persistent_mode_bit_exact(ctx, oracle, lut, shape, iters, tile, depth):
         ctx.set_option(k, 0)
 
 
+def test_persistent_mode_stress_under_uneven_load(oracle, lut):
+    """Hand-offs must hold under uneven load with warm caches (cdna_hip_programming.md G16 pitfall 3): 40 solves
+    back to back (1000 halo exchanges of 252 workgroups) while a second stream streams 1 GiB through the memory
+    system, every result compared bit for bit."""
+    import torch
+    rows, cols, iters = 1080, 1920, 200
+    p = make_problem(rows, cols, seed=99)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, 0, 0, lut, 1, threads=oracle.max_threads())
+    c = rt.Context(0); c.GPULoadWeights(0.4); c.GPUAllocateDeviceMemory(rows, cols, 1)
+    main = torch.cuda.Stream(); side = torch.cuda.Stream()
+    c.set_stream(main.cuda_stream)
+    m, g = up(p["mask"]), up(p["gray"])
+    ds = [up(p["depth"]) for _ in range(40)]
+    noise = torch.empty(256 << 20, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    c.profile_enable(True)
+    for i, d in enumerate(ds):
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                noise.mul_(1.0001)                      # bandwidth hog on another stream, overlapping some solves
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, iters, 0.0, 0)
+        assert c.profile().launches == 1                # persistent
+    c.synchronize(); torch.cuda.synchronize()           # synchronize() also checks the kernel's timeout word
+    bad = [i for i, d in enumerate(ds) if not np.array_equal(down(d).view(np.uint32), want.view(np.uint32))]
+    assert not bad, f"solves {bad} differ"
+    c.close()
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
 @pytest.mark.parametrize("contract", [0, 1])
 def test_both_kernels_both_contractions(ctx, oracle, lut, kernel, contract):
