@@ -100,11 +100,22 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("RTDD_BENCH_SHARE_GPU"):     # rehearsal on a 1-GPU box: every rank on device 0 (use --persistent 0)
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # The data path has NO collective (independent images); the process group only serves the timing barrier and
+        # the MAX/SUM of two scalars.  RCCL ("nccl") is used when it comes up, gloo otherwise -- the result is the same.
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.barrier()
+        except Exception as e:                                  # noqa: BLE001
+            print(f"[bench] rank {rank}: nccl unavailable ({e!r}); using gloo for the timing barrier", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo")
 
     w = WORKLOADS[args.workload]
     rows, cols, iters = w["rows"], w["cols"], w["iters"]
@@ -143,7 +154,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     px_iter_per_step = rows * cols * iters
-    units, elapsed, thr = shard.aggregate(args.steps * px_iter_per_step, elapsed, dist, dev)   # SUM of units, MAX of time
+    agg_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
+    units, elapsed, thr = shard.aggregate(args.steps * px_iter_per_step, elapsed, dist, agg_dev)   # SUM of units, MAX of time
     value = thr / 1e6
     launch_us = sweep_ms * 1e3 / max(launches, 1)
     sweeps_per_launch = sweeps / max(launches, 1)
