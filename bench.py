@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="1080p_jacobi1000", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="1080p_jacobi1000", help="one of %s, or ROWSxCOLSxITERS" % ", ".join(sorted(WORKLOADS)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-estimate", action="store_true", help="skip the whole-cascade timing leg (profiling runs)")
     ap.add_argument("--sweep-kernel", type=int, default=0)
@@ -117,6 +117,9 @@ def main():
                 dist.destroy_process_group()
             dist.init_process_group("gloo")
 
+    if args.workload not in WORKLOADS:
+        r_, c_, i_ = (int(v) for v in args.workload.split("x"))
+        WORKLOADS[args.workload] = dict(rows=r_, cols=c_, iters=i_)
     w = WORKLOADS[args.workload]
     rows, cols, iters = w["rows"], w["cols"], w["iters"]
     p = make_problem(rows, cols, seed=1234 + rank)

@@ -21,6 +21,7 @@
 // Outside-image pixels are held at x = 0 with all weights 0, which reproduces the reference's
 // "skip the missing neighbour" (src/GPUSolver.cu:79-101) exactly: fma(0, 0, s) == s up to the
 // sign of a zero sum, and that sign never reaches the output ("Zero-weight borders").
+#include <cstdlib>
 #include <type_traits>
 
 #include "rtdd_internal.hpp"
@@ -379,28 +380,97 @@ static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int nthreads, float *Xk, float 
 #undef RTDD_LAUNCH
 }
 
+// ---- configuration cost model -------------------------------------------------------------------------
+// Estimated microseconds per sweep of the whole image for (tile, depth T, persistent or not), from measured
+// constants (MI355X; scripts/tile_sweep*.sh, size_sweep.sh, ubench/blocked_phases.hip, ubench/launch_gap*.hip):
+//   a sweep of one workgroup   max(latency 0.25 + 0.28*G us  [dependent chains, one wave per SIMD is enough to see it],
+//                                  throughput 1.5 us per 12288 extended pixels resident on the CU [VALU bound])
+//   tile load                  12 B per extended pixel at 22.6 GB/s per CU (5.8 TB/s chip-wide); stores are posted
+//   kernel boundary            ~6 us when tens of MB move, ~3.5 us for small levels
+//   one round (nWG <= slots)   boundary + load + T sweeps, nothing overlaps
+//   several rounds             tiles with >= 2 workgroups per CU hide the load behind the other workgroup's arithmetic
+//                              (x1.25 for imperfect overlap); 1-per-CU tiles pay load + sweeps + store per workgroup
+//   persistent                 T sweeps + ~8 us halo exchange (6 us for the small tiles); needs nWG <= #CUs, T even,
+//                              halo no wider than a neighbour's centre
+// It only has to rank candidates; it reproduces the measured launch times within ~15 %.
+static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1};
+
+static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int tile, int T, bool persist) {
+    const int G = kTiles[tile].g;
+    const int EW = 4 * kTiles[tile].lx, EH = kTiles[tile].nt / kTiles[tile].lx * G;
+    const int hx = (T + 3) / 4 * 4, TW = EW - 2 * hx, TH = EH - 2 * T;
+    if (TW < 16 || TH < 8) return 1e30;
+    const double nwg = (double)((cols + TW - 1) / TW) * ((rows + TH - 1) / TH);
+    const double cus = ctx->num_cus, ext = (double)EW * EH;
+    const double lat = 0.25 + 0.28 * G;
+    const double thr1 = 1.5 * ext / 12288.0;                    // one workgroup alone on a CU
+    const double img_bytes = (double)rows * cols * 20.0;
+    const double small = img_bytes < 2e6 ? 0.5 : 1.0;           // tiny levels (< 100 Kpx) sit in L2: cheaper loads and boundaries
+    const double bw = img_bytes > 2e8 ? 17600.0 : 22600.0;      // bytes/us per CU: 4.5 TB/s from HBM (8K), 5.8 TB/s from the Infinity Cache
+    const double load1 = small * ext * 12.0 / bw, store1 = small * (double)TW * TH * 8.0 / bw;
+    if (persist) {
+        if (nwg > cus || (T & 1) || hx > TW || T > TH || n <= T) return 1e30;
+        return (T * (lat > thr1 ? lat : thr1) + 5.0 + 3.0 * ext / 12288.0) / T;
+    }
+    const int k = kWgPerCu[tile];
+    const double boundary = small < 1.0 ? 3.5 : 6.0;
+    const double m = nwg / cus;                                 // workgroups each CU has to process
+    double t;
+    if (m <= k) {                                               // one round
+        const double on_cu = m < 1.0 ? 1.0 : ceil(m);
+        const double thr = thr1 * on_cu;
+        t = boundary + load1 * on_cu + T * (lat > thr ? lat : thr) + 0.5;
+    } else if (k >= 2) {
+        const double rounds = ceil(nwg / (cus * k));
+        const double m_eff = rounds <= 3 ? rounds * k : m;     // few rounds: the last, partly filled one costs a whole round
+        const double comp = 1.45 * T * thr1, mem = load1 + store1;
+        t = boundary + load1 + m_eff * (comp > mem ? comp : mem);
+    } else {
+        t = boundary + ceil(m) * (load1 + T * (lat > thr1 ? lat : thr1) + 0.5 * store1);
+    }
+    return t / T;
+}
+
+static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fixed_tile, int fixed_T, int *tile, int *T, bool *persist) {
+    static const int tiles[] = {4, 8, 9, 6, 5, 7, 12};
+    static const int depths[] = {4, 8, 12, 16, 24};
+    double best = 1e30;
+    *tile = 9; *T = 8; *persist = false;
+    for (int ti : tiles) {
+        if (fixed_tile && ti != fixed_tile) continue;
+        for (int d : depths) {
+            if (fixed_T && d != fixed_T) continue;
+            for (int p = 0; p < 2; p++) {
+                if (p && !ctx->opt.persistent) continue;
+                const double c = config_cost(ctx, rows, cols, n, ti, d, p != 0);
+                if (c < best) { best = c; *tile = ti; *T = d; *persist = p != 0; }
+            }
+        }
+    }
+    if (fixed_tile && best >= 1e30) *tile = fixed_tile;
+    if (fixed_T && best >= 1e30) *T = fixed_T;
+    if (getenv("RTDD_DEBUG_CONFIG"))
+        fprintf(stderr, "[rtdd] %dx%d n=%d -> tile %d depth %d persistent %d (model %.3f us/sweep)\n", cols, rows, n, *tile, *T, (int)*persist, best);
+}
+
 // Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
 // holding x_{k+n} / x_{k+n-1}.  omegas_dev[0..n) must already be on the device.
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
                           int *pk, int *pm, int *launches) {
     const float gamma = 0.99;
-    // Tile / depth choice.  Measured on MI355X (scripts/tile_sweep*.sh, profiles/r01_tile_sweep.txt):
-    // what matters is (a) the number of workgroups against the number of resident slots (a 1080p
-    // image is only ~250 tiles of 128x96: ONE per CU, so one tile too many doubles the time),
-    // (b) redundancy (extended / written-back area) and (c) launches per sweep for the small,
-    // latency-bound pyramid levels.
+    // Tile / depth / persistence choice: a small cost model calibrated on MI355X measurements
+    // (scripts/tile_sweep*.sh, scripts/size_sweep.sh, scripts/ubench/*; tables in profiles/).
     int tile = ctx->opt.tile, T = ctx->opt.temporal_depth;
-    const long px = (long)rows * cols;
-    int auto_tile, auto_T;
-    if (cols <= 64 && rows <= 64) { auto_tile = 9; auto_T = 8; }             // ONE tile, 4 px/thread: all sweeps in one launch (0.45 us/sweep)
-    else if (cols <= 128 && rows <= 32) { auto_tile = 11; auto_T = 8; }      // ditto
-    else if (px < 40000L) { auto_tile = 9; auto_T = 24; }                    // 120x67, 240x135: idle CUs make halo redundancy free; fewer launches win
-    else if (px < 250000L) { auto_tile = 9; auto_T = 16; }                   // 480x270
-    else if (px < 1200000L) { auto_tile = 9; auto_T = 8; }                   // 960x540
-    else if (px < 3500000L) { auto_tile = 4; auto_T = 8; }                   // 1080p: 252 tiles of 128x96 on 256 CUs
-    else { auto_tile = 6; auto_T = 8; }                                      // 4K / 8K: many rounds, 2 workgroups per CU
-    if (tile == 0) tile = auto_tile;
-    if (T == 0) T = auto_T;
+    bool want_persistent = ctx->opt.persistent != 0;
+    if (tile == 0 || T == 0) {
+        int bt = 0, bT = 0; bool bp = false;
+        if (cols <= 64 && rows <= 64) { bt = 9; bT = 8; }                  // ONE tile, 4 px/thread: all sweeps in one launch
+        else if (cols <= 128 && rows <= 32) { bt = 11; bT = 8; }           // ditto
+        else choose_config(ctx, rows, cols, n, tile, T, &bt, &bT, &bp);
+        if (tile == 0) tile = bt;
+        if (T == 0) T = bT;
+        if (ctx->opt.tile == 0 && ctx->opt.temporal_depth == 0) want_persistent = want_persistent && bp;
+    }
     if (tile < 1 || tile > kNumTiles) tile = 1;
     const int EW = 4 * kTiles[tile].lx, EH = kTiles[tile].nt / kTiles[tile].lx * kTiles[tile].g;
     const bool single = cols <= EW && rows <= EH;
@@ -425,7 +495,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         // PERSISTENT mode: all remaining sweeps in ONE launch, neighbouring workgroups trade halo strips every T sweeps.
         // Only when every workgroup is certainly co-resident (grid <= #CUs), T is even, and there is more than one block.
         int block_sweeps = m;
-        const bool persistent = !single && ctx->opt.persistent && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= 1000 &&
+        const bool persistent = !single && want_persistent && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= 1000 &&
                                 (T % 2 == 0) && n - done > T && hy == T &&
                                 hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
         if (persistent) {
