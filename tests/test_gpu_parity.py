@@ -103,6 +103,34 @@ def test_persistent_mode_bit_exact(ctx, oracle, lut, shape, iters, tile, depth):
         ctx.set_option(k, 0)
 
 
+def test_randomised_shapes_and_options(ctx, oracle, lut):
+    """60 random (shape, sweeps, level rule, kernel, tile, depth, persistence, contraction) draws, fixed seed: every
+    one bit-exact.  Catches geometry corner cases the hand-picked lists miss (ragged tiles, tiny centres, 1-pixel strips)."""
+    rng = np.random.default_rng(20261003)
+    for trial in range(60):
+        rows = int(rng.integers(1, 420)); cols = int(rng.integers(1, 520))
+        if trial % 7 == 0: rows = int(rng.integers(1, 6))
+        if trial % 11 == 0: cols = int(rng.integers(1, 6))
+        iters = int(rng.integers(1, 90))
+        levels = int(rng.integers(1, 4)); level = int(rng.integers(0, levels))
+        contract = int(rng.integers(0, 2))
+        kernel = int(rng.choice([0, 0, 1, 2]))
+        opts = {rt.OPT_SWEEP_KERNEL: kernel, rt.OPT_PERSISTENT: int(rng.integers(0, 2))}
+        if kernel != 1 and rng.random() < 0.6:
+            opts[rt.OPT_TILE] = int(rng.integers(1, 13)); opts[rt.OPT_TEMPORAL_DEPTH] = int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 24]))
+        p = make_problem(rows, cols, seed=1000 + trial)
+        if (p["mask"] == 255).sum() == 0:
+            p["mask"][rows // 2, cols // 2] = 255; p["depth"][rows // 2, cols // 2] = 128
+        free = p["mask"] != 255
+        p["depth"][free] = rng.uniform(0, 255, int(free.sum())).astype(np.float32)
+        want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, level, levels - 1, lut, contract, threads=min(8, oracle.max_threads()))
+        got = _solve_gpu(ctx, p, iters, level, levels, contract, opts=opts)
+        for k in (rt.OPT_SWEEP_KERNEL, rt.OPT_TILE, rt.OPT_TEMPORAL_DEPTH):
+            ctx.set_option(k, 0)
+        ctx.set_option(rt.OPT_PERSISTENT, 1)
+        assert_bit_equal(got, want, f"trial {trial}: {rows}x{cols} iters {iters} level {level}/{levels} contract {contract} opts {opts}")
+
+
 def test_persistent_mode_stress_under_uneven_load(oracle, lut):
     """Hand-offs must hold under uneven load with warm caches (cdna_hip_programming.md G16 pitfall 3): 40 solves
     back to back (1000 halo exchanges of 252 workgroups) while a second stream streams 1 GiB through the memory
@@ -195,8 +223,8 @@ def test_solver_pitch_independent(ctx, oracle, lut, align):
 def test_solver_independent_of_strip_height(ctx, oracle, lut, rows_per_wave):
     p = make_problem(75, 300, seed=17)
     want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 20, 0, 0, lut, 1)
-    got = _solve_gpu(ctx, p, 20, 0, 1, 1, opts={rt.OPT_ROWS_PER_WAVE: rows_per_wave})
-    ctx.set_option(rt.OPT_ROWS_PER_WAVE, 0)
+    got = _solve_gpu(ctx, p, 20, 0, 1, 1, opts={rt.OPT_SWEEP_KERNEL: 1, rt.OPT_ROWS_PER_WAVE: rows_per_wave})   # the one-sweep kernel
+    ctx.set_option(rt.OPT_ROWS_PER_WAVE, 0); ctx.set_option(rt.OPT_SWEEP_KERNEL, 0)
     assert_bit_equal(got, want)
 
 
