@@ -152,10 +152,10 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
-        pr = ctx.profile(); sweep_ms += pr.sweep_ms; launches += pr.launches; sweeps += pr.sweeps
+        step(args.warmup + i)                  # asynchronous: nothing in the timed loop waits for the GPU
     fence()
     elapsed = time.perf_counter() - t0
+    pr = ctx.profile(); sweep_ms = pr.sweep_ms; launches = pr.launches; sweeps = pr.sweeps   # events recorded inside the timed region
     px_iter_per_step = rows * cols * iters
     agg_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
     units, elapsed, thr = shard.aggregate(args.steps * px_iter_per_step, elapsed, dist, agg_dev)   # SUM of units, MAX of time

@@ -198,10 +198,10 @@ int rtdd_download(rtdd_ctx *ctx, void *host, size_t hostPitch, const void *dev, 
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 
-/* Device time of the solver's sweep launches in the most recent rtdd_matrix_free_solver /
- * rtdd_solve_ex call on ctx, measured with HIP events on the context's stream (enable with
- * rtdd_profile_enable(ctx, 1); it forces a stream sync at the end of that call).
- * launches = sweep-kernel launches, sweeps = Jacobi sweeps they performed. */
+/* Device time of the solver's phases, measured with HIP events recorded on the context's stream around
+ * them (enable with rtdd_profile_enable(ctx, 1)).  Recording does not synchronise; rtdd_profile_get waits
+ * for the recorded calls and returns TOTALS over the solve calls made since the previous rtdd_profile_get
+ * (at most the last 64).  launches = sweep-kernel launches, sweeps = Jacobi sweeps they performed. */
 typedef struct rtdd_profile {
     double sweep_ms;
     int launches;

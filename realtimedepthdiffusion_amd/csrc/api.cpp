@@ -164,12 +164,30 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
 int rtdd_profile_enable(rtdd_ctx *ctx, int on) {
     if (!ctx) return RTDD_ERR_INVALID;
     ctx->profile_on = on != 0;
+    ctx->prof_pending = 0;
     return RTDD_OK;
 }
 
 int rtdd_profile_get(rtdd_ctx *ctx, rtdd_profile *out) {
     if (!ctx || !out) return RTDD_ERR_INVALID;
-    *out = ctx->prof;
+    DeviceGuard g(ctx->device);
+    // totals over the solve calls made since the previous rtdd_profile_get (at most the last kProfSlots of them)
+    rtdd_profile p{};
+    const int n = ctx->prof_pending < rtdd_ctx::kProfSlots ? ctx->prof_pending : rtdd_ctx::kProfSlots;
+    for (int i = 0; i < n; i++) {
+        const int slot = (ctx->prof_pending - 1 - i) % rtdd_ctx::kProfSlots;
+        hipEvent_t *ev = ctx->ev + 4 * slot;
+        RTDD_HIP(ctx, hipEventSynchronize(ev[3]));
+        float a = 0, b = 0, c = 0;
+        RTDD_HIP(ctx, hipEventElapsedTime(&a, ev[0], ev[1]));
+        RTDD_HIP(ctx, hipEventElapsedTime(&b, ev[1], ev[2]));
+        RTDD_HIP(ctx, hipEventElapsedTime(&c, ev[2], ev[3]));
+        p.prepare_ms += a; p.sweep_ms += b; p.finish_ms += c;
+        p.launches += ctx->prof_launches[slot]; p.sweeps += ctx->prof_sweeps[slot];
+    }
+    ctx->prof_pending = 0;
+    ctx->prof = p;
+    *out = p;
     return RTDD_OK;
 }
 
@@ -263,12 +281,12 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     const Level &L = ctx->levels[level];
     const size_t ip = plane_pitch(cols);
     const bool prof = ctx->profile_on;
-    ctx->prof = rtdd_profile{};
+    hipEvent_t *ev = ctx->ev + 4 * (ctx->prof_pending % rtdd_ctx::kProfSlots);
 
-    if (prof) RTDD_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (prof) RTDD_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
     rc = launch_prepare(ctx, L, ip, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
     if (rc != RTDD_OK) return rc;
-    if (prof) RTDD_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (prof) RTDD_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
 
     const bool stop_on_residual = params->tolerance > 0.0f;
     const int every = params->checkEvery > 0 ? params->checkEvery : 16;
@@ -317,18 +335,14 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     }
     const int result_plane = pk;
 
-    if (prof) RTDD_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (prof) RTDD_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
     rc = launch_finish(ctx, L, ip, result_plane, depth, depthPitch, rows, cols);
     if (rc != RTDD_OK) return rc;
     if (prof) {
-        RTDD_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-        RTDD_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
-        float a = 0, b = 0, c = 0;
-        RTDD_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-        RTDD_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
-        RTDD_HIP(ctx, hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]));
-        ctx->prof.prepare_ms = a; ctx->prof.sweep_ms = b; ctx->prof.finish_ms = c;
-        ctx->prof.launches = launches; ctx->prof.sweeps = done;
+        RTDD_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+        const int slot = ctx->prof_pending % rtdd_ctx::kProfSlots;
+        ctx->prof_launches[slot] = launches; ctx->prof_sweeps[slot] = done;
+        ctx->prof_pending++;                        // resolved (and synchronised) by rtdd_profile_get, not here
     }
     if (info) { info->iterations = done; info->residual = residual; }
     return RTDD_OK;

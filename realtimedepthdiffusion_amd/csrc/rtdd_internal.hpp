@@ -75,7 +75,11 @@ struct rtdd_ctx {
     rtdd::Options opt;
     bool profile_on = false;
     rtdd_profile prof{};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // profiling: 4 events per solve call, a ring of kProfSlots calls; resolved lazily by rtdd_profile_get (no sync per call)
+    static constexpr int kProfSlots = 64;
+    hipEvent_t ev[4 * kProfSlots] = {};
+    int prof_launches[kProfSlots] = {}, prof_sweeps[kProfSlots] = {};
+    int prof_pending = 0;           // calls recorded since the last rtdd_profile_get
     std::string last_error;
 };
 
