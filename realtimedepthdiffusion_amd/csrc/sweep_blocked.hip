@@ -97,7 +97,9 @@ __device__ __forceinline__ float relax(float xl, float xr, float xu, float xd, f
     } else {
         r = sum / cnt;
     }
-    r = fminf(fmaxf(r, 0.0f), 255.0f);         // :104
+    // :104  min(max(r,0),255).  v_med3_f32 returns min3 when an operand is NaN, i.e. 0 here -- the same as fmax/fmin --
+    // and, unlike fminf(fmaxf()), needs no canonicalising v_max in front of it (one VALU op per pixel less).
+    r = __builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
     // src/GPUSolver.cu:259
     if (CONTRACT) return __builtin_fmaf(omega, __builtin_fmaf(gamma, r - x, x) - prev, prev);
     return (omega * (gamma * (r - x) + x - prev)) + prev;
@@ -154,7 +156,9 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     const int y0 = blockIdx.y * TH - hy + tr * G;
     const bool colok = x0 >= 0 && x0 < cols;
 
-    float a[G][4], b[G][4];                    // a = x_k, b = x_{k-1}; roles alternate every sweep
+    // ext_vector_type keeps each 4-pixel group in 4 consecutive VGPRs, so the 16-byte LDS / global accesses need no moves
+    typedef float f4r __attribute__((ext_vector_type(4)));
+    f4r a[G], b[G];                            // a = x_k, b = x_{k-1}; roles alternate every sweep
     float wr[G][4], wd[G][4], wl0[G], wu0[4], cnt[G][4], rcp[G][4];
     bool unsafe = false;                       // some pixel of this lane has a denormal divisor
     uint32_t dirichlet = 0;                    // bit g*4+i
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
 
     RTDD_STAMP(1);
     // ---- n sweeps in registers -------------------------------------------------------------------
-    auto sweep = [&](float (&cur)[G][4], float (&oth)[G][4], int s, auto fast) {
+    auto sweep = [&](f4r (&cur)[G], f4r (&oth)[G], int s, auto fast) {
         constexpr bool FAST = decltype(fast)::value;
         const int buf = s & 1;
         // Vertical halo exchange.  A workgroup barrier here costs as much as the sweep's arithmetic (measured
@@ -224,8 +228,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
         // after it has consumed my sweep-s rows, and I overwrite that buffer (sweep s+2) only after waiting for
         // its sweep-s+1 rows.  All waves of a workgroup are co-resident, so the spin cannot deadlock.
         float4 up4 = make_float4(0, 0, 0, 0), dn4 = up4;
-        edge[buf][tr][0][lx] = make_float4(cur[0][0], cur[0][1], cur[0][2], cur[0][3]);
-        edge[buf][tr][1][lx] = make_float4(cur[G - 1][0], cur[G - 1][1], cur[G - 1][2], cur[G - 1][3]);
+        *(f4r *)&edge[buf][tr][0][lx] = cur[0];
+        *(f4r *)&edge[buf][tr][1][lx] = cur[G - 1];
         {
             const int wv = tid >> 6, nwv = (int)blockDim.x >> 6;
             __hip_atomic_store(&published[wv], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
