@@ -74,3 +74,13 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle", text, re.M), f
                 assert "liboracle" not in text and "orc_" not in text, f
+
+
+def test_header_is_plain_c99_and_a_c_program_links(so, tmp_path):
+    """include/rtdd.h must be usable from C (the reference's FFI surface is C-compatible): compile a C99 user with
+    -pedantic -Werror and link it against librtdd.so (it is RUN on the GPU box by tests/test_gpu_harness.py)."""
+    src = os.path.join(ROOT, "tests", "c_abi_smoke.c")
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe, src,
+                           "-L" + os.path.dirname(so), "-lrtdd", "-Wl,-rpath," + os.path.dirname(so)])
+    assert os.path.exists(exe)

@@ -49,3 +49,13 @@ def test_harness_batch_and_paint(tmp_path):
     assert "3 estimate(s) on 1 device(s)" in out
     d = _read_pnm(tmp_path / "DepthMap.pgm")
     assert d[40, 40] == 0 and d[180, 200] == 254 and 0 < d[110, 120] < 254      # labels held, interior interpolated
+
+
+def test_plain_c_program_drives_an_estimate(tmp_path):
+    """tests/c_abi_smoke.c: C99, links only librtdd.so, runs a whole estimate through the C ABI."""
+    lib_dir = os.path.join(ROOT, "realtimedepthdiffusion_amd")
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-L" + lib_dir, "-lrtdd", "-Wl,-rpath," + lib_dir])
+    out = subprocess.check_output([exe], text=True)
+    assert "c_abi_smoke ok" in out, out
