@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--persistent", type=int, default=-1)
+    ap.add_argument("--method", default="jacobi", choices=["jacobi", "rbgs"], help="rbgs = the red-black Gauss-Seidel EXTENSION (not the headline)")
     args = ap.parse_args()
 
     import numpy as np
@@ -138,7 +139,10 @@ def main():
     depths = [rt.device_image(p["depth"], dev) for _ in range(args.steps + args.warmup)]
 
     def step(i):
-        ctx.GPUMatrixFreeSolver(depths[i], mask, gray, rows, cols, 0.4, iters, 1e-5, 0)
+        if args.method == "rbgs":
+            ctx.solve_ex(depths[i], mask, gray, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=iters, tolerance=0.0)
+        else:
+            ctx.GPUMatrixFreeSolver(depths[i], mask, gray, rows, cols, 0.4, iters, 1e-5, 0)
 
     from realtimedepthdiffusion_amd import shard
 
@@ -168,7 +172,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps "
-                               f"(BASELINE configs[1])" if args.workload == "1080p_jacobi1000" else args.workload,
+                               f"(BASELINE configs[1])" if args.workload == "1080p_jacobi1000" and args.method == "jacobi" else f"{args.workload} ({args.method})",
                    "images_per_step": world, "sweep_kernel": ctx.get_option(rt.OPT_SWEEP_KERNEL), "tile": ctx.get_option(rt.OPT_TILE), "temporal_depth": ctx.get_option(rt.OPT_TEMPORAL_DEPTH), "persistent": ctx.get_option(rt.OPT_PERSISTENT),
                    "sweeps_per_launch": sweeps_per_launch},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -179,14 +183,14 @@ def main():
     # (scripts/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), committed under profiles/.
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        if prof.get("workload") == args.workload and not (args.sweep_kernel or args.tile or args.temporal_depth):
+        if prof.get("workload") == args.workload and args.method == "jacobi" and not (args.sweep_kernel or args.tile or args.temporal_depth):
             for name, k in prof["kernels"].items():
                 if "k_sweep" in name:
                     out["roofline"]["traffic"] = k["hbm_bytes_per_launch_corrected"]
                     out["roofline"]["traffic_source"] = prof.get("source", "profiles/traffic_latest.json")
     except (OSError, ValueError, KeyError):
         pass
-    if rank == 0 and args.workload == "1080p_jacobi1000" and not args.no_estimate:
+    if rank == 0 and args.workload == "1080p_jacobi1000" and args.method == "jacobi" and not args.no_estimate:
         out["estimate"] = estimate_ms(rt, ctx, p, rows, cols, dev)      # second half of BASELINE's metric; outside the timed region
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rows, cols)

@@ -322,16 +322,17 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
         const int chunk = stop_on_residual ? every : (params->maxIterations > 0 ? params->maxIterations : 1);
         while (done < params->maxIterations) {
             int n = params->maxIterations - done < chunk ? params->maxIterations - done : chunk;
-            rc = launch_rbgs(ctx, L, ip, 0, rows, cols, n);
+            int ln = 2 * n;
+            if (ctx->opt.sweep_kernel == 1) rc = launch_rbgs(ctx, L, ip, pk, rows, cols, n);        // one launch per colour, in place
+            else rc = launch_rbgs_blocked(ctx, L, ip, rows, cols, n, &pk, &ln);                       // register-blocked, ping-pong planes
             if (rc != RTDD_OK) return rc;
-            done += n; launches += 2 * n;
+            done += n; launches += ln;
             if (stop_on_residual) {
-                rc = launch_residual(ctx, L, ip, 0, rows, cols, &residual);
+                rc = launch_residual(ctx, L, ip, pk, rows, cols, &residual);
                 if (rc != RTDD_OK) return rc;
                 if (residual <= params->tolerance) break;
             }
         }
-        pk = 0;
     }
     const int result_plane = pk;
 

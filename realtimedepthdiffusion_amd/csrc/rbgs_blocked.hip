@@ -1,0 +1,217 @@
+// rbgs_blocked.hip -- red-black Gauss-Seidel sweeps (EXTENSION: the reference has no such solver, SURVEY.md
+// section 0), built like the temporally blocked Jacobi kernel: a workgroup loads a tile + halo once, keeps values,
+// f32 weights and reciprocals in registers, runs n full sweeps (2n half-sweeps) and writes back what is still exact.
+//
+// One half-sweep updates the pixels of one colour in place from their four neighbours, all of the other colour:
+//     x_i <- clamp(sum_j w_ij x_j / sum_j w_ij, 0, 255)        (the reference's solveDiffusion, src/GPUSolver.cu:73-106,
+//                                                                without the Chebyshev extrapolation)
+// so inside a half-sweep the order does not matter and the result is bit-identical to oracle/rtdd_oracle.c's sweep.
+// With G (rows per thread) even and all tile offsets even, the colour of pixel (g, i) of a thread is the compile-time
+// constant (g + i) & 1, so each half-sweep is straight-line code over exactly half of the thread's pixels.
+// Every half-sweep invalidates one more ring of the halo: n sweeps need a halo of 2n pixels.
+// Vertical neighbours across threads go through LDS with the per-wave handshake of sweep_blocked.hip, horizontal ones
+// through DPP wave shifts; the divide is the exhaustively verified 3-op form with the same tiny-numerator fallback.
+#include <type_traits>
+
+#include "rtdd_internal.hpp"
+
+namespace rtdd {
+namespace {
+
+__device__ __forceinline__ float from_prev_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float from_next_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float div3(float n, float d, float y) {     // see sweep_blocked.hip: == RN(n/d) for normal d, n = 0 or |n| >= 2^-100
+    const float q0 = n * y;
+    const float r = __builtin_fmaf(-d, q0, n);
+    return __builtin_fmaf(r, y, q0);
+}
+
+template <bool CONTRACT, bool FAST>
+__device__ __forceinline__ float gs_value(float xl, float xr, float xu, float xd, float wl, float wr, float wu, float wd, float cnt, float rcp) {
+    float sum = 0.0f;
+    sum = CONTRACT ? __builtin_fmaf(wl, xl, sum) : sum + wl * xl;
+    sum = CONTRACT ? __builtin_fmaf(wr, xr, sum) : sum + wr * xr;
+    sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
+    sum = CONTRACT ? __builtin_fmaf(wd, xd, sum) : sum + wd * xd;
+    float r;
+    if (FAST) {
+        r = div3(sum, cnt, rcp);
+        const bool tiny = __builtin_fabsf(sum) < 0x1p-100f && sum != 0.0f;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0, 0)) r = tiny ? sum / cnt : r;
+    } else {
+        r = sum / cnt;
+    }
+    return __builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
+}
+
+}  // namespace
+
+template <int LX, int NT, int G, bool CONTRACT>
+__global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict__ X, float *__restrict__ Y, const uint32_t *__restrict__ M,
+                                                        const float *__restrict__ lut_g, int ip, int rows, int cols, int hx, int hy, int nsweeps) {
+    static_assert(G % 2 == 0, "the compile-time colour pattern needs an even number of rows per thread");
+    constexpr int EW = 4 * LX, NTR = NT / LX;
+    typedef float f4r __attribute__((ext_vector_type(4)));
+    __shared__ float lut[257];
+    __shared__ float4 edge[2][NTR][2][LX];
+    __shared__ int published[NT / 64];
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
+    if (tid < NT / 64) published[tid] = 0;
+    __syncthreads();
+
+    const int lx = tid % LX, tr = tid / LX;
+    const int ntr = (int)blockDim.x / LX, eh = ntr * G;
+    const int TW = EW - 2 * hx, TH = eh - 2 * hy;                  // hx multiple of 4, hy even, TH even: pixel (g,i) has colour (g+i)&1
+    const int x0 = blockIdx.x * TW - hx + 4 * lx;
+    const int y0 = blockIdx.y * TH - hy + tr * G;
+    const bool colok = x0 >= 0 && x0 < cols;
+
+    f4r a[G];
+    float wr[G][4], wd[G][4], wl0[G], wu0[4], cnt[G][4], rcp[G][4];
+    uint32_t dirichlet = 0;
+    bool unsafe = false;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int y = y0 + g;
+        const bool ok = colok && y >= 0 && y < rows;
+        float4 vx = make_float4(0, 0, 0, 0);
+        uint4 m = make_uint4(0, 0, 0, 0);
+        if (ok) { const size_t off = (size_t)y * ip + x0; vx = *(const float4 *)(X + off); m = *(const uint4 *)(M + off); }
+        const float xv[4] = {vx.x, vx.y, vx.z, vx.w};
+        const uint32_t mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool in = ok && x0 + i < cols;
+            a[g][i] = in ? xv[i] : 0.0f;
+            wr[g][i] = (in && x0 + i + 1 < cols) ? lut[mv[i] & 255] : 0.0f;
+            wd[g][i] = (in && y + 1 < rows) ? lut[(mv[i] >> 8) & 255] : 0.0f;
+            if (!in || (mv[i] & kMetaDirichlet)) dirichlet |= 1u << (g * 4 + i);      // padding is never updated either
+        }
+        const float w = from_prev_lane(wr[g][3]);
+        wl0[g] = (lx > 0 && x0 > 0) ? w : 0.0f;
+    }
+    {
+        const int y = y0 - 1;
+        uint4 m = make_uint4(0, 0, 0, 0);
+        const bool ok = colok && y >= 0 && y + 1 < rows;
+        if (ok) m = *(const uint4 *)(M + (size_t)y * ip + x0);
+        const uint32_t mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) wu0[i] = (ok && x0 + i < cols) ? lut[(mv[i] >> 8) & 255] : 0.0f;
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
+            const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
+            float c = 0.0f;
+            c += wl; c += wr[g][i]; c += wu; c += wd[g][i];
+            cnt[g][i] = c == 0.0f ? 1.0f : c;
+            rcp[g][i] = 1.0f / cnt[g][i];
+            unsafe |= cnt[g][i] < 0x1p-126f;
+        }
+    const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
+
+    auto half = [&](int colour, int h, auto fast) {                // h = running half-sweep index
+        constexpr bool FAST = decltype(fast)::value;
+        const int buf = h & 1;
+        float4 up4 = make_float4(0, 0, 0, 0), dn4 = up4;
+        *(f4r *)&edge[buf][tr][0][lx] = a[0];
+        *(f4r *)&edge[buf][tr][1][lx] = a[G - 1];
+        {
+            const int wv = tid >> 6, nwv = (int)blockDim.x >> 6;
+            __hip_atomic_store(&published[wv], h + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wv > 0)
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < h + 1) __builtin_amdgcn_s_sleep(1);
+            if (wv < nwv - 1)
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < h + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        if (tr > 0) up4 = edge[buf][tr - 1][1][lx];
+        if (tr < ntr - 1) dn4 = edge[buf][tr + 1][0][lx];
+        const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
+        float xl0[G], xr3[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) { xl0[g] = from_prev_lane(a[g][3]); xr3[g] = from_next_lane(a[g][0]); }   // all fetched BEFORE any in-place update
+        // colour is wave-uniform at run time but the PIXELS of a colour are a compile-time pattern: two instantiations
+        auto run = [&](auto col) {
+            constexpr int C = decltype(col)::value;
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (((g + i) & 1) != C) continue;
+                    const float xl = i == 0 ? xl0[g] : a[g][i - 1];
+                    const float xr = i == 3 ? xr3[g] : a[g][i + 1];
+                    const float xu = g == 0 ? up[i] : a[g - 1][i];
+                    const float xd = g == G - 1 ? dn[i] : a[g + 1][i];
+                    const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
+                    const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
+                    const float v = gs_value<CONTRACT, FAST>(xl, xr, xu, xd, wl, wr[g][i], wu, wd[g][i], cnt[g][i], rcp[g][i]);
+                    a[g][i] = (dirichlet >> (g * 4 + i)) & 1u ? a[g][i] : v;
+                }
+        };
+        if (colour == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+    };
+
+    // colour 0 of the oracle = (x + y) even.  Pixel (g, i) sits at (x0 + i, y0 + g) with x0 % 4 == 0 and y0 even, so its
+    // image colour is (g + i) & 1.  (y0 = by*TH - hy + tr*G: every term even.)
+    int h = 0;
+    for (int s = 0; s < nsweeps; s++) {
+        if (!wave_unsafe) { half(0, h, std::true_type{}); half(1, h + 1, std::true_type{}); }
+        else { half(0, h, std::false_type{}); half(1, h + 1, std::false_type{}); }
+        h += 2;
+    }
+
+    const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int y = y0 + g, ty = tr * G + g;
+        if (xin && ty >= hy && ty < eh - hy && y < rows) *(f4r *)(Y + (size_t)y * ip + x0) = a[g];
+    }
+}
+
+// n full sweeps from plane *plane; on return *plane names the plane holding the result.
+int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, int *plane, int *launches) {
+    // two shapes: 128x64 (512 threads, 16 px/thread, two workgroups per CU) and, for images that fit it, ONE 128x128 tile
+    const bool single = cols <= 128 && rows <= 128;
+    const int EW = 128, EH = single ? 128 : 64;
+    int done = 0;
+    *launches = 0;
+    while (done < n) {
+        const int m = single ? n - done : (n - done < 4 ? n - done : 4);   // 4 sweeps = 8 half-sweeps = an 8-pixel halo
+        const int hy = single ? 0 : 2 * m, hx = single ? 0 : (2 * m + 3) / 4 * 4;
+        int nthreads = single ? 1024 : 512;
+        if (single) { const int need = (rows + 3) / 4 * 32; nthreads = (need + 63) / 64 * 64; if (nthreads > 1024) nthreads = 1024; }
+        const int eh = nthreads / 32 * 4;
+        const int TW = EW - 2 * hx, TH = eh - 2 * hy;
+        (void)EH;
+        const dim3 grid((cols + TW - 1) / TW, (rows + TH - 1) / TH);
+        int out = -1;
+        for (int i = 0; i < 4; i++) if (i != *plane) { out = i; break; }
+        const float *X = L.P(*plane, ip);
+        float *Y = L.P(out, ip);
+        if (single) {
+            if (ctx->opt.fp_contract) hipLaunchKernelGGL((k_rbgs_blocked<32, 1024, 4, true>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m);
+            else hipLaunchKernelGGL((k_rbgs_blocked<32, 1024, 4, false>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m);
+        } else {
+            if (ctx->opt.fp_contract) hipLaunchKernelGGL((k_rbgs_blocked<32, 512, 4, true>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m);
+            else hipLaunchKernelGGL((k_rbgs_blocked<32, 512, 4, false>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m);
+        }
+        // pixels outside the written-back centre keep stale values in the output plane only where no tile writes them:
+        // every image pixel belongs to exactly one tile's centre, so the output plane is complete.
+        *plane = out;
+        done += m;
+        (*launches)++;
+    }
+    RTDD_LAUNCH_CHECK(ctx, "k_rbgs_blocked");
+    return RTDD_OK;
+}
+
+}  // namespace rtdd

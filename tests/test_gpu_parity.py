@@ -200,6 +200,31 @@ def test_residual_stop_and_rbgs_extensions(ctx, oracle, lut):
     assert oracle.residual(down(d), idx, p["mask"], lut, 1) <= 1e-4
 
 
+@pytest.mark.parametrize("rows,cols,sweeps", [(64, 128, 7), (128, 128, 9), (129, 128, 5), (96, 131, 6), (240, 333, 11),
+                                             (547, 1021, 13), (1080, 1920, 8), (50, 77, 3), (1, 300, 4), (300, 1, 4), (2, 2, 5)])
+@pytest.mark.parametrize("contract", [1, 0])
+def test_rbgs_blocked_bit_exact(ctx, oracle, lut, rows, cols, sweeps, contract):
+    """Register-blocked red-black Gauss-Seidel (csrc/rbgs_blocked.hip; an EXTENSION, north_star config 3) == the
+    oracle's in-place sweep, bit for bit: single-tile and multi-tile shapes, sweep counts that are not multiples of the
+    4 sweeps one launch carries, ragged edges, and the one-launch-per-colour fallback kernel beside it."""
+    p = make_problem(rows, cols, seed=rows * 7 + cols)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    ctx.set_option(rt.OPT_FP_CONTRACT, contract)
+    idx = oracle.index_to_weight(p["gray"], None, 0, 0)
+    x = p["depth"].copy()
+    for _ in range(sweeps):
+        oracle.rbgs_sweep(x, idx, p["mask"], lut, contract)
+    m, g = up(p["mask"]), up(p["gray"])
+    for kernel in (0, 1):
+        ctx.set_option(rt.OPT_SWEEP_KERNEL, kernel)
+        d = up(p["depth"])
+        its, _ = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=sweeps, tolerance=0.0)
+        assert its == sweeps
+        assert_bit_equal(down(d), x, f"rbgs kernel {kernel} {rows}x{cols}x{sweeps}")
+    ctx.set_option(rt.OPT_SWEEP_KERNEL, 0)
+    ctx.set_option(rt.OPT_FP_CONTRACT, 1)
+
+
 def test_solver_zero_iterations_returns_input(ctx):
     p = make_problem(32, 48, seed=5)
     got = _solve_gpu(ctx, p, 0, 0, 1, 1)
