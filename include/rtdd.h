@@ -108,7 +108,14 @@ typedef struct rtdd_solve_params {
     int maxIterations;              /* upper bound on sweeps */
     float tolerance;                /* stop when max|J(x)-x| over free pixels <= tolerance; <= 0: never */
     int checkEvery;                 /* residual is evaluated every checkEvery sweeps (0 = 16) */
+    float relaxation;               /* RED_BLACK_GS only: SOR factor in (0,2), x <- clamp(x + relaxation (gs - x));
+                                     * 0 or 1 = plain Gauss-Seidel; RTDD_RELAXATION_AUTO = SOR cycles.  Cycle c (e = min(c,6)),
+                                     * with gap = max(0.005, (2 - min(1.99, 2/(1+sin(4 pi/N)))) / 2^e), N = max(rows,cols):
+                                     * N 2^e sweeps at omega = 2 - gap, a quarter as many at max(1, 2 - 10 gap), then <= 100
+                                     * plain sweeps with the residual checked every 20 (checkEvery is ignored); cycles repeat
+                                     * until tolerance or maxIterations */
 } rtdd_solve_params;
+#define RTDD_RELAXATION_AUTO (-1.0f)
 
 typedef struct rtdd_solve_info {
     int iterations;                 /* sweeps actually executed */

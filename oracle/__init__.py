@@ -166,10 +166,10 @@ def residual(x, idx, mask, lut, contract):
     return float(lib().orc_residual(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract)))
 
 
-def rbgs_sweep(x, idx, mask, lut, contract):
+def rbgs_sweep(x, idx, mask, lut, contract, omega=1.0):
     rows, cols = x.shape
     assert x.flags.c_contiguous and x.dtype == np.float32
-    lib().orc_rbgs_sweep(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract))
+    lib().orc_rbgs_sweep(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract), C.c_float(omega))
     return x
 
 

@@ -355,16 +355,22 @@ ORC_API float orc_residual(const float *in, const int32_t *index2, const uint8_t
 }
 
 /* One red-black Gauss-Seidel sweep (extension): colour 0 = (x+y) even first, then colour 1,
- * in place; x_i <- clamp(sum w x_j / sum w) for free pixels. */
+ * in place; gs_i = clamp(sum w x_j / sum w) for free pixels; x_i <- gs_i when omega == 1, else the
+ * SOR step x_i <- clamp(x_i + omega (gs_i - x_i)) (one fma under contraction). */
 ORC_API void orc_rbgs_sweep(float *x, const int32_t *index2, const uint8_t *mask, size_t maskPitch,
-                            int rows, int cols, const float *lut, int contract) {
+                            int rows, int cols, const float *lut, int contract, float omega) {
     for (int colour = 0; colour < 2; colour++)
         for (int y = 0; y < rows; y++)
             for (int xx = (y + colour) & 1; xx < cols; xx += 2) {
                 if (mask[(size_t)y * maskPitch + xx] == 255) continue;
                 size_t p = (size_t)y * cols + xx;
-                x[p] = mean4(index2[2 * p] / 1000, index2[2 * p] % 1000, index2[2 * p + 1] / 1000,
-                             index2[2 * p + 1] % 1000, lut, x, xx, y, cols, contract);
+                float v = mean4(index2[2 * p] / 1000, index2[2 * p] % 1000, index2[2 * p + 1] / 1000,
+                                index2[2 * p + 1] % 1000, lut, x, xx, y, cols, contract);
+                if (omega != 1.0f) {
+                    v = contract ? fmaf(omega, v - x[p], x[p]) : x[p] + omega * (v - x[p]);
+                    v = fminf(fmaxf(v, 0.0f), 255.0f);
+                }
+                x[p] = v;
             }
 }
 

@@ -22,6 +22,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 RTDD_OK = 0
 METHOD_CHEBYSHEV_JACOBI = 0
 METHOD_RED_BLACK_GS = 1
+RELAXATION_AUTO = -1.0                     # rtdd_solve_params.relaxation: SOR cycles (include/rtdd.h)
 OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, _OPT_RESERVED_3, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/rtdd.h declares (checked by tests/test_abi.py against the header)
@@ -52,7 +53,7 @@ class RtddError(RuntimeError):
 
 
 class SolveParams(C.Structure):
-    _fields_ = [("method", C.c_int), ("maxIterations", C.c_int), ("tolerance", C.c_float), ("checkEvery", C.c_int)]
+    _fields_ = [("method", C.c_int), ("maxIterations", C.c_int), ("tolerance", C.c_float), ("checkEvery", C.c_int), ("relaxation", C.c_float)]
 
 
 class SolveInfo(C.Structure):
@@ -181,9 +182,9 @@ class Context:
                                                   C.c_float(beta), C.c_int(maxIterations), C.c_float(tolerance), C.c_int(level)))
 
     def solve_ex(self, depthImage, scribbleImage, grayImage, rows, cols, level, method=METHOD_CHEBYSHEV_JACOBI,
-                 maxIterations=1000, tolerance=0.0, checkEvery=0):
+                 maxIterations=1000, tolerance=0.0, checkEvery=0, relaxation=0.0):
         dp, dpitch = _img(depthImage); sp, spitch = _img(scribbleImage); gp, gpitch = _img(grayImage)
-        params = SolveParams(method, maxIterations, tolerance, checkEvery)
+        params = SolveParams(method, maxIterations, tolerance, checkEvery, relaxation)
         info = SolveInfo()
         self._check(lib().rtdd_solve_ex(self._h, dp, dpitch, sp, spitch, gp, gpitch, C.c_int(rows), C.c_int(cols), C.c_int(level),
                                         C.byref(params), C.byref(info)))

@@ -275,6 +275,8 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     REQUIRE(ctx, params != nullptr, "null params");
     REQUIRE(ctx, params->maxIterations >= 0, "maxIterations must be >= 0");
     REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS, "unknown method");
+    REQUIRE(ctx, params->method != RTDD_METHOD_RED_BLACK_GS || params->relaxation == RTDD_RELAXATION_AUTO || (params->relaxation >= 0.0f && params->relaxation < 2.0f),
+            "relaxation must be in [0,2) or RTDD_RELAXATION_AUTO");
     int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
     if (rc != RTDD_OK) return rc;
     DeviceGuard g(ctx->device);
@@ -319,18 +321,56 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
             }
         }
     } else {
-        const int chunk = stop_on_residual ? every : (params->maxIterations > 0 ? params->maxIterations : 1);
-        while (done < params->maxIterations) {
-            int n = params->maxIterations - done < chunk ? params->maxIterations - done : chunk;
-            int ln = 2 * n;
-            if (ctx->opt.sweep_kernel == 1) rc = launch_rbgs(ctx, L, ip, pk, rows, cols, n);        // one launch per colour, in place
-            else rc = launch_rbgs_blocked(ctx, L, ip, rows, cols, n, &pk, &ln);                       // register-blocked, ping-pong planes
-            if (rc != RTDD_OK) return rc;
+        auto run = [&](int n, float omega) -> int {                                                   // n sweeps at one relaxation factor
+            if (n > params->maxIterations - done) n = params->maxIterations - done;
+            if (n <= 0) return RTDD_OK;
+            int ln = 2 * n, r;
+            if (ctx->opt.sweep_kernel == 1) r = launch_rbgs(ctx, L, ip, pk, rows, cols, n, omega);     // one launch per colour, in place
+            else r = launch_rbgs_blocked(ctx, L, ip, rows, cols, n, omega, &pk, &ln);                  // register-blocked, ping-pong planes
             done += n; launches += ln;
-            if (stop_on_residual) {
-                rc = launch_residual(ctx, L, ip, pk, rows, cols, &residual);
-                if (rc != RTDD_OK) return rc;
-                if (residual <= params->tolerance) break;
+            return r;
+        };
+        if (params->relaxation < 0.0f) {
+            // RTDD_RELAXATION_AUTO: SOR cycles.  Over-relaxation removes the smooth error a plain sweep hardly touches, but in
+            // f32 it idles at a residual ~ ulp(x)/(2 - omega); plain Gauss-Seidel has an exact f32 fixed point but is slow on
+            // smooth error.  So: n_hi sweeps at omega_hi, n_hi/4 at omega_mid, then a Gauss-Seidel polish of at most 100
+            // sweeps with the residual checked every 20; repeat (longer, closer to 2) until the tolerance or maxIterations
+            // (DESIGN.md section 7).
+            const int longest = rows > cols ? rows : cols;
+            double w0 = 2.0 / (1.0 + sin(4.0 * 3.14159265358979323846 / (double)longest));
+            if (w0 > 1.99) w0 = 1.99;
+            if (w0 < 1.0) w0 = 1.0;
+            bool reached = false;
+            for (int cycle = 0; done < params->maxIterations && !reached; cycle++) {
+                // a cycle that does not get there is followed by one twice as long and twice as close to omega = 2
+                const int e = cycle < 6 ? cycle : 6;
+                double gap = (2.0 - w0) / (double)(1 << e);
+                if (gap < 0.005) gap = 0.005;
+                const float w_hi = (float)(2.0 - gap);
+                float w_mid = (float)(2.0 - 10.0 * gap);
+                if (w_mid < 1.0f) w_mid = 1.0f;
+                const int n_hi = longest << e;
+                if ((rc = run(n_hi, w_hi)) != RTDD_OK) return rc;
+                if ((rc = run(n_hi / 4, w_mid)) != RTDD_OK) return rc;
+                for (int k = 0; k < 5 && done < params->maxIterations && !reached; k++) {
+                    if ((rc = run(20, 1.0f)) != RTDD_OK) return rc;
+                    if (stop_on_residual) {
+                        rc = launch_residual(ctx, L, ip, pk, rows, cols, &residual);
+                        if (rc != RTDD_OK) return rc;
+                        reached = residual <= params->tolerance;
+                    }
+                }
+            }
+        } else {
+            const int chunk = stop_on_residual ? every : (params->maxIterations > 0 ? params->maxIterations : 1);
+            const float omega = params->relaxation == 0.0f ? 1.0f : params->relaxation;
+            while (done < params->maxIterations) {
+                if ((rc = run(chunk, omega)) != RTDD_OK) return rc;
+                if (stop_on_residual) {
+                    rc = launch_residual(ctx, L, ip, pk, rows, cols, &residual);
+                    if (rc != RTDD_OK) return rc;
+                    if (residual <= params->tolerance) break;
+                }
             }
         }
     }
@@ -356,7 +396,7 @@ int rtdd_matrix_free_solver(rtdd_ctx *ctx, float *depth, size_t depthPitch, cons
     if (!ctx) return RTDD_ERR_INVALID;
     if (maxIterations < 0) maxIterations = 0;      // the reference's loop simply does not run (:295)
     rtdd_solve_params p;
-    p.method = RTDD_METHOD_CHEBYSHEV_JACOBI; p.maxIterations = maxIterations; p.tolerance = 0.0f; p.checkEvery = 0;
+    p.method = RTDD_METHOD_CHEBYSHEV_JACOBI; p.maxIterations = maxIterations; p.tolerance = 0.0f; p.checkEvery = 0; p.relaxation = 0.0f;
     return rtdd_solve_ex(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, &p, nullptr);
 }
 

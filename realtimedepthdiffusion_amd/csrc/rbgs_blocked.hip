@@ -30,8 +30,9 @@ __device__ __forceinline__ float div3(float n, float d, float y) {     // see sw
     return __builtin_fmaf(r, y, q0);
 }
 
-template <bool CONTRACT, bool FAST>
-__device__ __forceinline__ float gs_value(float xl, float xr, float xu, float xd, float wl, float wr, float wu, float wd, float cnt, float rcp) {
+// SOR: successive over-relaxation, x <- clamp(x + omega (clamp(gs) - x)); omega = 1 is plain Gauss-Seidel and takes the !SOR path.
+template <bool CONTRACT, bool FAST, bool SOR>
+__device__ __forceinline__ float gs_value(float x, float omega, float xl, float xr, float xu, float xd, float wl, float wr, float wu, float wd, float cnt, float rcp) {
     float sum = 0.0f;
     sum = CONTRACT ? __builtin_fmaf(wl, xl, sum) : sum + wl * xl;
     sum = CONTRACT ? __builtin_fmaf(wr, xr, sum) : sum + wr * xr;
@@ -45,14 +46,16 @@ __device__ __forceinline__ float gs_value(float xl, float xr, float xu, float xd
     } else {
         r = sum / cnt;
     }
-    return __builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
+    r = __builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
+    if (SOR) { r = CONTRACT ? __builtin_fmaf(omega, r - x, x) : x + omega * (r - x); r = __builtin_amdgcn_fmed3f(r, 0.0f, 255.0f); }
+    return r;
 }
 
 }  // namespace
 
-template <int LX, int NT, int G, bool CONTRACT>
+template <int LX, int NT, int G, bool CONTRACT, bool SOR>
 __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict__ X, float *__restrict__ Y, const uint32_t *__restrict__ M,
-                                                        const float *__restrict__ lut_g, int ip, int rows, int cols, int hx, int hy, int nsweeps) {
+                                                        const float *__restrict__ lut_g, int ip, int rows, int cols, int hx, int hy, int nsweeps, float omega) {
     static_assert(G % 2 == 0, "the compile-time colour pattern needs an even number of rows per thread");
     constexpr int EW = 4 * LX, NTR = NT / LX;
     typedef float f4r __attribute__((ext_vector_type(4)));
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict_
                     const float xd = g == G - 1 ? dn[i] : a[g + 1][i];
                     const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
                     const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
-                    const float v = gs_value<CONTRACT, FAST>(xl, xr, xu, xd, wl, wr[g][i], wu, wd[g][i], cnt[g][i], rcp[g][i]);
+                    const float v = gs_value<CONTRACT, FAST, SOR>(a[g][i], omega, xl, xr, xu, xd, wl, wr[g][i], wu, wd[g][i], cnt[g][i], rcp[g][i]);
                     a[g][i] = (dirichlet >> (g * 4 + i)) & 1u ? a[g][i] : v;
                 }
         };
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict_
 }
 
 // n full sweeps from plane *plane; on return *plane names the plane holding the result.
-int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, int *plane, int *launches) {
+int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, float omega, int *plane, int *launches) {
     // two shapes: 128x64 (512 threads, 16 px/thread, two workgroups per CU) and, for images that fit it, ONE 128x128 tile
     const bool single = cols <= 128 && rows <= 128;
     const int EW = 128, EH = single ? 128 : 64;
@@ -197,13 +200,20 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
         for (int i = 0; i < 4; i++) if (i != *plane) { out = i; break; }
         const float *X = L.P(*plane, ip);
         float *Y = L.P(out, ip);
-        if (single) {
-            if (ctx->opt.fp_contract) hipLaunchKernelGGL((k_rbgs_blocked<32, 1024, 4, true>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m);
-            else hipLaunchKernelGGL((k_rbgs_blocked<32, 1024, 4, false>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m);
-        } else {
-            if (ctx->opt.fp_contract) hipLaunchKernelGGL((k_rbgs_blocked<32, 512, 4, true>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m);
-            else hipLaunchKernelGGL((k_rbgs_blocked<32, 512, 4, false>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m);
+        const bool sor = omega != 1.0f;
+#define RTDD_RBGS_GO(NT_, C_, S_) hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega)
+        const int variant = (single ? 4 : 0) | (ctx->opt.fp_contract ? 2 : 0) | (sor ? 1 : 0);
+        switch (variant) {
+            case 0: RTDD_RBGS_GO(512, false, false); break;
+            case 1: RTDD_RBGS_GO(512, false, true); break;
+            case 2: RTDD_RBGS_GO(512, true, false); break;
+            case 3: RTDD_RBGS_GO(512, true, true); break;
+            case 4: RTDD_RBGS_GO(1024, false, false); break;
+            case 5: RTDD_RBGS_GO(1024, false, true); break;
+            case 6: RTDD_RBGS_GO(1024, true, false); break;
+            default: RTDD_RBGS_GO(1024, true, true); break;
         }
+#undef RTDD_RBGS_GO
         // pixels outside the written-back centre keep stale values in the output plane only where no tile writes them:
         // every image pixel belongs to exactly one tile's centre, so the output plane is complete.
         *plane = out;

@@ -126,8 +126,8 @@ int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float
 int launch_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch, const float *depth, size_t depthPitch,
                            int32_t *index2, int level, int rows, int cols);
 int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, float *host_out);
-int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps);
-int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, int *plane, int *launches);
+int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps, float omega);
+int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, float omega, int *plane, int *launches);
 
 // ---- image_kernels.hip --------------------------------------------------------------------------
 int launch_convert(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, float *dst, size_t dstPitch,

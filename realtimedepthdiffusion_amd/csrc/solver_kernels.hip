@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ X, c
 
 template <bool CONTRACT>
 __global__ __launch_bounds__(256) void k_rbgs_half(float *__restrict__ X, const uint32_t *__restrict__ M,
-                                                   const float *__restrict__ lut_g, int ip, int rows, int cols, int colour) {
+                                                   const float *__restrict__ lut_g, int ip, int rows, int cols, int colour, float omega) {
     __shared__ float lut[257];
     for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
     __syncthreads();
@@ -258,7 +258,13 @@ __global__ __launch_bounds__(256) void k_rbgs_half(float *__restrict__ X, const 
     if (x >= cols || y >= rows) return;
     const uint32_t m = M[(size_t)y * ip + x];
     if (m & kMetaDirichlet) return;
-    X[(size_t)y * ip + x] = mean_at<CONTRACT>(X, M, lut, ip, rows, cols, x, y, m);
+    float v = mean_at<CONTRACT>(X, M, lut, ip, rows, cols, x, y, m);
+    if (omega != 1.0f) {                                       // SOR extension: x <- clamp(x + omega (gs - x))
+        const float x0 = X[(size_t)y * ip + x];
+        v = CONTRACT ? __builtin_fmaf(omega, v - x0, x0) : x0 + omega * (v - x0);
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+    }
+    X[(size_t)y * ip + x] = v;
 }
 
 // ================================================================================================
@@ -340,14 +346,14 @@ int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int row
     return RTDD_OK;
 }
 
-int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps) {
+int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps, float omega) {
     const dim3 grid(((cols + 1) / 2 + 63) / 64, (rows + 3) / 4);
     for (int s = 0; s < nsweeps; s++)
         for (int colour = 0; colour < 2; colour++) {
             if (ctx->opt.fp_contract)
-                hipLaunchKernelGGL(k_rbgs_half<true>, grid, dim3(256), 0, ctx->stream, L.P(plane, ip), L.M(ip), ctx->lut_dev, (int)ip, rows, cols, colour);
+                hipLaunchKernelGGL(k_rbgs_half<true>, grid, dim3(256), 0, ctx->stream, L.P(plane, ip), L.M(ip), ctx->lut_dev, (int)ip, rows, cols, colour, omega);
             else
-                hipLaunchKernelGGL(k_rbgs_half<false>, grid, dim3(256), 0, ctx->stream, L.P(plane, ip), L.M(ip), ctx->lut_dev, (int)ip, rows, cols, colour);
+                hipLaunchKernelGGL(k_rbgs_half<false>, grid, dim3(256), 0, ctx->stream, L.P(plane, ip), L.M(ip), ctx->lut_dev, (int)ip, rows, cols, colour, omega);
         }
     RTDD_LAUNCH_CHECK(ctx, "k_rbgs_half");
     return RTDD_OK;

@@ -202,8 +202,8 @@ def test_residual_stop_and_rbgs_extensions(ctx, oracle, lut):
 
 @pytest.mark.parametrize("rows,cols,sweeps", [(64, 128, 7), (128, 128, 9), (129, 128, 5), (96, 131, 6), (240, 333, 11),
                                              (547, 1021, 13), (1080, 1920, 8), (50, 77, 3), (1, 300, 4), (300, 1, 4), (2, 2, 5)])
-@pytest.mark.parametrize("contract", [1, 0])
-def test_rbgs_blocked_bit_exact(ctx, oracle, lut, rows, cols, sweeps, contract):
+@pytest.mark.parametrize("contract,omega", [(1, 1.0), (0, 1.0), (1, 1.7), (0, 1.93)])
+def test_rbgs_blocked_bit_exact(ctx, oracle, lut, rows, cols, sweeps, contract, omega):
     """Register-blocked red-black Gauss-Seidel (csrc/rbgs_blocked.hip; an EXTENSION, north_star config 3) == the
     oracle's in-place sweep, bit for bit: single-tile and multi-tile shapes, sweep counts that are not multiples of the
     4 sweeps one launch carries, ragged edges, and the one-launch-per-colour fallback kernel beside it."""
@@ -213,16 +213,68 @@ def test_rbgs_blocked_bit_exact(ctx, oracle, lut, rows, cols, sweeps, contract):
     idx = oracle.index_to_weight(p["gray"], None, 0, 0)
     x = p["depth"].copy()
     for _ in range(sweeps):
-        oracle.rbgs_sweep(x, idx, p["mask"], lut, contract)
+        oracle.rbgs_sweep(x, idx, p["mask"], lut, contract, omega)      # omega != 1: the SOR step
     m, g = up(p["mask"]), up(p["gray"])
     for kernel in (0, 1):
         ctx.set_option(rt.OPT_SWEEP_KERNEL, kernel)
         d = up(p["depth"])
-        its, _ = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=sweeps, tolerance=0.0)
+        its, _ = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=sweeps, tolerance=0.0, relaxation=omega)
         assert its == sweeps
-        assert_bit_equal(down(d), x, f"rbgs kernel {kernel} {rows}x{cols}x{sweeps}")
+        assert_bit_equal(down(d), x, f"rbgs kernel {kernel} {rows}x{cols}x{sweeps} omega {omega}")
     ctx.set_option(rt.OPT_SWEEP_KERNEL, 0)
     ctx.set_option(rt.OPT_FP_CONTRACT, 1)
+
+
+def _sor_cycles_restated(oracle, x, idx, mask, lut, contract, tol, max_its):
+    """rtdd_solve_ex's RTDD_RELAXATION_AUTO schedule (include/rtdd.h, csrc/api.cpp) driven through the oracle's sweep and residual."""
+    import math
+    rows, cols = x.shape
+    longest = max(rows, cols)
+    w0 = min(1.99, max(1.0, 2.0 / (1.0 + math.sin(4.0 * math.pi / longest))))
+    done, res = 0, float("nan")
+
+    def run(n, om):
+        nonlocal done
+        n = min(n, max_its - done)
+        for _ in range(n):
+            oracle.rbgs_sweep(x, idx, mask, lut, contract, float(om))
+        done += n
+    reached, cycle = False, 0
+    while done < max_its and not reached:
+        e = min(cycle, 6)
+        gap = max(0.005, (2.0 - w0) / (1 << e))
+        w_hi, w_mid = np.float32(2.0 - gap), max(np.float32(1.0), np.float32(2.0 - 10.0 * gap))
+        run(longest << e, w_hi); run((longest << e) // 4, w_mid)
+        for _ in range(5):
+            if done >= max_its or reached:
+                break
+            run(20, 1.0)
+            res = oracle.residual(x, idx, mask, lut, contract)
+            reached = res <= tol
+        cycle += 1
+    return done, res
+
+
+@pytest.mark.parametrize("rows,cols,seed", [(96, 128, 12), (200, 150, 3)])
+def test_sor_cycles_reach_the_residual_and_match_the_restated_schedule(ctx, oracle, lut, rows, cols, seed):
+    """BASELINE config 3 in the small: red-black SOR cycles + Gauss-Seidel polish to a 1e-4 residual (an EXTENSION).  Same
+    sweep count, same reported residual and bit-identical depth as the schedule restated over the oracle; the oracle's
+    residual of the GPU result is under the tolerance; plain Gauss-Seidel needs far more sweeps for the same residual."""
+    p = make_problem(rows, cols, seed=seed)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    ctx.set_option(rt.OPT_FP_CONTRACT, 1)
+    idx = oracle.index_to_weight(p["gray"], None, 0, 0)
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=20000, tolerance=1e-4, relaxation=rt.RELAXATION_AUTO)
+    got = down(d)
+    x = p["depth"].copy()
+    want_its, want_res = _sor_cycles_restated(oracle, x, idx, p["mask"], lut, 1, 1e-4, 20000)
+    assert (its, res) == (want_its, np.float32(want_res)) and res <= 1e-4
+    assert_bit_equal(got, x, "SOR cycles")
+    assert oracle.residual(got, idx, p["mask"], lut, 1) <= 1e-4
+    d = up(p["depth"])
+    its_gs, res_gs = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=its, tolerance=1e-4, checkEvery=its)
+    assert res_gs > 1e-4, "plain Gauss-Seidel should not get there in the same number of sweeps"
 
 
 def test_solver_zero_iterations_returns_input(ctx):
