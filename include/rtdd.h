@@ -48,7 +48,9 @@ enum rtdd_status {
  *  and are opt-in through rtdd_solve_ex(). */
 enum rtdd_method {
     RTDD_METHOD_CHEBYSHEV_JACOBI = 0,
-    RTDD_METHOD_RED_BLACK_GS = 1
+    RTDD_METHOD_RED_BLACK_GS = 1,
+    RTDD_METHOD_MULTIGRID = 2        /* V(2,2) cycles, operator-dependent interpolation; maxIterations counts CYCLES,
+                                      * checkEvery defaults to 1 cycle */
 };
 
 /* Tunables, rtdd_set_option(ctx, key, value). */
@@ -127,6 +129,11 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch,
                   const uint8_t *gray, size_t grayPitch,
                   int rows, int cols, int level,
                   const rtdd_solve_params *params, rtdd_solve_info *info);
+
+/* Diagnostic for the parity tests: after a RTDD_METHOD_MULTIGRID solve, copy plane `which` (0-4: couplings E,S,SE,SW and
+ * diagonal D; 5-8: interpolation weights; 9-11: e, b, r) of hierarchy level `level` to host memory, dense rows x cols
+ * floats.  host == NULL only reports the size.  Synchronises. */
+int rtdd_multigrid_level(rtdd_ctx *ctx, int level, int which, float *host, int *rows, int *cols);
 
 /* The edge-weight index pass on its own (loadIndexToWeight, src/GPUSolver.cu:136-224), exposed
  * for parity tests: writes the reference's int2 {left*1000+right, up*1000+down} per pixel,

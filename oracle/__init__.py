@@ -173,6 +173,26 @@ def rbgs_sweep(x, idx, mask, lut, contract, omega=1.0):
     return x
 
 
+def mg_solve(x, idx, mask, lut, contract, max_cycles, tolerance=0.0, check_every=1):
+    """Multigrid V-cycles (extension; rtdd_mg_oracle.c) in place on x.  Returns (cycles, residual, levels)."""
+    rows, cols = x.shape
+    assert x.flags.c_contiguous and x.dtype == np.float32
+    cyc = C.c_int(0); res = C.c_float(0)
+    nlev = lib().orc_mg_solve(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract),
+                              C.c_int(max_cycles), C.c_float(tolerance), C.c_int(check_every), C.byref(cyc), C.byref(res))
+    return cyc.value, res.value, nlev
+
+
+def mg_level(level, which):
+    """Plane `which` (0-4 E,S,SE,SW,D; 5-8 P; 9-11 e,b,r) of level `level` of the last hierarchy mg_solve built."""
+    r = C.c_int(0); c = C.c_int(0)
+    if lib().orc_mg_level(C.c_int(level), C.c_int(which), None, C.byref(r), C.byref(c)) != 0:
+        raise IndexError((level, which))
+    out = np.zeros((r.value, c.value), np.float32)
+    lib().orc_mg_level(C.c_int(level), C.c_int(which), _p(out), C.byref(r), C.byref(c))
+    return out
+
+
 # ---- third-party (OpenCV) restatements used by the cascade harness --------------------------
 def bgr2gray(bgr):
     rows, cols = bgr.shape[:2]

@@ -22,6 +22,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 RTDD_OK = 0
 METHOD_CHEBYSHEV_JACOBI = 0
 METHOD_RED_BLACK_GS = 1
+METHOD_MULTIGRID = 2
 RELAXATION_AUTO = -1.0                     # rtdd_solve_params.relaxation: SOR cycles (include/rtdd.h)
 OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, _OPT_RESERVED_3, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
 
@@ -29,7 +30,7 @@ OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, _OPT_RESERVED_3, OPT_ROWS
 C_ABI_SYMBOLS = [
     "rtdd_ctx_create", "rtdd_ctx_destroy", "rtdd_ctx_set_stream", "rtdd_ctx_synchronize", "rtdd_set_option",
     "rtdd_get_option", "rtdd_last_error", "rtdd_status_string", "rtdd_version", "rtdd_allocate", "rtdd_free",
-    "rtdd_load_weights", "rtdd_matrix_free_solver", "rtdd_solve_ex", "rtdd_index_to_weight", "rtdd_convert_to_float",
+    "rtdd_load_weights", "rtdd_matrix_free_solver", "rtdd_solve_ex", "rtdd_multigrid_level", "rtdd_index_to_weight", "rtdd_convert_to_float",
     "rtdd_pyrdown_annotation", "rtdd_paint_image", "rtdd_simulate_defocus", "rtdd_simulate_desaturation",
     "rtdd_simulate_haze", "rtdd_profile_enable", "rtdd_profile_get",
     "rtdd_pyramid_levels", "rtdd_pyramid_create", "rtdd_pyramid_destroy", "rtdd_pyramid_set_image",
@@ -189,6 +190,15 @@ class Context:
         self._check(lib().rtdd_solve_ex(self._h, dp, dpitch, sp, spitch, gp, gpitch, C.c_int(rows), C.c_int(cols), C.c_int(level),
                                         C.byref(params), C.byref(info)))
         return info.iterations, info.residual
+
+    def multigrid_level(self, level, which):
+        """Diagnostic: plane `which` of hierarchy level `level` after a METHOD_MULTIGRID solve, as a numpy array."""
+        import numpy as np
+        r = C.c_int(0); c = C.c_int(0)
+        self._check(lib().rtdd_multigrid_level(self._h, C.c_int(level), C.c_int(which), None, C.byref(r), C.byref(c)))
+        out = np.zeros((r.value, c.value), np.float32)
+        self._check(lib().rtdd_multigrid_level(self._h, C.c_int(level), C.c_int(which), out.ctypes.data_as(C.c_void_p), C.byref(r), C.byref(c)))
+        return out
 
     def index_to_weight(self, grayImage, depthImage, index2, level, rows, cols):
         gp, gpitch = _img(grayImage); dp, dpitch = _img(depthImage)

@@ -97,6 +97,7 @@ int rtdd_ctx_destroy(rtdd_ctx *ctx) {
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     pyramid_free(ctx);
+    mg_release(ctx);
     free_levels(ctx);
     if (ctx->lut_dev) (void)hipFree(ctx->lut_dev);
     if (ctx->omega_dev) (void)hipFree(ctx->omega_dev);
@@ -224,6 +225,7 @@ int rtdd_free(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     DeviceGuard g(ctx->device);
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    mg_release(ctx);
     free_levels(ctx);
     return RTDD_OK;
 }
@@ -274,7 +276,7 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, params != nullptr, "null params");
     REQUIRE(ctx, params->maxIterations >= 0, "maxIterations must be >= 0");
-    REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS, "unknown method");
+    REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS || params->method == RTDD_METHOD_MULTIGRID, "unknown method");
     REQUIRE(ctx, params->method != RTDD_METHOD_RED_BLACK_GS || params->relaxation == RTDD_RELAXATION_AUTO || (params->relaxation >= 0.0f && params->relaxation < 2.0f),
             "relaxation must be in [0,2) or RTDD_RELAXATION_AUTO");
     int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
@@ -320,6 +322,10 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
                 if (residual <= params->tolerance) break;
             }
         }
+    } else if (params->method == RTDD_METHOD_MULTIGRID) {
+        rc = launch_multigrid(ctx, L, ip, rows, cols, params->maxIterations, params->tolerance, params->checkEvery > 0 ? params->checkEvery : 1,
+                              &pk, &done, &residual, &launches);
+        if (rc != RTDD_OK) return rc;
     } else {
         auto run = [&](int n, float omega) -> int {                                                   // n sweeps at one relaxation factor
             if (n > params->maxIterations - done) n = params->maxIterations - done;
@@ -387,6 +393,15 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     }
     if (info) { info->iterations = done; info->residual = residual; }
     return RTDD_OK;
+}
+
+int rtdd_multigrid_level(rtdd_ctx *ctx, int level, int which, float *host, int *rows, int *cols) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, rows && cols, "null size pointers");
+    DeviceGuard g(ctx->device);
+    const int rc = mg_download(ctx, level, which, host, rows, cols);
+    if (rc == RTDD_ERR_INVALID) return fail(ctx, rc, "no multigrid hierarchy, or level/plane out of range");
+    return rc;
 }
 
 int rtdd_matrix_free_solver(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,

@@ -1,0 +1,425 @@
+// multigrid.hip -- multigrid V-cycle for the depth-diffusion system (EXTENSION: the reference has no such solver;
+// BASELINE config 5).  Black-box multigrid in Dendy's sense: standard 2x coarsening (coarse point (I,J) = fine point
+// (2I,2J)), OPERATOR-DEPENDENT interpolation read off the stencil, Galerkin coarse operators (9-point from level 1 on).
+//
+// Level 0 is the image: unknown x on the free pixels, smoothed by the register-blocked red-black Gauss-Seidel kernel
+// (rbgs_blocked.hip) on the TRUE operator (LUT weights, Dirichlet values in place); its residual is formed from exact
+// differences, r_p = sum_q w_pq (x_q - x_p), so it carries no cancellation noise.  The hierarchy below it is built from
+// a copy of the level-0 operator in which links weaker than kTheta are kept on the diagonal only (an anchor to e = 0):
+// that bounds the condition of every coarse equation in f32 and changes the preconditioner, not the solution.
+// Levels >= 1 hold a symmetric 9-point stencil as four couplings per point (E, S, SE, SW: to the right / lower /
+// lower-right / lower-left neighbour; the other four are the neighbours' own) and the diagonal D; D == 0 marks an
+// inactive point (e = 0 for ever).  P holds, per fine point, its interpolation weights towards the four coarse points
+// at the corners of its coarse cell.  Coarse smoother: four-colour Gauss-Seidel (colour = (y&1)*2 + (x&1)).
+//
+// Every kernel is one thread per point with a fixed evaluation order and no atomics: oracle/rtdd_mg_oracle.c restates
+// the same arithmetic and the parity tests compare bit for bit.
+#include "rtdd_internal.hpp"
+
+namespace rtdd {
+
+constexpr float kTheta = 1e-4f;       // hierarchy only: weaker links become anchors
+constexpr int kNu = 2;                // pre- and post-smoothing sweeps on every level
+constexpr int kCoarsestSweeps = 30;
+constexpr int kSmallLevel = 16384;    // levels with at most this many points are smoothed by one workgroup in one launch
+
+struct MgLevel {
+    int rows = 0, cols = 0, pitch = 0;
+    float *buf = nullptr;             // 12 planes: E S SE SW D P0 P1 P2 P3 e b r
+    size_t plane = 0;
+    float *A(int i) const { return buf + (size_t)i * plane; }
+    float *E() const { return A(0); }
+    float *S() const { return A(1); }
+    float *SE() const { return A(2); }
+    float *SW() const { return A(3); }
+    float *D() const { return A(4); }
+    float *Pw(int k) const { return A(5 + k); }
+    float *e() const { return A(9); }
+    float *b() const { return A(10); }
+    float *r() const { return A(11); }
+};
+
+struct MgState {
+    int rows = 0, cols = 0;
+    std::vector<MgLevel> lv;
+    void release() {
+        for (auto &l : lv) if (l.buf) (void)hipFree(l.buf);
+        lv.clear(); rows = cols = 0;
+    }
+};
+
+struct Stencil {                      // device view of one level
+    const float *E, *S, *SE, *SW, *D;
+    int rows, cols, pitch;
+};
+
+namespace {
+
+__device__ __forceinline__ float at(const float *a, int pitch, int rows, int cols, int y, int x) {
+    return (y >= 0 && y < rows && x >= 0 && x < cols) ? a[(size_t)y * pitch + x] : 0.0f;
+}
+
+// coupling of point (y,x) towards (y+dy, x+dx), (dy,dx) != (0,0)
+__device__ __forceinline__ float coupling(const Stencil &s, int y, int x, int dy, int dx) {
+    if (dy == 0) return dx > 0 ? at(s.E, s.pitch, s.rows, s.cols, y, x) : at(s.E, s.pitch, s.rows, s.cols, y, x - 1);
+    if (dy > 0) {
+        if (dx == 0) return at(s.S, s.pitch, s.rows, s.cols, y, x);
+        return dx > 0 ? at(s.SE, s.pitch, s.rows, s.cols, y, x) : at(s.SW, s.pitch, s.rows, s.cols, y, x);
+    }
+    if (dx == 0) return at(s.S, s.pitch, s.rows, s.cols, y - 1, x);
+    return dx < 0 ? at(s.SE, s.pitch, s.rows, s.cols, y - 1, x - 1) : at(s.SW, s.pitch, s.rows, s.cols, y - 1, x + 1);
+}
+
+// level-0 hierarchy operator from the packed metadata
+__global__ __launch_bounds__(256) void k_mg_stencil0(const uint32_t *__restrict__ M, const float *__restrict__ lut_g, int ip, int rows, int cols,
+                                                     float *E, float *S, float *SE, float *SW, float *D, int pitch, float theta) {
+    __shared__ float lut[257];
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
+    __syncthreads();
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const size_t p = (size_t)y * ip + x;
+    const uint32_t m = M[p];
+    const bool fr = !(m & kMetaDirichlet);
+    const float wr = x + 1 < cols ? lut[m & 255] : 0.0f;
+    const float wd = y + 1 < rows ? lut[(m >> 8) & 255] : 0.0f;
+    const float wl = x > 0 ? lut[M[p - 1] & 255] : 0.0f;
+    const float wu = y > 0 ? lut[(M[p - ip] >> 8) & 255] : 0.0f;
+    float d = 0.0f;
+    d += wl; d += wr; d += wu; d += wd;
+    const bool rfree = x + 1 < cols && !(M[p + 1] & kMetaDirichlet);
+    const bool dfree = y + 1 < rows && !(M[p + ip] & kMetaDirichlet);
+    const size_t q = (size_t)y * pitch + x;
+    E[q] = (fr && rfree && wr >= theta) ? wr : 0.0f;
+    S[q] = (fr && dfree && wd >= theta) ? wd : 0.0f;
+    SE[q] = 0.0f; SW[q] = 0.0f;
+    D[q] = fr ? d : 0.0f;
+}
+
+// interpolation weights of coarse-coincident and edge points; cell centres in the second pass
+template <int PASS>
+__global__ __launch_bounds__(256) void k_mg_build_p(Stencil s, float *P0, float *P1, float *P2, float *P3) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= s.cols || y >= s.rows) return;
+    const size_t q = (size_t)y * s.pitch + x;
+    const float d = s.D[q];
+    const bool act = d > 0.0f;
+    const bool oy = y & 1, ox = x & 1;
+    if (PASS == 0) {
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
+        if (!oy && !ox) p0 = act ? 1.0f : 0.0f;
+        else if (!oy && ox) {                 // on a coarse row, between two coarse points: collapse the stencil vertically
+            const float den = (d - coupling(s, y, x, -1, 0)) - coupling(s, y, x, 1, 0);
+            if (act && den > 0.0f) {
+                p0 = ((coupling(s, y, x, 0, -1) + coupling(s, y, x, -1, -1)) + coupling(s, y, x, 1, -1)) / den;
+                p1 = ((coupling(s, y, x, 0, 1) + coupling(s, y, x, -1, 1)) + coupling(s, y, x, 1, 1)) / den;
+            }
+        } else if (oy && !ox) {               // on a coarse column: collapse horizontally
+            const float den = (d - coupling(s, y, x, 0, -1)) - coupling(s, y, x, 0, 1);
+            if (act && den > 0.0f) {
+                p0 = ((coupling(s, y, x, -1, 0) + coupling(s, y, x, -1, -1)) + coupling(s, y, x, -1, 1)) / den;
+                p2 = ((coupling(s, y, x, 1, 0) + coupling(s, y, x, 1, -1)) + coupling(s, y, x, 1, 1)) / den;
+            }
+        }
+        P0[q] = p0; P1[q] = p1; P2[q] = p2; P3[q] = 0.0f;
+    } else {
+        if (!(oy && ox) || !act) return;      // cell centre: its own equation with the edge neighbours replaced by their interpolants
+        const float wn = coupling(s, y, x, -1, 0), ws = coupling(s, y, x, 1, 0), ww = coupling(s, y, x, 0, -1), we = coupling(s, y, x, 0, 1);
+        const float n0 = at(P0, s.pitch, s.rows, s.cols, y - 1, x), n1 = at(P1, s.pitch, s.rows, s.cols, y - 1, x);
+        const float s0 = at(P0, s.pitch, s.rows, s.cols, y + 1, x), s1 = at(P1, s.pitch, s.rows, s.cols, y + 1, x);
+        const float w0 = at(P0, s.pitch, s.rows, s.cols, y, x - 1), w2 = at(P2, s.pitch, s.rows, s.cols, y, x - 1);
+        const float e0 = at(P0, s.pitch, s.rows, s.cols, y, x + 1), e2 = at(P2, s.pitch, s.rows, s.cols, y, x + 1);
+        P0[q] = ((coupling(s, y, x, -1, -1) + wn * n0) + ww * w0) / d;
+        P1[q] = ((coupling(s, y, x, -1, 1) + wn * n1) + we * e0) / d;
+        P2[q] = ((coupling(s, y, x, 1, -1) + ws * s0) + ww * w2) / d;
+        P3[q] = ((coupling(s, y, x, 1, 1) + ws * s1) + we * e2) / d;
+    }
+}
+
+struct Interp { const float *P0, *P1, *P2, *P3; };
+
+// weight of fine point (y,x) towards coarse point (I,J)
+__device__ __forceinline__ float pweight(const Interp &ip, int pitch, int rows, int cols, int y, int x, int I, int J) {
+    if (y < 0 || y >= rows || x < 0 || x >= cols) return 0.0f;
+    const int di = I - (y >> 1), dj = J - (x >> 1);
+    if (di < 0 || di > 1 || dj < 0 || dj > 1) return 0.0f;
+    const float *P = di ? (dj ? ip.P3 : ip.P2) : (dj ? ip.P1 : ip.P0);
+    return P[(size_t)y * pitch + x];
+}
+
+// Galerkin coarse operator A_c = P^T A P, one coarse point c = (I,J) per thread:
+//   A_c[c, c'] = sum_p sum_q P[p -> c] A[p, q] P[q -> c'],  p over the 3x3 support of c's basis function, q over p's stencil.
+// Each (p, q) pair feeds the up to four coarse points q interpolates from; with the loops unrolled every offset is a
+// compile-time constant.  For one target c' the terms arrive in (py, px, qy, qx) order -- the order of the restatement's
+// plain loops (terms with a zero weight add +-0 and change nothing).
+__global__ __launch_bounds__(256) void k_mg_galerkin(Stencil f, Interp ip, float *E, float *S, float *SE, float *SW, float *D, int crows, int ccols, int cpitch) {
+    const int J = blockIdx.x * 64 + (threadIdx.x & 63), I = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (J >= ccols || I >= crows) return;
+    float out[3][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};      // [dI + 1][dJ + 1]
+#pragma unroll
+    for (int py = -1; py <= 1; py++)
+#pragma unroll
+        for (int px = -1; px <= 1; px++) {
+            const int y = 2 * I + py, x = 2 * J + px;
+            const float wp = pweight(ip, f.pitch, f.rows, f.cols, y, x, I, J);
+            if (wp == 0.0f) continue;
+#pragma unroll
+            for (int qy = -1; qy <= 1; qy++)
+#pragma unroll
+                for (int qx = -1; qx <= 1; qx++) {
+                    const int v = y + qy, u = x + qx;
+                    if (v < 0 || v >= f.rows || u < 0 || u >= f.cols) continue;
+                    const float a = (qy == 0 && qx == 0) ? f.D[(size_t)y * f.pitch + x] : -coupling(f, y, x, qy, qx);
+                    const size_t qo = (size_t)v * f.pitch + u;
+                    // q = 2c + (py+qy, px+qx): its coarse cell starts at c + floor((py+qy)/2), floor((px+qx)/2)
+                    const int bi = (py + qy) >> 1, bj = (px + qx) >> 1;
+                    const float w4[4] = {ip.P0[qo], ip.P1[qo], ip.P2[qo], ip.P3[qo]};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int di = bi + (k >> 1), dj = bj + (k & 1);
+                        if (di < -1 || di > 1 || dj < -1 || dj > 1) continue;
+                        out[di + 1][dj + 1] += wp * (a * w4[k]);
+                    }
+                }
+        }
+    const size_t q = (size_t)I * cpitch + J;
+    const bool act = out[1][1] > 0.0f;
+    // targets outside the coarse grid received only zero weights: their sums are +0 and the stored couplings -0
+    D[q] = act ? out[1][1] : 0.0f;
+    E[q] = act ? -out[1][2] : 0.0f; S[q] = act ? -out[2][1] : 0.0f; SE[q] = act ? -out[2][2] : 0.0f; SW[q] = act ? -out[2][0] : 0.0f;
+}
+
+// a coupling towards an inactive point would read e = 0 for ever: harmless; but a coupling FROM an inactive point was
+// zeroed above while its mirror is read through the neighbour -- so zero the couplings that END at an inactive point too
+__global__ __launch_bounds__(256) void k_mg_prune(float *E, float *S, float *SE, float *SW, const float *D, int rows, int cols, int pitch) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const size_t q = (size_t)y * pitch + x;
+    if (!(at(D, pitch, rows, cols, y, x + 1) > 0.0f)) E[q] = 0.0f;
+    if (!(at(D, pitch, rows, cols, y + 1, x) > 0.0f)) S[q] = 0.0f;
+    if (!(at(D, pitch, rows, cols, y + 1, x + 1) > 0.0f)) SE[q] = 0.0f;
+    if (!(at(D, pitch, rows, cols, y + 1, x - 1) > 0.0f)) SW[q] = 0.0f;
+}
+
+// level-0 residual from exact differences, on the true operator
+__global__ __launch_bounds__(256) void k_mg_residual0(const float *__restrict__ X, const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
+                                                      int ip, int rows, int cols, float *R, int pitch) {
+    __shared__ float lut[257];
+    for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
+    __syncthreads();
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const size_t p = (size_t)y * ip + x;
+    const uint32_t m = M[p];
+    float r = 0.0f;
+    if (!(m & kMetaDirichlet)) {
+        const float xc = X[p];
+        if (x > 0) r += lut[M[p - 1] & 255] * (X[p - 1] - xc);
+        if (x + 1 < cols) r += lut[m & 255] * (X[p + 1] - xc);
+        if (y > 0) r += lut[(M[p - ip] >> 8) & 255] * (X[p - ip] - xc);
+        if (y + 1 < rows) r += lut[(m >> 8) & 255] * (X[p + ip] - xc);
+    }
+    R[(size_t)y * pitch + x] = r;
+}
+
+__device__ __forceinline__ float gs_sum(const Stencil &s, const float *e, const float *b, int y, int x) {
+    float v = b[(size_t)y * s.pitch + x];
+    v += coupling(s, y, x, 0, -1) * at(e, s.pitch, s.rows, s.cols, y, x - 1);
+    v += coupling(s, y, x, 0, 1) * at(e, s.pitch, s.rows, s.cols, y, x + 1);
+    v += coupling(s, y, x, -1, 0) * at(e, s.pitch, s.rows, s.cols, y - 1, x);
+    v += coupling(s, y, x, 1, 0) * at(e, s.pitch, s.rows, s.cols, y + 1, x);
+    v += coupling(s, y, x, -1, -1) * at(e, s.pitch, s.rows, s.cols, y - 1, x - 1);
+    v += coupling(s, y, x, -1, 1) * at(e, s.pitch, s.rows, s.cols, y - 1, x + 1);
+    v += coupling(s, y, x, 1, -1) * at(e, s.pitch, s.rows, s.cols, y + 1, x - 1);
+    v += coupling(s, y, x, 1, 1) * at(e, s.pitch, s.rows, s.cols, y + 1, x + 1);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_mg_residual(Stencil s, const float *e, const float *b, float *R) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= s.cols || y >= s.rows) return;
+    const size_t q = (size_t)y * s.pitch + x;
+    const float d = s.D[q];
+    R[q] = d > 0.0f ? gs_sum(s, e, b, y, x) - d * e[q] : 0.0f;
+}
+
+// one colour of the four-colour Gauss-Seidel sweep; the launch covers that colour's quarter grid
+__global__ __launch_bounds__(256) void k_mg_gs(Stencil s, float *e, const float *b, int colour) {
+    const int x = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)) + (colour & 1), y = 2 * (blockIdx.y * 4 + (threadIdx.x >> 6)) + (colour >> 1);
+    if (x >= s.cols || y >= s.rows) return;
+    const size_t q = (size_t)y * s.pitch + x;
+    const float d = s.D[q];
+    if (d > 0.0f) e[q] = gs_sum(s, e, b, y, x) / d;
+}
+
+// small levels: all sweeps of a smoothing step in one launch of one workgroup
+__global__ __launch_bounds__(1024) void k_mg_gs_small(Stencil s, float *e, const float *b, int nsweeps, int reverse) {
+    const int hr = (s.rows + 1) >> 1, hc = (s.cols + 1) >> 1;
+    for (int sw = 0; sw < nsweeps; sw++)
+        for (int c = 0; c < 4; c++) {
+            const int colour = reverse ? 3 - c : c;
+            for (int i = threadIdx.x; i < hr * hc; i += 1024) {
+                const int y = 2 * (i / hc) + (colour >> 1), x = 2 * (i % hc) + (colour & 1);
+                if (x < s.cols && y < s.rows) {
+                    const size_t q = (size_t)y * s.pitch + x;
+                    const float d = s.D[q];
+                    if (d > 0.0f) e[q] = gs_sum(s, e, b, y, x) / d;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// b_c = P^T r, and the coarse correction starts from zero
+__global__ __launch_bounds__(256) void k_mg_restrict(const float *R, Interp ip, int frows, int fcols, int fpitch, float *bc, float *ec, int crows, int ccols, int cpitch) {
+    const int J = blockIdx.x * 64 + (threadIdx.x & 63), I = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (J >= ccols || I >= crows) return;
+    float acc = 0.0f;
+    for (int py = -1; py <= 1; py++)
+        for (int px = -1; px <= 1; px++) {
+            const int y = 2 * I + py, x = 2 * J + px;
+            const float wp = pweight(ip, fpitch, frows, fcols, y, x, I, J);
+            if (wp != 0.0f) acc += wp * R[(size_t)y * fpitch + x];
+        }
+    bc[(size_t)I * cpitch + J] = acc;
+    ec[(size_t)I * cpitch + J] = 0.0f;
+}
+
+// target += P e_c
+__global__ __launch_bounds__(256) void k_mg_prolong(const float *ec, int crows, int ccols, int cpitch, Interp ip, int frows, int fcols, int fpitch, float *T, int tpitch) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= fcols || y >= frows) return;
+    const size_t q = (size_t)y * fpitch + x;
+    const int I = y >> 1, J = x >> 1;
+    float v = ip.P0[q] * at(ec, cpitch, crows, ccols, I, J);
+    v += ip.P1[q] * at(ec, cpitch, crows, ccols, I, J + 1);
+    v += ip.P2[q] * at(ec, cpitch, crows, ccols, I + 1, J);
+    v += ip.P3[q] * at(ec, cpitch, crows, ccols, I + 1, J + 1);
+    T[(size_t)y * tpitch + x] += v;
+}
+
+inline dim3 grid_for(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
+inline Stencil view(const MgLevel &l) { return Stencil{l.E(), l.S(), l.SE(), l.SW(), l.D(), l.rows, l.cols, l.pitch}; }
+inline Interp interp(const MgLevel &l) { return Interp{l.Pw(0), l.Pw(1), l.Pw(2), l.Pw(3)}; }
+
+}  // namespace
+
+void mg_release(rtdd_ctx *ctx) {
+    if (ctx->mg) { ctx->mg->release(); delete ctx->mg; ctx->mg = nullptr; }
+}
+
+static int mg_allocate(rtdd_ctx *ctx, int rows, int cols) {
+    if (ctx->mg && ctx->mg->rows == rows && ctx->mg->cols == cols) return RTDD_OK;
+    mg_release(ctx);
+    ctx->mg = new MgState();
+    ctx->mg->rows = rows; ctx->mg->cols = cols;
+    int r = rows, c = cols;
+    for (int l = 0; l < 16; l++) {
+        MgLevel L;
+        L.rows = r; L.cols = c; L.pitch = (c + 63) / 64 * 64;
+        L.plane = (size_t)L.pitch * r;
+        RTDD_HIP(ctx, hipMalloc((void **)&L.buf, 12 * L.plane * sizeof(float)));
+        ctx->mg->lv.push_back(L);
+        if ((size_t)r * c <= 256 || (r == 1 && c == 1)) break;
+        r = (r + 1) / 2; c = (c + 1) / 2;
+    }
+    return RTDD_OK;
+}
+
+// the hierarchy for the current level-0 metadata (prepare has run): operators and interpolation of every level
+static int mg_setup(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int *launches) {
+    int rc = mg_allocate(ctx, rows, cols);
+    if (rc != RTDD_OK) return rc;
+    auto &lv = ctx->mg->lv;
+    hipLaunchKernelGGL(k_mg_stencil0, grid_for(rows, cols), dim3(256), 0, ctx->stream, L0.M(ip), ctx->lut_dev, (int)ip, rows, cols,
+                       lv[0].E(), lv[0].S(), lv[0].SE(), lv[0].SW(), lv[0].D(), lv[0].pitch, kTheta);
+    (*launches)++;
+    for (size_t l = 0; l + 1 < lv.size(); l++) {
+        const MgLevel &f = lv[l], &c = lv[l + 1];
+        hipLaunchKernelGGL(k_mg_build_p<0>, grid_for(f.rows, f.cols), dim3(256), 0, ctx->stream, view(f), f.Pw(0), f.Pw(1), f.Pw(2), f.Pw(3));
+        hipLaunchKernelGGL(k_mg_build_p<1>, grid_for(f.rows, f.cols), dim3(256), 0, ctx->stream, view(f), f.Pw(0), f.Pw(1), f.Pw(2), f.Pw(3));
+        hipLaunchKernelGGL(k_mg_galerkin, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, view(f), interp(f), c.E(), c.S(), c.SE(), c.SW(), c.D(), c.rows, c.cols, c.pitch);
+        hipLaunchKernelGGL(k_mg_prune, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, c.E(), c.S(), c.SE(), c.SW(), c.D(), c.rows, c.cols, c.pitch);
+        *launches += 4;
+    }
+    RTDD_LAUNCH_CHECK(ctx, "multigrid setup");
+    return RTDD_OK;
+}
+
+static void mg_smooth(rtdd_ctx *ctx, const MgLevel &l, int nsweeps, bool reverse, int *launches) {
+    if ((size_t)l.rows * l.cols <= (size_t)kSmallLevel) {
+        hipLaunchKernelGGL(k_mg_gs_small, dim3(1), dim3(1024), 0, ctx->stream, view(l), l.e(), l.b(), nsweeps, reverse ? 1 : 0);
+        (*launches)++;
+        return;
+    }
+    const dim3 g(((l.cols + 1) / 2 + 63) / 64, ((l.rows + 1) / 2 + 3) / 4);
+    for (int s = 0; s < nsweeps; s++)
+        for (int c = 0; c < 4; c++) {
+            hipLaunchKernelGGL(k_mg_gs, g, dim3(256), 0, ctx->stream, view(l), l.e(), l.b(), reverse ? 3 - c : c);
+            (*launches)++;
+        }
+}
+
+// one V(kNu,kNu) cycle on the level-0 iterate in plane *plane
+static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int *plane, int *launches) {
+    auto &lv = ctx->mg->lv;
+    const int last = (int)lv.size() - 1;
+    int ln = 0, rc;
+    if (last == 0) return launch_rbgs_blocked(ctx, L0, ip, rows, cols, 2 * kNu, 1.0f, plane, launches);
+    if ((rc = launch_rbgs_blocked(ctx, L0, ip, rows, cols, kNu, 1.0f, plane, &ln)) != RTDD_OK) return rc;
+    *launches += ln;
+    hipLaunchKernelGGL(k_mg_residual0, grid_for(rows, cols), dim3(256), 0, ctx->stream, L0.P(*plane, ip), L0.M(ip), ctx->lut_dev, (int)ip, rows, cols, lv[0].r(), lv[0].pitch);
+    (*launches)++;
+    for (int l = 0; l < last; l++) {                    // down
+        const MgLevel &f = lv[l], &c = lv[l + 1];
+        hipLaunchKernelGGL(k_mg_restrict, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, f.r(), interp(f), f.rows, f.cols, f.pitch, c.b(), c.e(), c.rows, c.cols, c.pitch);
+        (*launches)++;
+        if (l + 1 == last) { mg_smooth(ctx, c, kCoarsestSweeps, false, launches); break; }
+        mg_smooth(ctx, c, kNu, false, launches);
+        hipLaunchKernelGGL(k_mg_residual, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, view(c), c.e(), c.b(), c.r());
+        (*launches)++;
+    }
+    for (int l = last - 1; l >= 1; l--) {                // up
+        const MgLevel &f = lv[l], &c = lv[l + 1];
+        hipLaunchKernelGGL(k_mg_prolong, grid_for(f.rows, f.cols), dim3(256), 0, ctx->stream, c.e(), c.rows, c.cols, c.pitch, interp(f), f.rows, f.cols, f.pitch, f.e(), f.pitch);
+        (*launches)++;
+        mg_smooth(ctx, f, kNu, true, launches);
+    }
+    hipLaunchKernelGGL(k_mg_prolong, grid_for(rows, cols), dim3(256), 0, ctx->stream, lv[1].e(), lv[1].rows, lv[1].cols, lv[1].pitch, interp(lv[0]), rows, cols, lv[0].pitch,
+                       L0.P(*plane, ip), (int)ip);
+    (*launches)++;
+    RTDD_LAUNCH_CHECK(ctx, "multigrid cycle");
+    ln = 0;
+    if ((rc = launch_rbgs_blocked(ctx, L0, ip, rows, cols, kNu, 1.0f, plane, &ln)) != RTDD_OK) return rc;
+    *launches += ln;
+    return RTDD_OK;
+}
+
+int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every,
+                     int *plane, int *cycles_done, float *residual, int *launches) {
+    int rc = mg_setup(ctx, L0, ip, rows, cols, launches);
+    if (rc != RTDD_OK) return rc;
+    *cycles_done = 0;
+    while (*cycles_done < max_cycles) {
+        if ((rc = mg_vcycle(ctx, L0, ip, rows, cols, plane, launches)) != RTDD_OK) return rc;
+        (*cycles_done)++;
+        if (tolerance > 0.0f && (*cycles_done % check_every == 0 || *cycles_done == max_cycles)) {
+            if ((rc = launch_residual(ctx, L0, ip, *plane, rows, cols, residual)) != RTDD_OK) return rc;
+            if (*residual <= tolerance) break;
+        }
+    }
+    return RTDD_OK;
+}
+
+// diagnostics for the parity tests: copy one plane of one level to the host (dense rows x cols)
+int mg_download(rtdd_ctx *ctx, int level, int which, float *host, int *rows, int *cols) {
+    if (!ctx->mg || level < 0 || level >= (int)ctx->mg->lv.size() || which < 0 || which >= 12) return RTDD_ERR_INVALID;
+    const MgLevel &l = ctx->mg->lv[level];
+    *rows = l.rows; *cols = l.cols;
+    if (!host) return RTDD_OK;
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RTDD_HIP(ctx, hipMemcpy2D(host, (size_t)l.cols * sizeof(float), l.A(which), (size_t)l.pitch * sizeof(float), (size_t)l.cols * sizeof(float), l.rows, hipMemcpyDeviceToHost));
+    return RTDD_OK;
+}
+
+}  // namespace rtdd

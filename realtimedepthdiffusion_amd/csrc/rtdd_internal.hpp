@@ -52,11 +52,12 @@ struct Options {
 
 }  // namespace rtdd
 
-namespace rtdd { struct Pyramid; }
+namespace rtdd { struct Pyramid; struct MgState; }
 
 struct rtdd_ctx {
     int device = 0;
     rtdd::Pyramid *pyr = nullptr;       // whole-estimate driver state (cascade_api.cpp)
+    rtdd::MgState *mg = nullptr;        // multigrid hierarchy buffers (multigrid.hip), kept between solves of one size
     hipStream_t stream = nullptr;
     std::vector<rtdd::Level> levels;
     int maxLevel = -1;
@@ -127,6 +128,12 @@ int launch_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch,
                            int32_t *index2, int level, int rows, int cols);
 int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, float *host_out);
 int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps, float omega);
+// ---- multigrid.hip ------------------------------------------------------------------------------
+int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every,
+                     int *plane, int *cycles_done, float *residual, int *launches);
+void mg_release(rtdd_ctx *ctx);
+int mg_download(rtdd_ctx *ctx, int level, int which, float *host, int *rows, int *cols);
+
 int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, float omega, int *plane, int *launches);
 
 // ---- image_kernels.hip --------------------------------------------------------------------------

@@ -243,7 +243,10 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ X, c
     __syncthreads();
     if (threadIdx.x == 0) {
         d = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        atomicMax(out_bits, __float_as_uint(d));               // non-negative floats order like their bit patterns
+        // non-negative floats order like their bit patterns.  The target only grows, so a block whose maximum is not above
+        // what is already there has nothing to add: without this test 130 000 blocks of an 8K image serialise on one address
+        const unsigned int bits = __float_as_uint(d);
+        if (bits > __hip_atomic_load(out_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out_bits, bits);
     }
 }
 
