@@ -8,6 +8,7 @@
 //     key 'b'/'g'/'h' -> --effect defocus|desaturation|haze     -> <out>ArtisticEffect.ppm (main.cpp:190-230, 312-316)
 //     key 't'  -> prints "Processing Time"  (main.cpp:320-322; wall clock here, the reference uses clock())
 //     --paint x,y,label,radius  = a mouse drag sample (main.cpp:46-62), repeatable
+//     --refine sor|mg [--tolerance T] = extension: converge the finest level after the estimate (rtdd_refine_depth)
 // and adds what the reference cannot do: --devices N --batch B runs B independent estimates
 // round-robin over N GPUs, one host thread + one HIP stream + one rtdd_ctx per GPU, no collective.
 #include <hip/hip_runtime.h>
@@ -61,6 +62,8 @@ struct Job {
     std::vector<Paint> paints;
     std::string effect;
     int iters = 1000;
+    std::string refine;           // "" | "sor" | "mg": rtdd_refine_depth after every estimate
+    float tolerance = 1e-4f;
 };
 
 // One GPU: context + stream + device staging, runs `count` estimates; keeps the last result on the host.
@@ -99,6 +102,14 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
                 CK(rtdd_paint_image(ctx, p.x, p.y, p.label, p.radius, (uint8_t *)p_ed, pi_ed, (uint8_t *)p_scr, pi_scr, rows, cols));
         }
         CK(rtdd_estimate_depth(ctx, job.iters));                        // main.cpp:239-291
+        if (!job.refine.empty()) {                                      // extension: converge the finest level
+            rtdd_solve_params sp;
+            sp.method = job.refine == "mg" ? RTDD_METHOD_MULTIGRID : RTDD_METHOD_RED_BLACK_GS;
+            sp.maxIterations = job.refine == "mg" ? 100 : 400000; sp.tolerance = job.tolerance; sp.checkEvery = 0; sp.relaxation = RTDD_RELAXATION_AUTO;
+            rtdd_solve_info si;
+            CK(rtdd_refine_depth(ctx, &sp, &si));
+            if (n == 0) std::printf("refine %s: %d %s, residual %g\n", job.refine.c_str(), si.iterations, job.refine == "mg" ? "cycles" : "sweeps", si.residual);
+        }
         if (job.effect == "defocus") CK(rtdd_simulate_defocus(ctx, (uint8_t *)p_orig, pi_orig, (float *)p_depth, pi_depth, (uint8_t *)p_art, pi_art, rows, cols));
         else if (job.effect == "desaturation") CK(rtdd_simulate_desaturation(ctx, (uint8_t *)p_orig, pi_orig, (uint8_t *)p_gray, pi_gray, (float *)p_depth, pi_depth, (uint8_t *)p_art, pi_art, rows, cols));
         else if (job.effect == "haze") CK(rtdd_simulate_haze(ctx, (uint8_t *)p_orig, pi_orig, (float *)p_depth, pi_depth, (uint8_t *)p_art, pi_art, rows, cols));
@@ -114,7 +125,7 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
 }
 
 int main(int argc, const char *argv[]) {
-    if (argc == 1) { std::printf("Usage: rtdd_harness -i image.ppm [-a annotation.pgm] [-o prefix] [--effect defocus|desaturation|haze] [--iters N]\n"
+    if (argc == 1) { std::printf("Usage: rtdd_harness -i image.ppm [-a annotation.pgm] [-o prefix] [--effect defocus|desaturation|haze] [--iters N] [--refine sor|mg [--tolerance T]]\n"
                                  "                    [--paint x,y,label,radius]... [--live N] [--devices D --batch B]\n"); return 0; }
     Job job;
     std::string in, an, out = "";
@@ -126,6 +137,8 @@ int main(int argc, const char *argv[]) {
         else if (!std::strcmp(argv[i], "-o")) out = next();
         else if (!std::strcmp(argv[i], "--effect")) job.effect = next();
         else if (!std::strcmp(argv[i], "--iters")) job.iters = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--refine")) job.refine = next();          // sor | mg
+        else if (!std::strcmp(argv[i], "--tolerance")) job.tolerance = (float)std::atof(next());
         else if (!std::strcmp(argv[i], "--devices")) devices = std::atoi(next());
         else if (!std::strcmp(argv[i], "--batch")) batch = std::atoi(next());
         else if (!std::strcmp(argv[i], "--live")) live = std::atoi(next());

@@ -200,6 +200,11 @@ int rtdd_pyramid_set_annotation(rtdd_ctx *ctx, const uint8_t *annotation, size_t
 int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *pitch, int *rows, int *cols);
 /* src/main.cpp:239-291; asynchronous; results in RTDD_IMG_DEPTH (all levels) and RTDD_IMG_DEPTH_U8 */
 int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations);
+/* Extension: one more solve of the finest level, in place on RTDD_IMG_DEPTH level 0, by rtdd_solve_ex with `params`
+ * (e.g. RTDD_METHOD_RED_BLACK_GS + RTDD_RELAXATION_AUTO, or RTDD_METHOD_MULTIGRID, tolerance 1e-4), then RTDD_IMG_DEPTH_U8
+ * again: "estimate, then converge".  The level-0 edge weights are rebuilt from the current depth, as every solve does
+ * (src/GPUSolver.cu:136-224).  Synchronises when params->tolerance > 0. */
+int rtdd_refine_depth(rtdd_ctx *ctx, const rtdd_solve_params *params, rtdd_solve_info *info);
 /* the standalone third-party pieces, exposed for parity tests against the oracle's restatement */
 int rtdd_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bgrPitch, uint8_t *gray, size_t grayPitch, int rows, int cols);
 int rtdd_pyrdown_gray(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, int rows, int cols, uint8_t *dst, size_t dstPitch);

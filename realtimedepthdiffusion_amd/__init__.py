@@ -34,7 +34,7 @@ C_ABI_SYMBOLS = [
     "rtdd_pyrdown_annotation", "rtdd_paint_image", "rtdd_simulate_defocus", "rtdd_simulate_desaturation",
     "rtdd_simulate_haze", "rtdd_profile_enable", "rtdd_profile_get",
     "rtdd_pyramid_levels", "rtdd_pyramid_create", "rtdd_pyramid_destroy", "rtdd_pyramid_set_image",
-    "rtdd_pyramid_set_annotation", "rtdd_pyramid_image", "rtdd_estimate_depth", "rtdd_bgr2gray", "rtdd_pyrdown_gray",
+    "rtdd_pyramid_set_annotation", "rtdd_pyramid_image", "rtdd_estimate_depth", "rtdd_refine_depth", "rtdd_bgr2gray", "rtdd_pyrdown_gray",
     "rtdd_pyrup_depth", "rtdd_depth_to_u8", "rtdd_upload", "rtdd_download",
 ]
 IMG_ORIGINAL, IMG_GRAY, IMG_SCRIBBLE, IMG_EDITED, IMG_DEPTH, IMG_DEPTH_U8, IMG_ARTISTIC = range(7)
@@ -269,6 +269,13 @@ class Context:
 
     def estimate_depth(self, maxIterations=1000):
         self._check(lib().rtdd_estimate_depth(self._h, C.c_int(maxIterations)))
+
+    def refine_depth(self, method=METHOD_RED_BLACK_GS, maxIterations=200000, tolerance=1e-4, checkEvery=0, relaxation=RELAXATION_AUTO):
+        """rtdd_refine_depth: converge the finest level of the last estimate in place.  Returns (iterations, residual)."""
+        params = SolveParams(method, maxIterations, tolerance, checkEvery, relaxation if method == METHOD_RED_BLACK_GS else 0.0)
+        info = SolveInfo()
+        self._check(lib().rtdd_refine_depth(self._h, C.byref(params), C.byref(info)))
+        return info.iterations, info.residual
 
     def bgr2gray(self, bgr, gray, rows, cols):
         b, bp = _img(bgr); g, gp = _img(gray)

@@ -179,6 +179,17 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
     return launch_depth_to_u8(ctx, (const float *)p->depth[0].ptr, p->depth[0].pitch, (uint8_t *)p->depth_u8.ptr, p->depth_u8.pitch, p->rows, p->cols);   // :290
 }
 
+int rtdd_refine_depth(rtdd_ctx *ctx, const rtdd_solve_params *params, rtdd_solve_info *info) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
+    Pyramid *p = ctx->pyr;
+    int rc = rtdd_solve_ex(ctx, (float *)p->depth[0].ptr, p->depth[0].pitch, (const uint8_t *)p->scribble[0].ptr, p->scribble[0].pitch,
+                           (const uint8_t *)p->gray[0].ptr, p->gray[0].pitch, p->rows, p->cols, 0, params, info);
+    if (rc != RTDD_OK) return rc;
+    DeviceGuard g(ctx->device);
+    return launch_depth_to_u8(ctx, (const float *)p->depth[0].ptr, p->depth[0].pitch, (uint8_t *)p->depth_u8.ptr, p->depth_u8.pitch, p->rows, p->cols);
+}
+
 int rtdd_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bgrPitch, uint8_t *gray, size_t grayPitch, int rows, int cols) {
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, bgr && gray && rows > 0 && cols > 0 && bgrPitch >= (size_t)cols * 3 && grayPitch >= (size_t)cols, "bad argument");

@@ -106,3 +106,26 @@ def test_estimate_1080p_full_cascade(oracle, lut):
         assert np.abs(got - ref.depth[0]).max() <= 1e-4
         assert_bit_equal(got, ref.depth[0], "1080p cascade")
         assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), ref.depth_u8)
+
+
+@pytest.mark.parametrize("name", NAMES[:2])
+def test_refine_depth_converges_the_estimate(oracle, name):
+    """rtdd_refine_depth (extension): estimate, then SOR cycles on the finest level to a 1e-4 residual -- the same sweep
+    count, residual and bits as the schedule restated over the oracle, starting from the estimate's own depth (whose
+    values gate the level-0 weights, src/GPUSolver.cu:188-218)."""
+    from test_gpu_parity import _sor_cycles_restated
+    g = load(name)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        c.pyramid_create(256, 256)
+        c.pyramid_set_image(up(g["bgr"])); c.pyramid_set_annotation(up(g["annotation"]))
+        c.estimate_depth(1000); c.synchronize()
+        start = c.pyramid_download(rt.IMG_DEPTH, 0)
+        its, res = c.refine_depth(method=rt.METHOD_RED_BLACK_GS, tolerance=1e-4, relaxation=rt.RELAXATION_AUTO)
+        got = c.pyramid_download(rt.IMG_DEPTH, 0)
+        idx = oracle.index_to_weight(g["gray0"], start, 0, 2)
+        x = start.copy()
+        want_its, want_res = _sor_cycles_restated(oracle, x, idx, g["mask0"], g["lut"], 1, 1e-4, 200000)
+        assert (its, res) == (want_its, np.float32(want_res)) and res <= 1e-4
+        assert_bit_equal(got, x, "refined depth")
+        assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), oracle.depth_to_u8(x))

@@ -51,6 +51,23 @@ def test_harness_batch_and_paint(tmp_path):
     assert d[40, 40] == 0 and d[180, 200] == 254 and 0 < d[110, 120] < 254      # labels held, interior interpolated
 
 
+@pytest.mark.parametrize("how,unit", [("sor", "sweeps"), ("mg", "cycles")])
+def test_harness_refine_extension(tmp_path, how, unit):
+    """--refine: rtdd_refine_depth after the estimate, reported on stdout; the depth map stays a valid one."""
+    import re
+    g = load(NAMES[2])
+    _write_pnm(tmp_path / "img.ppm", g["bgr"][..., ::-1])
+    _write_pnm(tmp_path / "ann.pgm", g["annotation"])
+    out = subprocess.check_output([BIN, "-i", str(tmp_path / "img.ppm"), "-a", str(tmp_path / "ann.pgm"), "-o", str(tmp_path) + "/", "--refine", how], text=True)
+    m = re.search(r"refine %s: (\d+) %s, residual ([0-9.e+-]+)" % (how, unit), out)
+    assert m, out
+    if how == "sor":
+        assert float(m.group(2)) <= 1e-4
+    d = _read_pnm(tmp_path / "DepthMap.pgm")
+    lab = g["mask0"] == 255
+    assert np.array_equal(d[lab], g["depth_u8"][lab])                  # labels are Dirichlet values: untouched
+
+
 def test_plain_c_program_drives_an_estimate(tmp_path):
     """tests/c_abi_smoke.c: C99, links only librtdd.so, runs a whole estimate through the C ABI."""
     lib_dir = os.path.join(ROOT, "realtimedepthdiffusion_amd")
