@@ -4,6 +4,7 @@
 A *step* is one GPUMatrixFreeSolver call (edge-weight pass + K sweeps + copy-back) on one
 synthetic image already resident in HBM.  Default workload = BASELINE.json configs[1]:
 a single 1920x1080 image, one pyramid level, exactly 1000 Chebyshev-Jacobi sweeps.
+Workloads *_rbsor_1e-4 / *_multigrid_1e-4 (BASELINE configs 3 and 5, extensions) solve to a residual instead.
 With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank solves its own
 image of the same size (independent images shard with no collective; the only communication
 is the timing barrier and a MAX-reduce of the elapsed time), so scaling is weak.
@@ -28,18 +29,42 @@ WORKLOADS = {
     "480x270_jacobi250": dict(rows=270, cols=480, iters=250),
     "240x135_jacobi500": dict(rows=135, cols=240, iters=500),
     "960x540_jacobi125": dict(rows=540, cols=960, iters=125),
+    # extensions (BASELINE configs 3 and 5): solve from the cold start to a residual max|J(x)-x| <= 1e-4; `iters` is the cap
+    "4k_rbsor_1e-4": dict(rows=2160, cols=3840, iters=400000, method="sor_cycles", tolerance=1e-4),
+    "1080p_rbsor_1e-4": dict(rows=1080, cols=1920, iters=400000, method="sor_cycles", tolerance=1e-4),
+    "8k_multigrid_1e-4": dict(rows=4320, cols=7680, iters=200, method="multigrid", tolerance=1e-4),
+    "1080p_multigrid_1e-4": dict(rows=1080, cols=1920, iters=200, method="multigrid", tolerance=1e-4),
 }
-ALGO_BYTES_PER_PX_ITER = 17.0          # x_k 4 + x_{k-1} 4 + x_{k+1} 4 + 4 weight indices 4 + mask 1
+# Chebyshev-Jacobi x_k 4 + x_{k-1} 4 + x_{k+1} 4 + 4 weight indices 4 + mask 1 = 17 B per pixel-sweep;
+# red-black sweep (no x_{k-1}) 13 B.  A V-cycle is counted as its four level-0 red-black sweeps (everything else -- residual,
+# transfers, the coarse levels -- is overhead on top), so its figure is a lower bound.
+ALGO_BYTES = {"jacobi": 17.0, "rbgs": 13.0, "sor_cycles": 13.0, "multigrid": 13.0}
+MG_SWEEPS_PER_CYCLE = 4
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(rows, cols, seconds_target=12.0):
+def cpu_baseline(rows, cols, method="jacobi", seconds_target=12.0):
     """Oracle (CPU port of the reference kernels) on this box's host cores, bounded sample."""
     import oracle
     from realtimedepthdiffusion_amd.synth import make_problem
     p = make_problem(rows, cols, seed=1234)
     lut = oracle.load_weights(0.4)
     threads = oracle.max_threads()
+    if method in ("rbgs", "sor_cycles"):              # scalar in-place sweep: one thread
+        idx = oracle.index_to_weight(p["gray"], None, 0, 0)
+        d = p["depth"].copy(); n = 0; t = time.perf_counter()
+        while time.perf_counter() - t < seconds_target:
+            oracle.rbgs_sweep(d, idx, p["mask"], lut, 1, 1.9); n += 1
+        el = time.perf_counter() - t
+        return {"value": rows * cols * n / el / 1e6, "unit": "Mpixel-iterations/s", "cores": 1, "kind": "port",
+                "sample": f"{n} red-black SOR sweeps of the same {cols}x{rows} problem, scalar C, {el:.1f} s"}
+    if method == "multigrid":                         # scalar restatement of the V-cycle: hierarchy setup + ONE cycle
+        idx = oracle.index_to_weight(p["gray"], None, 0, 0)
+        d = p["depth"].copy(); t = time.perf_counter()
+        oracle.mg_solve(d, idx, p["mask"], lut, 1, 1, 0.0, 1)
+        el = time.perf_counter() - t
+        return {"value": rows * cols * MG_SWEEPS_PER_CYCLE / el / 1e6, "unit": "Mpixel-iterations/s", "cores": 1, "kind": "port",
+                "sample": f"hierarchy setup + 1 V-cycle (= {MG_SWEEPS_PER_CYCLE} level-0 sweeps) of the same {cols}x{rows} problem, scalar C, {el:.1f} s"}
     n, el = 16, 0.0
     while True:                               # grow the sample until it is ~seconds_target of CPU work
         d = p["depth"].copy()
@@ -87,7 +112,8 @@ def main():
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--persistent", type=int, default=-1)
-    ap.add_argument("--method", default="jacobi", choices=["jacobi", "rbgs"], help="rbgs = the red-black Gauss-Seidel EXTENSION (not the headline)")
+    ap.add_argument("--method", default=None, choices=["jacobi", "rbgs", "sor_cycles", "multigrid"],
+                    help="override the workload's method; everything but jacobi is an EXTENSION (not the headline)")
     args = ap.parse_args()
 
     import numpy as np
@@ -123,6 +149,8 @@ def main():
         WORKLOADS[args.workload] = dict(rows=r_, cols=c_, iters=i_)
     w = WORKLOADS[args.workload]
     rows, cols, iters = w["rows"], w["cols"], w["iters"]
+    method = args.method or w.get("method", "jacobi")
+    tolerance = w.get("tolerance", 1e-4 if method in ("sor_cycles", "multigrid") else 0.0)
     p = make_problem(rows, cols, seed=1234 + rank)
     dev = f"cuda:{local}"
     ctx = rt.Context(local)
@@ -138,9 +166,16 @@ def main():
     # one pristine initial-depth image per step, uploaded before the clock starts
     depths = [rt.device_image(p["depth"], dev) for _ in range(args.steps + args.warmup)]
 
+    executed = []                           # iterations actually run per step (residual-stopped methods), and the residual reached
+
     def step(i):
-        if args.method == "rbgs":
+        if method == "rbgs":
             ctx.solve_ex(depths[i], mask, gray, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=iters, tolerance=0.0)
+        elif method == "sor_cycles":
+            executed.append(ctx.solve_ex(depths[i], mask, gray, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=iters, tolerance=tolerance,
+                                         relaxation=rt.RELAXATION_AUTO))
+        elif method == "multigrid":
+            executed.append(ctx.solve_ex(depths[i], mask, gray, rows, cols, 0, method=rt.METHOD_MULTIGRID, maxIterations=iters, tolerance=tolerance))
         else:
             ctx.GPUMatrixFreeSolver(depths[i], mask, gray, rows, cols, 0.4, iters, 1e-5, 0)
 
@@ -151,6 +186,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    executed.clear()
     ctx.profile_enable(True)               # HIP events around the sweep launches, on the launch stream
     sweep_ms = 0.0; launches = 0; sweeps = 0
     fence()
@@ -160,40 +196,50 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     pr = ctx.profile(); sweep_ms = pr.sweep_ms; launches = pr.launches; sweeps = pr.sweeps   # events recorded inside the timed region
-    px_iter_per_step = rows * cols * iters
+    if executed:                              # residual-stopped: count what actually ran (a V-cycle = its level-0 sweeps)
+        per = MG_SWEEPS_PER_CYCLE if method == "multigrid" else 1
+        px_iter_per_step = rows * cols * per * sum(e[0] for e in executed) / len(executed)
+    else:
+        px_iter_per_step = rows * cols * iters
+    algo_bytes = ALGO_BYTES[method]
     agg_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
     units, elapsed, thr = shard.aggregate(args.steps * px_iter_per_step, elapsed, dist, agg_dev)   # SUM of units, MAX of time
     value = thr / 1e6
     launch_us = sweep_ms * 1e3 / max(launches, 1)
+    if method == "multigrid": sweeps *= MG_SWEEPS_PER_CYCLE
     sweeps_per_launch = sweeps / max(launches, 1)
-    achieved = ALGO_BYTES_PER_PX_ITER * rows * cols * sweeps_per_launch / (launch_us * 1e-6) / 1e9
+    achieved = algo_bytes * rows * cols * sweeps_per_launch / (launch_us * 1e-6) / 1e9
     out = {
         "metric": "Mpixel-iterations/s (solver sweep)", "value": value, "unit": "Mpixel-iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps "
-                               f"(BASELINE configs[1])" if args.workload == "1080p_jacobi1000" and args.method == "jacobi" else f"{args.workload} ({args.method})",
+                               f"(BASELINE configs[1])" if args.workload == "1080p_jacobi1000" and method == "jacobi" else f"{args.workload} ({method})",
                    "images_per_step": world, "sweep_kernel": ctx.get_option(rt.OPT_SWEEP_KERNEL), "tile": ctx.get_option(rt.OPT_TILE), "temporal_depth": ctx.get_option(rt.OPT_TEMPORAL_DEPTH), "persistent": ctx.get_option(rt.OPT_PERSISTENT),
                    "sweeps_per_launch": sweeps_per_launch},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "sweep", "launch_us": launch_us,
-                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX_ITER * rows * cols * sweeps_per_launch},
+                     "traffic": None, "kernel": {"jacobi": "k_sweep_blocked", "rbgs": "k_rbgs_blocked", "sor_cycles": "k_rbgs_blocked (+ residual checks)",
+                                                 "multigrid": "whole V-cycle, counted as its 4 level-0 sweeps"}[method], "launch_us": launch_us,
+                     "algorithmic_bytes_per_launch": algo_bytes * rows * cols * sweeps_per_launch},
     }
+    if executed:
+        out["config"]["converged"] = {"tolerance": tolerance, "iterations": [e[0] for e in executed], "unit": "cycles" if method == "multigrid" else "sweeps",
+                                      "residual": max(e[1] for e in executed), "start": "cold (depth 255 + labels)"}
     # HBM-side traffic of the sweep kernel comes from a separate rocprofv3 --pmc pass of this same command
     # (scripts/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), committed under profiles/.
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        if prof.get("workload") == args.workload and args.method == "jacobi" and not (args.sweep_kernel or args.tile or args.temporal_depth):
+        if prof.get("workload") == args.workload and method == "jacobi" and not (args.sweep_kernel or args.tile or args.temporal_depth):
             for name, k in prof["kernels"].items():
                 if "k_sweep" in name:
                     out["roofline"]["traffic"] = k["hbm_bytes_per_launch_corrected"]
                     out["roofline"]["traffic_source"] = prof.get("source", "profiles/traffic_latest.json")
     except (OSError, ValueError, KeyError):
         pass
-    if rank == 0 and args.workload == "1080p_jacobi1000" and args.method == "jacobi" and not args.no_estimate:
+    if rank == 0 and args.workload == "1080p_jacobi1000" and method == "jacobi" and not args.no_estimate:
         out["estimate"] = estimate_ms(rt, ctx, p, rows, cols, dev)      # second half of BASELINE's metric; outside the timed region
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(rows, cols)
+        out["cpu_baseline"] = cpu_baseline(rows, cols, method)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
