@@ -180,21 +180,35 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict_
     }
 }
 
+// 1024-thread tiles waste less on halo (centre 112x112 of 128x128 vs 112x48 of 128x64 at 4 sweeps per launch) but
+// there is one per CU instead of two: prefer them when the grid still fills the chip evenly.
+static bool rbgs_prefers_big_tile(const rtdd_ctx *ctx, int rows, int cols) {
+    // measured (scripts/rbgs_tile_sweep*.sh): 128x128 tiles at 8 sweeps per launch beat 128x64 at 4 from 1080p up
+    // (658 vs 462, 771 vs 663, 824 vs 766 Gpx-sweeps/s at 1080p / 4K / 8K); below that the grid no longer covers the chip
+    const int centre = 128 - 2 * 16;
+    const long tiles = (long)((cols + centre - 1) / centre) * ((rows + centre - 1) / centre);
+    return tiles >= (long)ctx->num_cus * 3 / 4;
+}
+
 // n full sweeps from plane *plane; on return *plane names the plane holding the result.
 int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, float omega, int *plane, int *launches) {
-    // two shapes: 128x64 (512 threads, 16 px/thread, two workgroups per CU) and, for images that fit it, ONE 128x128 tile
+    // two shapes: 128x64 (512 threads, 16 px/thread, two workgroups per CU) and 128x128 (1024 threads, one per CU); an image
+    // that fits ONE 128x128 tile runs all its sweeps in one launch.  RTDD_OPT_TILE 1/2 forces a shape, RTDD_OPT_TEMPORAL_DEPTH the
+    // sweeps per launch (default 8 = 16 half-sweeps = a 16-pixel halo).
     const bool single = cols <= 128 && rows <= 128;
-    const int EW = 128, EH = single ? 128 : 64;
+    const bool big = single || ctx->opt.tile == 2 || (ctx->opt.tile == 0 && rbgs_prefers_big_tile(ctx, rows, cols));
+    const int EW = 128;
+    int depth = ctx->opt.temporal_depth > 0 ? ctx->opt.temporal_depth : 8;
+    if (depth > (big ? 24 : 12)) depth = big ? 24 : 12;               // keep a centre of at least 32x16 / 32x32
     int done = 0;
     *launches = 0;
     while (done < n) {
-        const int m = single ? n - done : (n - done < 4 ? n - done : 4);   // 4 sweeps = 8 half-sweeps = an 8-pixel halo
+        const int m = single ? n - done : (n - done < depth ? n - done : depth);
         const int hy = single ? 0 : 2 * m, hx = single ? 0 : (2 * m + 3) / 4 * 4;
-        int nthreads = single ? 1024 : 512;
+        int nthreads = big ? 1024 : 512;
         if (single) { const int need = (rows + 3) / 4 * 32; nthreads = (need + 63) / 64 * 64; if (nthreads > 1024) nthreads = 1024; }
         const int eh = nthreads / 32 * 4;
         const int TW = EW - 2 * hx, TH = eh - 2 * hy;
-        (void)EH;
         const dim3 grid((cols + TW - 1) / TW, (rows + TH - 1) / TH);
         int out = -1;
         for (int i = 0; i < 4; i++) if (i != *plane) { out = i; break; }
@@ -202,7 +216,7 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
         float *Y = L.P(out, ip);
         const bool sor = omega != 1.0f;
 #define RTDD_RBGS_GO(NT_, C_, S_) hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega)
-        const int variant = (single ? 4 : 0) | (ctx->opt.fp_contract ? 2 : 0) | (sor ? 1 : 0);
+        const int variant = (big ? 4 : 0) | (ctx->opt.fp_contract ? 2 : 0) | (sor ? 1 : 0);
         switch (variant) {
             case 0: RTDD_RBGS_GO(512, false, false); break;
             case 1: RTDD_RBGS_GO(512, false, true); break;

@@ -201,7 +201,7 @@ def test_residual_stop_and_rbgs_extensions(ctx, oracle, lut):
 
 
 @pytest.mark.parametrize("rows,cols,sweeps", [(64, 128, 7), (128, 128, 9), (129, 128, 5), (96, 131, 6), (240, 333, 11),
-                                             (547, 1021, 13), (1080, 1920, 8), (50, 77, 3), (1, 300, 4), (300, 1, 4), (2, 2, 5)])
+                                             (547, 1021, 13), (1080, 1920, 26), (50, 77, 3), (1, 300, 4), (300, 1, 4), (2, 2, 5)])
 @pytest.mark.parametrize("contract,omega", [(1, 1.0), (0, 1.0), (1, 1.7), (0, 1.93)])
 def test_rbgs_blocked_bit_exact(ctx, oracle, lut, rows, cols, sweeps, contract, omega):
     """Register-blocked red-black Gauss-Seidel (csrc/rbgs_blocked.hip; an EXTENSION, north_star config 3) == the
@@ -215,13 +215,14 @@ def test_rbgs_blocked_bit_exact(ctx, oracle, lut, rows, cols, sweeps, contract, 
     for _ in range(sweeps):
         oracle.rbgs_sweep(x, idx, p["mask"], lut, contract, omega)      # omega != 1: the SOR step
     m, g = up(p["mask"]), up(p["gray"])
-    for kernel in (0, 1):
-        ctx.set_option(rt.OPT_SWEEP_KERNEL, kernel)
+    # (sweep kernel, tile shape, sweeps per launch): automatic; one launch per colour; both tile shapes at several depths
+    for kernel, tile, depth in ((0, 0, 0), (1, 0, 0), (0, 1, 4), (0, 1, 3), (0, 2, 8), (0, 2, 5), (0, 1, 12), (0, 2, 24)):
+        ctx.set_option(rt.OPT_SWEEP_KERNEL, kernel); ctx.set_option(rt.OPT_TILE, tile); ctx.set_option(rt.OPT_TEMPORAL_DEPTH, depth)
         d = up(p["depth"])
         its, _ = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=sweeps, tolerance=0.0, relaxation=omega)
         assert its == sweeps
-        assert_bit_equal(down(d), x, f"rbgs kernel {kernel} {rows}x{cols}x{sweeps} omega {omega}")
-    ctx.set_option(rt.OPT_SWEEP_KERNEL, 0)
+        assert_bit_equal(down(d), x, f"rbgs kernel {kernel} tile {tile} depth {depth} {rows}x{cols}x{sweeps} omega {omega}")
+    ctx.set_option(rt.OPT_SWEEP_KERNEL, 0); ctx.set_option(rt.OPT_TILE, 0); ctx.set_option(rt.OPT_TEMPORAL_DEPTH, 0)
     ctx.set_option(rt.OPT_FP_CONTRACT, 1)
 
 
