@@ -229,7 +229,7 @@ def main():
     # (scripts/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), committed under profiles/.
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        if prof.get("workload") == args.workload and method == "jacobi" and not (args.sweep_kernel or args.tile or args.temporal_depth):
+        if prof.get("workload") == args.workload and method == "jacobi" and not (args.sweep_kernel or args.tile or args.temporal_depth or args.persistent >= 0):
             for name, k in prof["kernels"].items():
                 if "k_sweep" in name:
                     out["roofline"]["traffic"] = k["hbm_bytes_per_launch_corrected"]

@@ -8,7 +8,7 @@
 //     key 'b'/'g'/'h' -> --effect defocus|desaturation|haze     -> <out>ArtisticEffect.ppm (main.cpp:190-230, 312-316)
 //     key 't'  -> prints "Processing Time"  (main.cpp:320-322; wall clock here, the reference uses clock())
 //     --paint x,y,label,radius  = a mouse drag sample (main.cpp:46-62), repeatable
-//     --refine sor|mg [--tolerance T] = extension: converge the finest level after the estimate (rtdd_refine_depth)
+//     --refine sor|mg|auto [--tolerance T] = extension: converge the finest level after the estimate (rtdd_refine_depth)
 // and adds what the reference cannot do: --devices N --batch B runs B independent estimates
 // round-robin over N GPUs, one host thread + one HIP stream + one rtdd_ctx per GPU, no collective.
 #include <hip/hip_runtime.h>
@@ -104,11 +104,12 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
         CK(rtdd_estimate_depth(ctx, job.iters));                        // main.cpp:239-291
         if (!job.refine.empty()) {                                      // extension: converge the finest level
             rtdd_solve_params sp;
-            sp.method = job.refine == "mg" ? RTDD_METHOD_MULTIGRID : RTDD_METHOD_RED_BLACK_GS;
+            sp.method = job.refine == "mg" ? RTDD_METHOD_MULTIGRID : job.refine == "auto" ? RTDD_METHOD_AUTO : RTDD_METHOD_RED_BLACK_GS;
             sp.maxIterations = job.refine == "mg" ? 100 : 400000; sp.tolerance = job.tolerance; sp.checkEvery = 0; sp.relaxation = RTDD_RELAXATION_AUTO;
             rtdd_solve_info si;
             CK(rtdd_refine_depth(ctx, &sp, &si));
-            if (n == 0) std::printf("refine %s: %d %s, residual %g\n", job.refine.c_str(), si.iterations, job.refine == "mg" ? "cycles" : "sweeps", si.residual);
+            if (n == 0 && job.refine == "auto") std::printf("refine auto: %d cycles + %d sweeps, residual %g\n", si.cycles, si.iterations, si.residual);
+            else if (n == 0) std::printf("refine %s: %d %s, residual %g\n", job.refine.c_str(), si.iterations, job.refine == "mg" ? "cycles" : "sweeps", si.residual);
         }
         if (job.effect == "defocus") CK(rtdd_simulate_defocus(ctx, (uint8_t *)p_orig, pi_orig, (float *)p_depth, pi_depth, (uint8_t *)p_art, pi_art, rows, cols));
         else if (job.effect == "desaturation") CK(rtdd_simulate_desaturation(ctx, (uint8_t *)p_orig, pi_orig, (uint8_t *)p_gray, pi_gray, (float *)p_depth, pi_depth, (uint8_t *)p_art, pi_art, rows, cols));
@@ -125,7 +126,7 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
 }
 
 int main(int argc, const char *argv[]) {
-    if (argc == 1) { std::printf("Usage: rtdd_harness -i image.ppm [-a annotation.pgm] [-o prefix] [--effect defocus|desaturation|haze] [--iters N] [--refine sor|mg [--tolerance T]]\n"
+    if (argc == 1) { std::printf("Usage: rtdd_harness -i image.ppm [-a annotation.pgm] [-o prefix] [--effect defocus|desaturation|haze] [--iters N] [--refine sor|mg|auto [--tolerance T]]\n"
                                  "                    [--paint x,y,label,radius]... [--live N] [--devices D --batch B]\n"); return 0; }
     Job job;
     std::string in, an, out = "";
@@ -137,7 +138,7 @@ int main(int argc, const char *argv[]) {
         else if (!std::strcmp(argv[i], "-o")) out = next();
         else if (!std::strcmp(argv[i], "--effect")) job.effect = next();
         else if (!std::strcmp(argv[i], "--iters")) job.iters = std::atoi(next());
-        else if (!std::strcmp(argv[i], "--refine")) job.refine = next();          // sor | mg
+        else if (!std::strcmp(argv[i], "--refine")) job.refine = next();          // sor | mg | auto
         else if (!std::strcmp(argv[i], "--tolerance")) job.tolerance = (float)std::atof(next());
         else if (!std::strcmp(argv[i], "--devices")) devices = std::atoi(next());
         else if (!std::strcmp(argv[i], "--batch")) batch = std::atoi(next());

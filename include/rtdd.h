@@ -49,8 +49,11 @@ enum rtdd_status {
 enum rtdd_method {
     RTDD_METHOD_CHEBYSHEV_JACOBI = 0,
     RTDD_METHOD_RED_BLACK_GS = 1,
-    RTDD_METHOD_MULTIGRID = 2        /* V(2,2) cycles, operator-dependent interpolation; maxIterations counts CYCLES,
+    RTDD_METHOD_MULTIGRID = 2,       /* V(2,2) cycles, operator-dependent interpolation; maxIterations counts CYCLES,
                                       * checkEvery defaults to 1 cycle */
+    RTDD_METHOD_AUTO = 3             /* to a tolerance (required): V-cycles while they pay (until the tolerance, 60 cycles, or two
+                                      * cycles that together do not halve the residual), then red-black SOR cycles
+                                      * (RTDD_RELAXATION_AUTO) from there; maxIterations caps the SOR sweeps */
 };
 
 /* Tunables, rtdd_set_option(ctx, key, value). */
@@ -120,8 +123,9 @@ typedef struct rtdd_solve_params {
 #define RTDD_RELAXATION_AUTO (-1.0f)
 
 typedef struct rtdd_solve_info {
-    int iterations;                 /* sweeps actually executed */
+    int iterations;                 /* sweeps actually executed (RTDD_METHOD_MULTIGRID: cycles) */
     float residual;                 /* last evaluated max|J(x)-x| (NaN if never evaluated) */
+    int cycles;                     /* V-cycles executed (RTDD_METHOD_MULTIGRID, RTDD_METHOD_AUTO), else 0 */
 } rtdd_solve_info;
 
 int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch,

@@ -23,6 +23,7 @@ RTDD_OK = 0
 METHOD_CHEBYSHEV_JACOBI = 0
 METHOD_RED_BLACK_GS = 1
 METHOD_MULTIGRID = 2
+METHOD_AUTO = 3
 RELAXATION_AUTO = -1.0                     # rtdd_solve_params.relaxation: SOR cycles (include/rtdd.h)
 OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, _OPT_RESERVED_3, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
 
@@ -58,7 +59,7 @@ class SolveParams(C.Structure):
 
 
 class SolveInfo(C.Structure):
-    _fields_ = [("iterations", C.c_int), ("residual", C.c_float)]
+    _fields_ = [("iterations", C.c_int), ("residual", C.c_float), ("cycles", C.c_int)]
 
 
 class Profile(C.Structure):
@@ -189,6 +190,7 @@ class Context:
         info = SolveInfo()
         self._check(lib().rtdd_solve_ex(self._h, dp, dpitch, sp, spitch, gp, gpitch, C.c_int(rows), C.c_int(cols), C.c_int(level),
                                         C.byref(params), C.byref(info)))
+        self.last_cycles = info.cycles          # V-cycles of the last solve (METHOD_MULTIGRID / METHOD_AUTO)
         return info.iterations, info.residual
 
     def multigrid_level(self, level, which):
@@ -275,6 +277,7 @@ class Context:
         params = SolveParams(method, maxIterations, tolerance, checkEvery, relaxation if method == METHOD_RED_BLACK_GS else 0.0)
         info = SolveInfo()
         self._check(lib().rtdd_refine_depth(self._h, C.byref(params), C.byref(info)))
+        self.last_cycles = info.cycles
         return info.iterations, info.residual
 
     def bgr2gray(self, bgr, gray, rows, cols):

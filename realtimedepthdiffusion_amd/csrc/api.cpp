@@ -256,6 +256,8 @@ static int ensure_omegas(rtdd_ctx *ctx, int n) {
     return RTDD_OK;
 }
 
+static constexpr int kAutoMaxCycles = 60;
+
 static int check_solve_args(rtdd_ctx *ctx, const float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
                             const uint8_t *gray, size_t grayPitch, int rows, int cols, int level) {
     REQUIRE(ctx, depth && scribble && gray, "null image pointer");
@@ -276,7 +278,9 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, params != nullptr, "null params");
     REQUIRE(ctx, params->maxIterations >= 0, "maxIterations must be >= 0");
-    REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS || params->method == RTDD_METHOD_MULTIGRID, "unknown method");
+    REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS || params->method == RTDD_METHOD_MULTIGRID ||
+                 params->method == RTDD_METHOD_AUTO, "unknown method");
+    REQUIRE(ctx, params->method != RTDD_METHOD_AUTO || params->tolerance > 0.0f, "RTDD_METHOD_AUTO needs a tolerance");
     REQUIRE(ctx, params->method != RTDD_METHOD_RED_BLACK_GS || params->relaxation == RTDD_RELAXATION_AUTO || (params->relaxation >= 0.0f && params->relaxation < 2.0f),
             "relaxation must be in [0,2) or RTDD_RELAXATION_AUTO");
     int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
@@ -294,7 +298,7 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
 
     const bool stop_on_residual = params->tolerance > 0.0f;
     const int every = params->checkEvery > 0 ? params->checkEvery : 16;
-    int done = 0, launches = 0;
+    int done = 0, launches = 0, cycles = 0;
     int pk = 0, pm = 1;                            // planes holding x_k and x_{k-1}
     float residual = NAN;
 
@@ -323,9 +327,10 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
             }
         }
     } else if (params->method == RTDD_METHOD_MULTIGRID) {
-        rc = launch_multigrid(ctx, L, ip, rows, cols, params->maxIterations, params->tolerance, params->checkEvery > 0 ? params->checkEvery : 1,
-                              &pk, &done, &residual, &launches);
+        rc = launch_multigrid(ctx, L, ip, rows, cols, params->maxIterations, params->tolerance, params->checkEvery > 0 ? params->checkEvery : 1, false,
+                              &pk, &cycles, &residual, &launches);
         if (rc != RTDD_OK) return rc;
+        done = cycles;
     } else {
         auto run = [&](int n, float omega) -> int {                                                   // n sweeps at one relaxation factor
             if (n > params->maxIterations - done) n = params->maxIterations - done;
@@ -336,7 +341,15 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
             done += n; launches += ln;
             return r;
         };
-        if (params->relaxation < 0.0f) {
+        bool reached = false;
+        if (params->method == RTDD_METHOD_AUTO) {
+            // V-cycles while they pay: they stop at the tolerance, after kAutoMaxCycles, or when two cycles together no longer halve
+            // the residual (thin high-contrast structures); SOR cycles finish from whatever they reached
+            rc = launch_multigrid(ctx, L, ip, rows, cols, kAutoMaxCycles, params->tolerance, 1, true, &pk, &cycles, &residual, &launches);
+            if (rc != RTDD_OK) return rc;
+            reached = residual <= params->tolerance;
+        }
+        if (params->method == RTDD_METHOD_AUTO || params->relaxation < 0.0f) {
             // RTDD_RELAXATION_AUTO: SOR cycles.  Over-relaxation removes the smooth error a plain sweep hardly touches, but in
             // f32 it idles at a residual ~ ulp(x)/(2 - omega); plain Gauss-Seidel has an exact f32 fixed point but is slow on
             // smooth error.  So: n_hi sweeps at omega_hi, n_hi/4 at omega_mid, then a Gauss-Seidel polish of at most 100
@@ -346,7 +359,6 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
             double w0 = 2.0 / (1.0 + sin(4.0 * 3.14159265358979323846 / (double)longest));
             if (w0 > 1.99) w0 = 1.99;
             if (w0 < 1.0) w0 = 1.0;
-            bool reached = false;
             for (int cycle = 0; done < params->maxIterations && !reached; cycle++) {
                 // a cycle that does not get there is followed by one twice as long and twice as close to omega = 2
                 const int e = cycle < 6 ? cycle : 6;
@@ -391,7 +403,7 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
         ctx->prof_launches[slot] = launches; ctx->prof_sweeps[slot] = done;
         ctx->prof_pending++;                        // resolved (and synchronised) by rtdd_profile_get, not here
     }
-    if (info) { info->iterations = done; info->residual = residual; }
+    if (info) { info->iterations = done; info->residual = residual; info->cycles = cycles; }
     return RTDD_OK;
 }
 

@@ -395,17 +395,20 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     return RTDD_OK;
 }
 
-int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every,
+int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every, bool stop_on_stall,
                      int *plane, int *cycles_done, float *residual, int *launches) {
     int rc = mg_setup(ctx, L0, ip, rows, cols, launches);
     if (rc != RTDD_OK) return rc;
     *cycles_done = 0;
+    float before = INFINITY, before2 = INFINITY;         // residuals one and two checks ago
     while (*cycles_done < max_cycles) {
         if ((rc = mg_vcycle(ctx, L0, ip, rows, cols, plane, launches)) != RTDD_OK) return rc;
         (*cycles_done)++;
         if (tolerance > 0.0f && (*cycles_done % check_every == 0 || *cycles_done == max_cycles)) {
             if ((rc = launch_residual(ctx, L0, ip, *plane, rows, cols, residual)) != RTDD_OK) return rc;
             if (*residual <= tolerance) break;
+            if (stop_on_stall && !(*residual <= 0.5f * before2)) break;      // two cycles did not halve it
+            before2 = before; before = *residual;
         }
     }
     return RTDD_OK;

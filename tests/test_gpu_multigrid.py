@@ -67,3 +67,31 @@ def test_agrees_with_scipy_direct_solution(ctx, name):
     its, res = ctx.solve_ex(d, up(g[f"mask{lvl}"]), up(g["direct_gray_L2"]), r, r, 0, method=rt.METHOD_MULTIGRID, maxIterations=10, tolerance=1e-30, checkEvery=10)
     assert its == 10 and res <= 5e-5
     assert np.abs(down(d) - g["direct_solution_L2"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("rows,cols,seed,expect_sor", [(135, 240, 1234, False), (270, 480, 1234, True)])
+def test_auto_method_vcycles_then_sor_cycles(ctx, oracle, lut, rows, cols, seed, expect_sor):
+    """RTDD_METHOD_AUTO: V-cycles until the tolerance or until two cycles no longer halve the residual, then SOR cycles.
+    One instance the V-cycle finishes alone, one (a thin strip between two edges) where it stalls and the sweeps take over;
+    cycle count, sweep count, residual and bits as the same logic driven through the restatements."""
+    from test_gpu_parity import _sor_cycles_restated
+    p = make_problem(rows, cols, seed=seed)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    idx = oracle.index_to_weight(p["gray"], None, 0, 0)
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_AUTO, maxIterations=200000, tolerance=1e-4)
+    cycles = ctx.last_cycles
+    x = p["depth"].copy()
+    want_cycles, before, before2, want_res = 0, np.inf, np.inf, np.nan
+    while want_cycles < 60:
+        _, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, 1, 1, 1e-30, 1)     # one cycle (the hierarchy only depends on the weights)
+        want_cycles += 1
+        if want_res <= 1e-4 or not (want_res <= np.float32(0.5) * np.float32(before2)):
+            break
+        before2, before = before, want_res
+    want_its = 0
+    if want_res > 1e-4:
+        want_its, want_res = _sor_cycles_restated(oracle, x, idx, p["mask"], lut, 1, 1e-4, 200000)
+    assert (cycles, its, res) == (want_cycles, want_its, np.float32(want_res)) and res <= 1e-4
+    assert (its > 0) == expect_sor
+    assert_bit_equal(down(d), x, "auto")
