@@ -51,9 +51,10 @@ enum rtdd_method {
     RTDD_METHOD_RED_BLACK_GS = 1,
     RTDD_METHOD_MULTIGRID = 2,       /* V(2,2) cycles, operator-dependent interpolation; maxIterations counts CYCLES,
                                       * checkEvery defaults to 1 cycle */
-    RTDD_METHOD_AUTO = 3             /* to a tolerance (required): V-cycles while they pay (until the tolerance, 60 cycles, or two
-                                      * cycles that together do not halve the residual), then red-black SOR cycles
-                                      * (RTDD_RELAXATION_AUTO) from there; maxIterations caps the SOR sweeps */
+    RTDD_METHOD_AUTO = 3             /* to a tolerance (required): V-cycles while they pay (until the tolerance, 60 cycles, or until
+                                      * the cycles still needed at the current rate are modelled dearer than the sweeps), then red-black SOR cycles
+                                      * (RTDD_RELAXATION_AUTO, started at half length: N = max(rows,cols)/2 rounded up) from there;
+                                      * maxIterations caps the SOR sweeps */
 };
 
 /* Tunables, rtdd_set_option(ctx, key, value). */

@@ -327,7 +327,7 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
             }
         }
     } else if (params->method == RTDD_METHOD_MULTIGRID) {
-        rc = launch_multigrid(ctx, L, ip, rows, cols, params->maxIterations, params->tolerance, params->checkEvery > 0 ? params->checkEvery : 1, false,
+        rc = launch_multigrid(ctx, L, ip, rows, cols, params->maxIterations, params->tolerance, params->checkEvery > 0 ? params->checkEvery : 1, 0.0,
                               &pk, &cycles, &residual, &launches);
         if (rc != RTDD_OK) return rc;
         done = cycles;
@@ -343,9 +343,14 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
         };
         bool reached = false;
         if (params->method == RTDD_METHOD_AUTO) {
-            // V-cycles while they pay: they stop at the tolerance, after kAutoMaxCycles, or when two cycles together no longer halve
-            // the residual (thin high-contrast structures); SOR cycles finish from whatever they reached
-            rc = launch_multigrid(ctx, L, ip, rows, cols, kAutoMaxCycles, params->tolerance, 1, true, &pk, &cycles, &residual, &launches);
+            // V-cycles while they pay: they stop at the tolerance, after kAutoMaxCycles, or when the cycles still needed (at the
+            // rate of the last two) are modelled to cost more than finishing with SOR cycles of half length -- thin high-contrast
+            // structures stall them, and below ~4K a cycle is launch-bound and dear.
+            const int longest_ = rows > cols ? rows : cols;
+            const double px = (double)rows * cols;
+            const double sweep_seconds = px / 700e9 > 2.5e-6 ? px / 700e9 : 2.5e-6;            // k_rbgs_blocked, measured
+            const double sor_seconds = ((double)((longest_ + 1) / 2) * 1.25 + 20.0) * sweep_seconds;
+            rc = launch_multigrid(ctx, L, ip, rows, cols, kAutoMaxCycles, params->tolerance, 1, sor_seconds, &pk, &cycles, &residual, &launches);
             if (rc != RTDD_OK) return rc;
             reached = residual <= params->tolerance;
         }
@@ -356,6 +361,8 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
             // sweeps with the residual checked every 20; repeat (longer, closer to 2) until the tolerance or maxIterations
             // (DESIGN.md section 7).
             const int longest = rows > cols ? rows : cols;
+            // after V-cycles the smooth error is gone and half the length does (scripts/auto_probe.py); a cycle that fails still doubles
+            const int base = params->method == RTDD_METHOD_AUTO ? (longest + 1) / 2 : longest;
             double w0 = 2.0 / (1.0 + sin(4.0 * 3.14159265358979323846 / (double)longest));
             if (w0 > 1.99) w0 = 1.99;
             if (w0 < 1.0) w0 = 1.0;
@@ -367,7 +374,7 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
                 const float w_hi = (float)(2.0 - gap);
                 float w_mid = (float)(2.0 - 10.0 * gap);
                 if (w_mid < 1.0f) w_mid = 1.0f;
-                const int n_hi = longest << e;
+                const int n_hi = base << e;
                 if ((rc = run(n_hi, w_hi)) != RTDD_OK) return rc;
                 if ((rc = run(n_hi / 4, w_mid)) != RTDD_OK) return rc;
                 for (int k = 0; k < 5 && done < params->maxIterations && !reached; k++) {

@@ -395,7 +395,14 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     return RTDD_OK;
 }
 
-int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every, bool stop_on_stall,
+// Modelled duration of one V-cycle (seconds): ~100 launch-bound launches on the small levels + the streaming part
+// (measured 0.64 / 1.0 / 2.2 ms at 1080p / 4K / 8K, profiles/r01_config3_config5_timings.jsonl).
+static double cycle_seconds(int rows, int cols) { return 450e-6 + (double)rows * cols * 53e-12; }
+
+// alternative_seconds > 0 (RTDD_METHOD_AUTO): leave as soon as the cycles still needed at the rate of the last two,
+// priced by cycle_seconds, cost more than the alternative (SOR cycles from here).  A deterministic rule on the f32
+// residuals -- no clocks -- so that a solve is reproducible.
+int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every, double alternative_seconds,
                      int *plane, int *cycles_done, float *residual, int *launches) {
     int rc = mg_setup(ctx, L0, ip, rows, cols, launches);
     if (rc != RTDD_OK) return rc;
@@ -407,7 +414,12 @@ int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
         if (tolerance > 0.0f && (*cycles_done % check_every == 0 || *cycles_done == max_cycles)) {
             if ((rc = launch_residual(ctx, L0, ip, *plane, rows, cols, residual)) != RTDD_OK) return rc;
             if (*residual <= tolerance) break;
-            if (stop_on_stall && !(*residual <= 0.5f * before2)) break;      // two cycles did not halve it
+            if (alternative_seconds > 0.0 && before2 < INFINITY) {
+                const double rate = sqrt((double)*residual / (double)before2);         // per cycle, over the last two
+                if (!(rate < 1.0)) break;
+                const double needed = ceil(log((double)*residual / (double)tolerance) / -log(rate));
+                if (needed * cycle_seconds(rows, cols) > alternative_seconds) break;
+            }
             before2 = before; before = *residual;
         }
     }

@@ -129,7 +129,7 @@ int launch_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch,
 int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, float *host_out);
 int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps, float omega);
 // ---- multigrid.hip ------------------------------------------------------------------------------
-int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every, bool stop_on_stall,
+int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every, double alternative_seconds,
                      int *plane, int *cycles_done, float *residual, int *launches);
 void mg_release(rtdd_ctx *ctx);
 int mg_download(rtdd_ctx *ctx, int level, int which, float *host, int *rows, int *cols);

@@ -226,7 +226,7 @@ def test_rbgs_blocked_bit_exact(ctx, oracle, lut, rows, cols, sweeps, contract, 
     ctx.set_option(rt.OPT_FP_CONTRACT, 1)
 
 
-def _sor_cycles_restated(oracle, x, idx, mask, lut, contract, tol, max_its):
+def _sor_cycles_restated(oracle, x, idx, mask, lut, contract, tol, max_its, halve=False):
     """rtdd_solve_ex's RTDD_RELAXATION_AUTO schedule (include/rtdd.h, csrc/api.cpp) driven through the oracle's sweep and residual."""
     import math
     rows, cols = x.shape
@@ -245,7 +245,8 @@ def _sor_cycles_restated(oracle, x, idx, mask, lut, contract, tol, max_its):
         e = min(cycle, 6)
         gap = max(0.005, (2.0 - w0) / (1 << e))
         w_hi, w_mid = np.float32(2.0 - gap), max(np.float32(1.0), np.float32(2.0 - 10.0 * gap))
-        run(longest << e, w_hi); run((longest << e) // 4, w_mid)
+        base = (longest + 1) // 2 if halve else longest             # RTDD_METHOD_AUTO starts its SOR cycles at half length
+        run(base << e, w_hi); run((base << e) // 4, w_mid)
         for _ in range(5):
             if done >= max_its or reached:
                 break
