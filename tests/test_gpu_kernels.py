@@ -153,6 +153,18 @@ def test_error_behaviour(ctx):
         c.GPUMatrixFreeSolver(d, m, m, 64, 64, 0.4, 10, 0.0, 0)          # larger than the allocation
     c.GPUMatrixFreeSolver(d, m, m, 8, 8, 0.4, 10, 0.0, 0)                # and a legal call still works
     c.synchronize()
+    # rtdd_solve_ex (extension) argument checks: unknown method, relaxation outside [0,2), AUTO without a tolerance
+    for kw in (dict(method=7), dict(method=rt.METHOD_RED_BLACK_GS, relaxation=2.0), dict(method=rt.METHOD_RED_BLACK_GS, relaxation=-0.5),
+               dict(method=rt.METHOD_AUTO, tolerance=0.0), dict(maxIterations=-1)):
+        with pytest.raises(rt.RtddError) as e:
+            c.solve_ex(d, m, m, 8, 8, 0, **kw)
+        assert e.value.status == 1, kw
+    with pytest.raises(rt.RtddError):
+        c.multigrid_level(0, 0)                                          # no multigrid solve has run on this context
+    assert c.solve_ex(d, m, m, 8, 8, 0, method=rt.METHOD_MULTIGRID, maxIterations=2)[0] == 2
+    assert c.multigrid_level(0, 4).shape == (8, 8)
+    with pytest.raises(rt.RtddError):
+        c.multigrid_level(5, 0)
     c.close()
 
 
