@@ -55,7 +55,7 @@ __device__ __forceinline__ float gs_value(float x, float omega, float xl, float 
 
 template <int LX, int NT, int G, bool CONTRACT, bool SOR>
 __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict__ X, float *__restrict__ Y, const uint32_t *__restrict__ M,
-                                                        const float *__restrict__ lut_g, int ip, int rows, int cols, int hx, int hy, int nsweeps, float omega) {
+                                                        const float *__restrict__ lut_g, int ip, int rows, int cols, int hx, int hy, int nsweeps, float omega, int gx, int gy, int xcd_tiles) {
     static_assert(G % 2 == 0, "the compile-time colour pattern needs an even number of rows per thread");
     constexpr int EW = 4 * LX, NTR = NT / LX;
     typedef float f4r __attribute__((ext_vector_type(4)));
@@ -63,6 +63,13 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict_
     __shared__ float4 edge[2][NTR][2][LX];
     __shared__ int published[NT / 64];
 
+    // XCD-aware placement as in sweep_blocked.hip: workgroup p (on XCD p % 8) takes tile (p % 8) * xcd_tiles + p / 8
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (xcd_tiles > 0) {
+        const int t = ((int)blockIdx.x & 7) * xcd_tiles + ((int)blockIdx.x >> 3);
+        if (t >= gx * gy) return;
+        bx = t % gx; by = t / gx;
+    }
     const int tid = threadIdx.x;
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
     if (tid < NT / 64) published[tid] = 0;
@@ -71,8 +78,8 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict_
     const int lx = tid % LX, tr = tid / LX;
     const int ntr = (int)blockDim.x / LX, eh = ntr * G;
     const int TW = EW - 2 * hx, TH = eh - 2 * hy;                  // hx multiple of 4, hy even, TH even: pixel (g,i) has colour (g+i)&1
-    const int x0 = blockIdx.x * TW - hx + 4 * lx;
-    const int y0 = blockIdx.y * TH - hy + tr * G;
+    const int x0 = bx * TW - hx + 4 * lx;
+    const int y0 = by * TH - hy + tr * G;
     const bool colok = x0 >= 0 && x0 < cols;
 
     f4r a[G];
@@ -215,7 +222,9 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
         const float *X = L.P(*plane, ip);
         float *Y = L.P(out, ip);
         const bool sor = omega != 1.0f;
-#define RTDD_RBGS_GO(NT_, C_, S_) hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_>), grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega)
+        const int xcd_tiles = single ? 0 : ((int)(grid.x * grid.y) + 7) / 8;
+        const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
+#define RTDD_RBGS_GO(NT_, C_, S_) hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_>), launch_grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega, (int)grid.x, (int)grid.y, xcd_tiles)
         const int variant = (big ? 4 : 0) | (ctx->opt.fp_contract ? 2 : 0) | (sor ? 1 : 0);
         switch (variant) {
             case 0: RTDD_RBGS_GO(512, false, false); break;

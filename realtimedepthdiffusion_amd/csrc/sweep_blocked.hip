@@ -142,12 +142,12 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     __shared__ float4 edge[2][NTR][2][LX];     // [buffer][thread row][0 = its top row, 1 = its bottom row][lane]
     __shared__ int published[NT / 64];         // per wave: number of sweeps whose edge rows it has published
 
-    // (gx, gy) = the grid of tiles.  xcd_tiles > 0 (persistent launches): a 1-D launch of 8 * xcd_tiles workgroups in which
+    // (gx, gy) = the grid of tiles.  xcd_tiles > 0 (every multi-tile launch): a 1-D launch of 8 * xcd_tiles workgroups in which
     // workgroup p -- dispatched to XCD p % 8 -- takes tile number (p % 8) * xcd_tiles + p / 8, so that each XCD owns a run
     // of consecutive tile numbers and most halo strips are traded inside one L2 instead of through memory (+3.5 % at 1080p);
     // surplus workgroups leave.
     int bx = blockIdx.x, by = blockIdx.y;
-    if (PERSIST && xcd_tiles > 0) {
+    if (xcd_tiles > 0) {
         const int t = ((int)blockIdx.x & 7) * xcd_tiles + ((int)blockIdx.x >> 3);
         if (t >= gx * gy) return;
         bx = t % gx; by = t / gx;           // (numbering the tiles in compact 8x4 patches instead of row bands measured the same)
@@ -524,9 +524,10 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             block_sweeps = T;
             m = n - done;
         }
-        // XCD-aware tile placement for persistent launches (RTDD_XCD_REMAP=0 turns it off)
+        // XCD-aware tile placement (RTDD_XCD_REMAP=0 turns it off): +1.5-4 % persistent (strips traded inside one L2), +8 % at 4K
+        // launch-per-block (a tile's halo is its neighbours' centre: the same XCD reads both)
         static const bool xcd_remap = !(getenv("RTDD_XCD_REMAP") && atoi(getenv("RTDD_XCD_REMAP")) == 0);
-        const int xcd_tiles = (persistent && xcd_remap) ? ((int)(grid.x * grid.y) + 7) / 8 : 0;   // (filling one XCD before the next measured the same)
+        const int xcd_tiles = (!single && xcd_remap) ? ((int)(grid.x * grid.y) + 7) / 8 : 0;   // (filling one XCD before the next measured the same)
         // outputs go to the two spare planes, then the pairs swap
         int free0 = -1, free1 = -1;
         for (int i = 0; i < 4; i++) if (i != *pk && i != *pm) { if (free0 < 0) free0 = i; else free1 = i; }
