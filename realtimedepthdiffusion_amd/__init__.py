@@ -120,6 +120,7 @@ class Context:
         if rc != RTDD_OK:
             raise RtddError(rc, lib().rtdd_status_string(rc).decode())
         self.device = device
+        self.last_cycles = 0                    # V-cycles of the last solve_ex / refine_depth (rtdd_solve_info.cycles)
         if stream is not None:
             self.set_stream(stream)
 
