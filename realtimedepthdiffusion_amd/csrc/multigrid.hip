@@ -34,9 +34,10 @@ struct MgLevel {
     float *SW() const { return A(3); }
     float *D() const { return A(4); }
     float *Pw(int k) const { return A(5 + k); }
-    float *e() const { return A(9); }
+    int ei = 9, ri = 11;              // e and r trade places after every tiled smoothing step (it writes e into r's plane)
+    float *e() const { return A(ei); }
     float *b() const { return A(10); }
-    float *r() const { return A(11); }
+    float *r() const { return A(ri); }
 };
 
 struct MgState {
@@ -270,6 +271,117 @@ __global__ __launch_bounds__(1024) void k_mg_gs_small(Stencil s, float *e, const
         }
 }
 
+// levels of at most PPT * 1024 points whose iterate (plus a ring of zeros) fits in 62 KB of LDS: the same smoothing step
+// with the iterate in LDS and every thread's points' couplings, diagonal and right-hand side in registers, so that a colour
+// step costs an LDS round trip and a barrier instead of a chain of global loads (8 160 points: 42 -> 6 us; the 30
+// coarsest sweeps: 123 -> 12 us).  Same sums in the same order as gs_sum: a missing neighbour is (coupling 0, value 0).
+template <int PPT>
+__global__ __launch_bounds__(1024) void k_mg_gs_lds(Stencil s, float *e, const float *b, int nsweeps, int reverse) {
+    extern __shared__ float le[];                       // (rows + 2) x (cols + 2)
+    const int R = s.rows, C = s.cols, LP = C + 2, tid = threadIdx.x;
+    for (int i = tid; i < (R + 2) * LP; i += 1024) le[i] = 0.0f;
+    __syncthreads();
+    for (int i = tid; i < R * C; i += 1024) le[(i / C + 1) * LP + i % C + 1] = e[(size_t)(i / C) * s.pitch + i % C];
+    float cw[PPT][8], dg[PPT], rb[PPT];
+    int at_[PPT], col[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int i = tid + k * 1024;
+        const bool in = i < R * C;
+        const int y = in ? i / C : 0, x = in ? i % C : 0;
+        at_[k] = (y + 1) * LP + x + 1;
+        col[k] = in ? (y & 1) * 2 + (x & 1) : -1;
+        dg[k] = in ? s.D[(size_t)y * s.pitch + x] : 0.0f;
+        rb[k] = in ? b[(size_t)y * s.pitch + x] : 0.0f;
+        cw[k][0] = coupling(s, y, x, 0, -1); cw[k][1] = coupling(s, y, x, 0, 1); cw[k][2] = coupling(s, y, x, -1, 0); cw[k][3] = coupling(s, y, x, 1, 0);
+        cw[k][4] = coupling(s, y, x, -1, -1); cw[k][5] = coupling(s, y, x, -1, 1); cw[k][6] = coupling(s, y, x, 1, -1); cw[k][7] = coupling(s, y, x, 1, 1);
+        if (!(dg[k] > 0.0f)) col[k] = -1;               // inactive points are never updated
+    }
+    __syncthreads();
+    for (int sw = 0; sw < nsweeps; sw++)
+        for (int c = 0; c < 4; c++) {
+            const int colour = reverse ? 3 - c : c;
+#pragma unroll
+            for (int k = 0; k < PPT; k++)
+                if (col[k] == colour) {
+                    const int a = at_[k];
+                    float v = rb[k];
+                    v += cw[k][0] * le[a - 1];
+                    v += cw[k][1] * le[a + 1];
+                    v += cw[k][2] * le[a - LP];
+                    v += cw[k][3] * le[a + LP];
+                    v += cw[k][4] * le[a - LP - 1];
+                    v += cw[k][5] * le[a - LP + 1];
+                    v += cw[k][6] * le[a + LP - 1];
+                    v += cw[k][7] * le[a + LP + 1];
+                    le[a] = v / dg[k];
+                }
+            __syncthreads();
+        }
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int i = tid + k * 1024;
+        if (i < R * C) e[(size_t)(i / C) * s.pitch + i % C] = le[at_[k]];
+    }
+}
+
+// larger levels: the same smoothing step tile by tile.  A workgroup takes a 64 x 32 tile plus a halo of 4 points per sweep
+// into LDS and runs ALL the colour steps of the smoothing step on it; what a missing outer neighbour spoils moves inwards one
+// point per colour step and stops short of the tile, so the tile's own points end up exactly as a level-wide sweep leaves
+// them.  One launch instead of 4 per sweep.  Tiles read each other's points, so the result goes to a second plane.
+constexpr int kTileX = 64, kTileY = 32;
+__global__ __launch_bounds__(1024) void k_mg_gs_tile(Stencil s, const float *e, float *out, const float *b, int nsweeps, int reverse) {
+    constexpr int PPT = 4;
+    extern __shared__ float le[];
+    const int H = 4 * nsweeps, EW = kTileX + 2 * H, EH = kTileY + 2 * H, LP = EW + 2, tid = threadIdx.x;
+    const int ox = blockIdx.x * kTileX - H, oy = blockIdx.y * kTileY - H;
+    for (int i = tid; i < (EH + 2) * LP; i += 1024) le[i] = 0.0f;
+    __syncthreads();
+    float cw[PPT][8], dg[PPT], rb[PPT];
+    int at_[PPT], col[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int i = tid + k * 1024;
+        const int ly = i / EW, lx = i % EW, y = oy + ly, x = ox + lx;
+        const bool in = i < EW * EH && y >= 0 && y < s.rows && x >= 0 && x < s.cols;
+        at_[k] = in ? (ly + 1) * LP + lx + 1 : 0;
+        col[k] = in ? (y & 1) * 2 + (x & 1) : -1;
+        dg[k] = in ? s.D[(size_t)y * s.pitch + x] : 0.0f;
+        rb[k] = in ? b[(size_t)y * s.pitch + x] : 0.0f;
+        if (in) le[at_[k]] = e[(size_t)y * s.pitch + x];
+        cw[k][0] = coupling(s, y, x, 0, -1); cw[k][1] = coupling(s, y, x, 0, 1); cw[k][2] = coupling(s, y, x, -1, 0); cw[k][3] = coupling(s, y, x, 1, 0);
+        cw[k][4] = coupling(s, y, x, -1, -1); cw[k][5] = coupling(s, y, x, -1, 1); cw[k][6] = coupling(s, y, x, 1, -1); cw[k][7] = coupling(s, y, x, 1, 1);
+        if (!(dg[k] > 0.0f)) col[k] = -1;
+    }
+    __syncthreads();
+    for (int sw = 0; sw < nsweeps; sw++)
+        for (int c = 0; c < 4; c++) {
+            const int colour = reverse ? 3 - c : c;
+#pragma unroll
+            for (int k = 0; k < PPT; k++)
+                if (col[k] == colour) {
+                    const int a = at_[k];
+                    float v = rb[k];
+                    v += cw[k][0] * le[a - 1];
+                    v += cw[k][1] * le[a + 1];
+                    v += cw[k][2] * le[a - LP];
+                    v += cw[k][3] * le[a + LP];
+                    v += cw[k][4] * le[a - LP - 1];
+                    v += cw[k][5] * le[a - LP + 1];
+                    v += cw[k][6] * le[a + LP - 1];
+                    v += cw[k][7] * le[a + LP + 1];
+                    le[a] = v / dg[k];
+                }
+            __syncthreads();
+        }
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int i = tid + k * 1024;
+        const int ly = i / EW, lx = i % EW, y = oy + ly, x = ox + lx;
+        if (i < EW * EH && ly >= H && ly < H + kTileY && lx >= H && lx < H + kTileX && y < s.rows && x < s.cols) out[(size_t)y * s.pitch + x] = le[at_[k]];
+    }
+}
+
 // b_c = P^T r, and the coarse correction starts from zero
 __global__ __launch_bounds__(256) void k_mg_restrict(const float *R, Interp ip, int frows, int fcols, int fpitch, float *bc, float *ec, int crows, int ccols, int cpitch) {
     const int J = blockIdx.x * 64 + (threadIdx.x & 63), I = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -346,9 +458,29 @@ static int mg_setup(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int col
     return RTDD_OK;
 }
 
-static void mg_smooth(rtdd_ctx *ctx, const MgLevel &l, int nsweeps, bool reverse, int *launches) {
-    if ((size_t)l.rows * l.cols <= (size_t)kSmallLevel) {
+static void mg_smooth(rtdd_ctx *ctx, MgLevel &l, int nsweeps, bool reverse, int *launches) {
+    const size_t npts = (size_t)l.rows * l.cols, lds = (size_t)(l.rows + 2) * (l.cols + 2) * sizeof(float);
+    if (npts <= 8192 && lds <= 62 * 1024) {
+        const Stencil v = view(l);
+        const int rev = reverse ? 1 : 0;
+        if (npts <= 1024) hipLaunchKernelGGL(k_mg_gs_lds<1>, dim3(1), dim3(1024), lds, ctx->stream, v, l.e(), l.b(), nsweeps, rev);
+        else if (npts <= 2048) hipLaunchKernelGGL(k_mg_gs_lds<2>, dim3(1), dim3(1024), lds, ctx->stream, v, l.e(), l.b(), nsweeps, rev);
+        else if (npts <= 4096) hipLaunchKernelGGL(k_mg_gs_lds<4>, dim3(1), dim3(1024), lds, ctx->stream, v, l.e(), l.b(), nsweeps, rev);
+        else hipLaunchKernelGGL(k_mg_gs_lds<8>, dim3(1), dim3(1024), lds, ctx->stream, v, l.e(), l.b(), nsweeps, rev);
+        (*launches)++;
+        return;
+    }
+    if (npts <= (size_t)kSmallLevel) {
         hipLaunchKernelGGL(k_mg_gs_small, dim3(1), dim3(1024), 0, ctx->stream, view(l), l.e(), l.b(), nsweeps, reverse ? 1 : 0);
+        (*launches)++;
+        return;
+    }
+    if (nsweeps <= 2) {                                   // (64 + 16) x (32 + 16) extended points = 4 per thread
+        const int H = 4 * nsweeps;
+        const size_t lds = (size_t)(kTileX + 2 * H + 2) * (kTileY + 2 * H + 2) * sizeof(float);
+        const dim3 g((l.cols + kTileX - 1) / kTileX, (l.rows + kTileY - 1) / kTileY);
+        hipLaunchKernelGGL(k_mg_gs_tile, g, dim3(1024), lds, ctx->stream, view(l), l.e(), l.r(), l.b(), nsweeps, reverse ? 1 : 0);
+        const int t = l.ei; l.ei = l.ri; l.ri = t;        // the result is in what was r's plane
         (*launches)++;
         return;
     }
@@ -371,7 +503,7 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     hipLaunchKernelGGL(k_mg_residual0, grid_for(rows, cols), dim3(256), 0, ctx->stream, L0.P(*plane, ip), L0.M(ip), ctx->lut_dev, (int)ip, rows, cols, lv[0].r(), lv[0].pitch);
     (*launches)++;
     for (int l = 0; l < last; l++) {                    // down
-        const MgLevel &f = lv[l], &c = lv[l + 1];
+        MgLevel &f = lv[l], &c = lv[l + 1];
         hipLaunchKernelGGL(k_mg_restrict, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, f.r(), interp(f), f.rows, f.cols, f.pitch, c.b(), c.e(), c.rows, c.cols, c.pitch);
         (*launches)++;
         if (l + 1 == last) { mg_smooth(ctx, c, kCoarsestSweeps, false, launches); break; }
@@ -380,7 +512,7 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
         (*launches)++;
     }
     for (int l = last - 1; l >= 1; l--) {                // up
-        const MgLevel &f = lv[l], &c = lv[l + 1];
+        MgLevel &f = lv[l], &c = lv[l + 1];
         hipLaunchKernelGGL(k_mg_prolong, grid_for(f.rows, f.cols), dim3(256), 0, ctx->stream, c.e(), c.rows, c.cols, c.pitch, interp(f), f.rows, f.cols, f.pitch, f.e(), f.pitch);
         (*launches)++;
         mg_smooth(ctx, f, kNu, true, launches);
@@ -395,9 +527,9 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     return RTDD_OK;
 }
 
-// Modelled duration of one V-cycle (seconds): ~100 launch-bound launches on the small levels + the streaming part
-// (measured 0.64 / 1.0 / 2.2 ms at 1080p / 4K / 8K, profiles/r01_config3_config5_timings.jsonl).
-static double cycle_seconds(int rows, int cols) { return 450e-6 + (double)rows * cols * 53e-12; }
+// Modelled duration of one V-cycle with its residual check (seconds): ~50 launch-bound launches on the small levels + the
+// streaming part (measured 0.39 / 0.72 / 2.12 ms at 1080p / 4K / 8K, scripts/config5_bench.py).
+static double cycle_seconds(int rows, int cols) { return 275e-6 + (double)rows * cols * 56e-12; }
 
 // alternative_seconds > 0 (RTDD_METHOD_AUTO): leave as soon as the cycles still needed at the rate of the last two,
 // priced by cycle_seconds, cost more than the alternative (SOR cycles from here).  A deterministic rule on the f32

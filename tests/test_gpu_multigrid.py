@@ -84,7 +84,7 @@ def test_auto_method_vcycles_then_sor_cycles(ctx, oracle, lut, rows, cols, seed)
     import math
     px = rows * cols
     sor_seconds = (((max(rows, cols) + 1) // 2) * 1.25 + 20.0) * max(px / 700e9, 2.5e-6)       # csrc/api.cpp
-    cycle_seconds = 450e-6 + px * 53e-12                                                          # csrc/multigrid.hip
+    cycle_seconds = 275e-6 + px * 56e-12                                                          # csrc/multigrid.hip
     want_cycles, before, before2, want_res = 0, math.inf, math.inf, math.nan
     while want_cycles < 60:
         _, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, 1, 1, 1e-30, 1)     # one cycle (the hierarchy only depends on the weights)
