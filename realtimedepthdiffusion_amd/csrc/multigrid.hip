@@ -10,10 +10,11 @@
 // Levels >= 1 hold a symmetric 9-point stencil as four couplings per point (E, S, SE, SW: to the right / lower /
 // lower-right / lower-left neighbour; the other four are the neighbours' own) and the diagonal D; D == 0 marks an
 // inactive point (e = 0 for ever).  P holds, per fine point, its interpolation weights towards the four coarse points
-// at the corners of its coarse cell.  Coarse smoother: four-colour Gauss-Seidel (colour = (y&1)*2 + (x&1)).
+// at the corners of its coarse cell.  Coarse smoother: four-colour Gauss-Seidel (colour = (y&1)*2 + (x&1)), one launch per
+// smoothing step: LDS tiles with a halo for large levels, the whole level in LDS for small ones.
 //
-// Every kernel is one thread per point with a fixed evaluation order and no atomics: oracle/rtdd_mg_oracle.c restates
-// the same arithmetic and the parity tests compare bit for bit.
+// Every point is computed with a fixed evaluation order and no atomics (the smoothers recompute halo points rather than
+// exchange them): oracle/rtdd_mg_oracle.c restates the same arithmetic and the parity tests compare bit for bit.
 #include "rtdd_internal.hpp"
 
 namespace rtdd {
@@ -21,7 +22,7 @@ namespace rtdd {
 constexpr float kTheta = 1e-4f;       // hierarchy only: weaker links become anchors
 constexpr int kNu = 2;                // pre- and post-smoothing sweeps on every level
 constexpr int kCoarsestSweeps = 30;
-constexpr int kSmallLevel = 16384;    // levels with at most this many points are smoothed by one workgroup in one launch
+constexpr int kSmallLevel = 16384;    // fallback single-workgroup smoother out of global memory (not used by the cycle as configured)
 
 struct MgLevel {
     int rows = 0, cols = 0, pitch = 0;
@@ -470,17 +471,18 @@ static void mg_smooth(rtdd_ctx *ctx, MgLevel &l, int nsweeps, bool reverse, int 
         (*launches)++;
         return;
     }
-    if (npts <= (size_t)kSmallLevel) {
-        hipLaunchKernelGGL(k_mg_gs_small, dim3(1), dim3(1024), 0, ctx->stream, view(l), l.e(), l.b(), nsweeps, reverse ? 1 : 0);
-        (*launches)++;
-        return;
-    }
     if (nsweeps <= 2) {                                   // (64 + 16) x (32 + 16) extended points = 4 per thread
         const int H = 4 * nsweeps;
         const size_t lds = (size_t)(kTileX + 2 * H + 2) * (kTileY + 2 * H + 2) * sizeof(float);
         const dim3 g((l.cols + kTileX - 1) / kTileX, (l.rows + kTileY - 1) / kTileY);
         hipLaunchKernelGGL(k_mg_gs_tile, g, dim3(1024), lds, ctx->stream, view(l), l.e(), l.r(), l.b(), nsweeps, reverse ? 1 : 0);
         const int t = l.ei; l.ei = l.ri; l.ri = t;        // the result is in what was r's plane
+        (*launches)++;
+        return;
+    }
+    // not reached by the cycle as configured (a coarsest level is at most 256 points): many sweeps on a level too large for LDS
+    if (npts <= (size_t)kSmallLevel) {
+        hipLaunchKernelGGL(k_mg_gs_small, dim3(1), dim3(1024), 0, ctx->stream, view(l), l.e(), l.b(), nsweeps, reverse ? 1 : 0);
         (*launches)++;
         return;
     }
