@@ -31,6 +31,11 @@ __device__ __forceinline__ float div3(float n, float d, float y) {     // see sw
 }
 
 // SOR: successive over-relaxation, x <- clamp(x + omega (clamp(gs) - x)); omega = 1 is plain Gauss-Seidel and takes the !SOR path.
+__device__ __forceinline__ float rcp_rn(float d) {       // == 1.0f/d for every normal d with a normal reciprocal (sweep_blocked.hip)
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
+}
+
 template <bool CONTRACT, bool FAST, bool SOR>
 __device__ __forceinline__ float gs_value(float x, float omega, float xl, float xr, float xu, float xd, float wl, float wr, float wu, float wd, float cnt, float rcp) {
     float sum = 0.0f;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict_
             float c = 0.0f;
             c += wl; c += wr[g][i]; c += wu; c += wd[g][i];
             cnt[g][i] = c == 0.0f ? 1.0f : c;
-            rcp[g][i] = 1.0f / cnt[g][i];
+            rcp[g][i] = rcp_rn(cnt[g][i]);
             unsafe |= cnt[g][i] < 0x1p-126f;
         }
     const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;

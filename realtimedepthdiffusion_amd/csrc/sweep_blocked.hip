@@ -127,6 +127,14 @@ __device__ unsigned long long g_xphase[4096][6];
 #define RTDD_XT_BEGIN do {} while (0)
 #endif
 
+// RN(1/d) for a normal d with a normal reciprocal: v_rcp_f32 (1 ulp) + one Newton step.  Equal to the IEEE quotient 1.0f/d for
+// EVERY such f32 (all 4 227 858 434 of them checked on the GPU, scripts/ubench/rcp_exhaustive.hip, profiles/r01_rcp_exhaustive.log):
+// 3 VALU ops instead of the 11 of the full divide, in the per-launch setup of every pixel.
+__device__ __forceinline__ float rcp_rn(float d) {
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
+}
+
 template <int LX, int NT, int G, bool CONTRACT, bool PERSIST>
 __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_blocked(float *Xk, float *Xm, float *Yk, float *Ym,
                                                       const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
             float c = 0.0f;                    // count accumulates left, right, up, down (:82,88,94,100)
             c += wl; c += wr[g][i]; c += wu; c += wd[g][i];
             cnt[g][i] = c == 0.0f ? 1.0f : c;
-            rcp[g][i] = 1.0f / cnt[g][i];           // correctly rounded reciprocal, once per launch
+            rcp[g][i] = rcp_rn(cnt[g][i]);          // correctly rounded reciprocal, once per launch
             unsafe |= cnt[g][i] < 0x1p-126f;
         }
     const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
