@@ -411,6 +411,17 @@ __global__ __launch_bounds__(256) void k_mg_prolong(const float *ec, int crows, 
     T[(size_t)y * tpitch + x] += v;
 }
 
+// x <- clamp(x + alpha (x - x_prev)): removes an error component that shrinks by lambda = alpha / (1 + alpha) per cycle
+template <bool CONTRACT>
+__global__ __launch_bounds__(256) void k_mg_extrapolate(float *X, const float *Xp, int ip, int rows, int cols, float alpha) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const size_t p = (size_t)y * ip + x;
+    const float v = X[p], d = v - Xp[p];
+    const float w = CONTRACT ? __builtin_fmaf(alpha, d, v) : v + alpha * d;
+    X[p] = __builtin_amdgcn_fmed3f(w, 0.0f, 255.0f);
+}
+
 inline dim3 grid_for(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
 inline Stencil view(const MgLevel &l) { return Stencil{l.E(), l.S(), l.SE(), l.SW(), l.D(), l.rows, l.cols, l.pitch}; }
 inline Interp interp(const MgLevel &l) { return Interp{l.Pw(0), l.Pw(1), l.Pw(2), l.Pw(3)}; }
@@ -495,11 +506,13 @@ static void mg_smooth(rtdd_ctx *ctx, MgLevel &l, int nsweeps, bool reverse, int 
 }
 
 // one V(kNu,kNu) cycle on the level-0 iterate in plane *plane
+// The plane holding the iterate on entry is left untouched (the extrapolation needs x_{k-1}): the result lands in a third one.
 static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int *plane, int *launches) {
+    const int entry = *plane;
     auto &lv = ctx->mg->lv;
     const int last = (int)lv.size() - 1;
     int ln = 0, rc;
-    if (last == 0) return launch_rbgs_blocked(ctx, L0, ip, rows, cols, 2 * kNu, 1.0f, plane, launches);
+    if (last == 0) return launch_rbgs_blocked(ctx, L0, ip, rows, cols, 2 * kNu, 1.0f, plane, launches, -1);
     if ((rc = launch_rbgs_blocked(ctx, L0, ip, rows, cols, kNu, 1.0f, plane, &ln)) != RTDD_OK) return rc;
     *launches += ln;
     hipLaunchKernelGGL(k_mg_residual0, grid_for(rows, cols), dim3(256), 0, ctx->stream, L0.P(*plane, ip), L0.M(ip), ctx->lut_dev, (int)ip, rows, cols, lv[0].r(), lv[0].pitch);
@@ -524,7 +537,7 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     (*launches)++;
     RTDD_LAUNCH_CHECK(ctx, "multigrid cycle");
     ln = 0;
-    if ((rc = launch_rbgs_blocked(ctx, L0, ip, rows, cols, kNu, 1.0f, plane, &ln)) != RTDD_OK) return rc;
+    if ((rc = launch_rbgs_blocked(ctx, L0, ip, rows, cols, kNu, 1.0f, plane, &ln, entry)) != RTDD_OK) return rc;
     *launches += ln;
     return RTDD_OK;
 }
@@ -542,7 +555,9 @@ int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     if (rc != RTDD_OK) return rc;
     *cycles_done = 0;
     float before = INFINITY, before2 = INFINITY;         // residuals one and two checks ago
+    int since = 0;                                       // cycles since the start or the last extrapolation
     while (*cycles_done < max_cycles) {
+        const int prev_plane = *plane;                   // x_{k-1} stays here during the cycle
         if ((rc = mg_vcycle(ctx, L0, ip, rows, cols, plane, launches)) != RTDD_OK) return rc;
         (*cycles_done)++;
         if (tolerance > 0.0f && (*cycles_done % check_every == 0 || *cycles_done == max_cycles)) {
@@ -553,6 +568,20 @@ int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
                 if (!(rate < 1.0)) break;
                 const double needed = ceil(log((double)*residual / (double)tolerance) / -log(rate));
                 if (needed * cycle_seconds(rows, cols) > alternative_seconds) break;
+            }
+            // Vector extrapolation.  Once the residual shrinks by the same factor lambda two cycles in a row, what is left is
+            // one slowly decaying family, e_k = lambda e_{k-1}, and x_k + lambda/(1-lambda) (x_k - x_{k-1}) removes it
+            // (8K: 19 -> 11 cycles; scripts/mg_extrapolation_probe.py).  Decided on the f32 residuals alone: reproducible.
+            since++;
+            if (check_every == 1 && since >= 3 && before2 < INFINITY && ctx->mg->lv.size() > 1 && *plane != prev_plane && *cycles_done < max_cycles) {
+                const double l1 = (double)*residual / (double)before, l0 = (double)before / (double)before2;
+                if (l1 > 0.3 && l1 < 0.995 && fabs(l1 - l0) <= 0.05 * l1) {
+                    const float alpha = (float)(l1 / (1.0 - l1));
+                    if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_mg_extrapolate<true>, grid_for(rows, cols), dim3(256), 0, ctx->stream, L0.P(*plane, ip), L0.P(prev_plane, ip), (int)ip, rows, cols, alpha);
+                    else hipLaunchKernelGGL(k_mg_extrapolate<false>, grid_for(rows, cols), dim3(256), 0, ctx->stream, L0.P(*plane, ip), L0.P(prev_plane, ip), (int)ip, rows, cols, alpha);
+                    (*launches)++;
+                    since = 0;
+                }
             }
             before2 = before; before = *residual;
         }

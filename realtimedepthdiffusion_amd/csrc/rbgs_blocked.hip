@@ -203,7 +203,7 @@ static bool rbgs_prefers_big_tile(const rtdd_ctx *ctx, int rows, int cols) {
 }
 
 // n full sweeps from plane *plane; on return *plane names the plane holding the result.
-int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, float omega, int *plane, int *launches) {
+int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, float omega, int *plane, int *launches, int keep) {
     // two shapes: 128x64 (512 threads, 16 px/thread, two workgroups per CU) and 128x128 (1024 threads, one per CU); an image
     // that fits ONE 128x128 tile runs all its sweeps in one launch.  RTDD_OPT_TILE 1/2 forces a shape, RTDD_OPT_TEMPORAL_DEPTH the
     // sweeps per launch (default 8 = 16 half-sweeps = a 16-pixel halo).
@@ -223,7 +223,7 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
         const int TW = EW - 2 * hx, TH = eh - 2 * hy;
         const dim3 grid((cols + TW - 1) / TW, (rows + TH - 1) / TH);
         int out = -1;
-        for (int i = 0; i < 4; i++) if (i != *plane) { out = i; break; }
+        for (int i = 0; i < 4; i++) if (i != *plane && i != keep) { out = i; break; }      // `keep`: a plane the caller still needs (-1: none)
         const float *X = L.P(*plane, ip);
         float *Y = L.P(out, ip);
         const bool sor = omega != 1.0f;

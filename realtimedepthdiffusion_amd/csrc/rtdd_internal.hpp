@@ -134,7 +134,7 @@ int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
 void mg_release(rtdd_ctx *ctx);
 int mg_download(rtdd_ctx *ctx, int level, int which, float *host, int *rows, int *cols);
 
-int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, float omega, int *plane, int *launches);
+int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, float omega, int *plane, int *launches, int keep = -1);
 
 // ---- image_kernels.hip --------------------------------------------------------------------------
 int launch_convert(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, float *dst, size_t dstPitch,

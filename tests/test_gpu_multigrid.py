@@ -81,24 +81,9 @@ def test_auto_method_vcycles_then_sor_cycles(ctx, oracle, lut, rows, cols, seed)
     its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_AUTO, maxIterations=200000, tolerance=1e-4)
     cycles = ctx.last_cycles
     x = p["depth"].copy()
-    import math
     px = rows * cols
     sor_seconds = (((max(rows, cols) + 1) // 2) * 1.25 + 20.0) * max(px / 700e9, 2.5e-6)       # csrc/api.cpp
-    cycle_seconds = 275e-6 + px * 56e-12                                                          # csrc/multigrid.hip
-    want_cycles, before, before2, want_res = 0, math.inf, math.inf, math.nan
-    while want_cycles < 60:
-        _, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, 1, 1, 1e-30, 1)     # one cycle (the hierarchy only depends on the weights)
-        want_cycles += 1
-        if want_res <= 1e-4:
-            break
-        if before2 < math.inf:
-            rate = math.sqrt(float(np.float32(want_res)) / float(np.float32(before2)))
-            if not rate < 1.0:
-                break
-            needed = math.ceil(math.log(float(np.float32(want_res)) / float(np.float32(1e-4))) / -math.log(rate))
-            if needed * cycle_seconds > sor_seconds:
-                break
-        before2, before = before, want_res
+    want_cycles, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, 1, 60, 1e-4, 1, alternative_seconds=sor_seconds)
     want_its = 0
     if want_res > 1e-4:
         want_its, want_res = _sor_cycles_restated(oracle, x, idx, p["mask"], lut, 1, 1e-4, 200000, halve=True)
