@@ -36,6 +36,13 @@ __device__ __forceinline__ float rcp_rn(float d) {       // == 1.0f/d for every 
     return __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
 }
 
+// write-through (sc1) 16-byte store for the inter-workgroup hand-off of the persistent mode (see sweep_blocked.hip)
+__device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+
 template <bool CONTRACT, bool FAST, bool SOR>
 __device__ __forceinline__ float gs_value(float x, float omega, float xl, float xr, float xu, float xd, float wl, float wr, float wu, float wd, float cnt, float rcp) {
     float sum = 0.0f;
@@ -58,9 +65,15 @@ __device__ __forceinline__ float gs_value(float x, float omega, float xl, float 
 
 }  // namespace
 
-template <int LX, int NT, int G, bool CONTRACT, bool SOR>
-__global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict__ X, float *__restrict__ Y, const uint32_t *__restrict__ M,
-                                                        const float *__restrict__ lut_g, int ip, int rows, int cols, int hx, int hy, int nsweeps, float omega, int gx, int gy, int xcd_tiles) {
+// PERSIST: ONE launch for all nsweeps.  The workgroup keeps its tile in registers and, every block_sweeps sweeps (halo =
+// 2 * block_sweeps), trades the strips of its centre that the neighbours' halos overlap -- the protocol of
+// sweep_blocked.hip's persistent mode (write-through stores, drain, barrier, per-tile flag, bounded poll, one agent
+// acquire).  Exchange buffers alternate between Y and the input plane X by block parity; the result goes to the buffer of
+// the last block's parity.  Needs every workgroup resident at once (host: grid <= #CUs).
+template <int LX, int NT, int G, bool CONTRACT, bool SOR, bool PERSIST>
+__global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, const uint32_t *__restrict__ M,
+                                                        const float *__restrict__ lut_g, int ip, int rows, int cols, int hx, int hy, int nsweeps, float omega, int gx, int gy, int xcd_tiles,
+                                                        int block_sweeps, int *sync_words) {
     static_assert(G % 2 == 0, "the compile-time colour pattern needs an even number of rows per thread");
     constexpr int EW = 4 * LX, NTR = NT / LX;
     typedef float f4r __attribute__((ext_vector_type(4)));
@@ -177,14 +190,55 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(const float *__restrict_
 
     // colour 0 of the oracle = (x + y) even.  Pixel (g, i) sits at (x0 + i, y0 + g) with x0 % 4 == 0 and y0 even, so its
     // image colour is (g + i) & 1.  (y0 = by*TH - hy + tr*G: every term even.)
-    int h = 0;
-    for (int s = 0; s < nsweeps; s++) {
-        if (!wave_unsafe) { half(0, h, std::true_type{}); half(1, h + 1, std::true_type{}); }
-        else { half(0, h, std::false_type{}); half(1, h + 1, std::false_type{}); }
-        h += 2;
-    }
-
     const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
+    const int tile_id = by * gx + bx;
+    int h = 0, s = 0, blk = 0;
+    for (;; blk++) {
+        const int s_end = min(s + block_sweeps, nsweeps);
+        for (; s < s_end; s++) {
+            if (!wave_unsafe) { half(0, h, std::true_type{}); half(1, h + 1, std::true_type{}); }
+            else { half(0, h, std::false_type{}); half(1, h + 1, std::false_type{}); }
+            h += 2;
+        }
+        if (!PERSIST || s >= nsweeps) break;
+        float *Ex = (blk & 1) ? X : Y;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int y = y0 + g, ty = tr * G + g;
+            const bool central = xin && ty >= hy && ty < eh - hy && y < rows;
+            const bool band = ty < 2 * hy || ty >= eh - 2 * hy || 4 * lx < 2 * hx || 4 * lx >= EW - 2 * hx;
+            if (central && band) store_sc1((float4 *)(Ex + (size_t)y * ip + x0), make_float4(a[g][0], a[g][1], a[g][2], a[g][3]));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every storing wave drains its write-through stores
+        __syncthreads();
+        int *flags = sync_words + 16;
+        if (tid == 0) __hip_atomic_store(&flags[tile_id], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 9 && tid != 4) {                                       // lane i polls neighbour (i%3-1, i/3-1)
+            const int nx = bx + tid % 3 - 1, ny = by + tid / 3 - 1;
+            if (nx >= 0 && ny >= 0 && nx < gx && ny < gy) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&flags[ny * gx + nx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < blk + 1) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 22)) { __hip_atomic_store(&sync_words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never hang
+                }
+            }
+        }
+        if (tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int y = y0 + g, ty = tr * G + g;
+            const bool central = xin && ty >= hy && ty < eh - hy;
+            if (colok && y >= 0 && y < rows && !central) {             // a halo pixel inside the image: some neighbour's centre
+                const float4 vx = *(const float4 *)(Ex + (size_t)y * ip + x0);
+                const float xv[4] = {vx.x, vx.y, vx.z, vx.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) a[g][i] = x0 + i < cols ? xv[i] : 0.0f;
+            }
+        }
+    }
+    if (PERSIST && (blk & 1)) Y = X;                                     // the last block's parity names the result buffer
+
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const int y = y0 + g, ty = tr * G + g;
@@ -215,21 +269,37 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
     int done = 0;
     *launches = 0;
     while (done < n) {
-        const int m = single ? n - done : (n - done < depth ? n - done : depth);
+        int m = single ? n - done : (n - done < depth ? n - done : depth);
         const int hy = single ? 0 : 2 * m, hx = single ? 0 : (2 * m + 3) / 4 * 4;
         int nthreads = big ? 1024 : 512;
         if (single) { const int need = (rows + 3) / 4 * 32; nthreads = (need + 63) / 64 * 64; if (nthreads > 1024) nthreads = 1024; }
         const int eh = nthreads / 32 * 4;
         const int TW = EW - 2 * hx, TH = eh - 2 * hy;
         const dim3 grid((cols + TW - 1) / TW, (rows + TH - 1) / TH);
+        // persistent: all remaining sweeps in one launch when every tile is resident at once (as in sweep_blocked.hip).  Pays only
+        // when the chip is at least half full (1080p: 727 -> 767 Gpx-sweeps/s); smaller grids are launch-bound and an exchange
+        // costs more than a launch there (540x960: 265 -> 250), so they keep one launch per block.
+        const bool persistent = !single && ctx->opt.persistent && (int)(grid.x * grid.y) <= ctx->num_cus && (int)(grid.x * grid.y) >= ctx->num_cus / 2 && grid.x * grid.y <= 1000 &&
+                                n - done > m && m == depth && hx <= TW && hy <= TH;
+        int block_sweeps = m;
+        if (persistent) {
+            if (!ctx->sync_words) {
+                RTDD_HIP(ctx, hipMalloc((void **)&ctx->sync_words, 1024 * sizeof(int) + 64));
+                RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words, 0, 64, ctx->stream));
+            }
+            RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + 16, 0, 1024 * sizeof(int), ctx->stream));
+            ctx->persistent_used = true;
+            m = n - done;
+        }
         int out = -1;
         for (int i = 0; i < 4; i++) if (i != *plane && i != keep) { out = i; break; }      // `keep`: a plane the caller still needs (-1: none)
-        const float *X = L.P(*plane, ip);
+        float *X = L.P(*plane, ip);
         float *Y = L.P(out, ip);
         const bool sor = omega != 1.0f;
         const int xcd_tiles = single ? 0 : ((int)(grid.x * grid.y) + 7) / 8;
         const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
-#define RTDD_RBGS_GO(NT_, C_, S_) hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_>), launch_grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega, (int)grid.x, (int)grid.y, xcd_tiles)
+#define RTDD_RBGS_GO(NT_, C_, S_) do { if (persistent) hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_, true>), launch_grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega, (int)grid.x, (int)grid.y, xcd_tiles, block_sweeps, ctx->sync_words); \
+        else hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_, false>), launch_grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega, (int)grid.x, (int)grid.y, xcd_tiles, block_sweeps, ctx->sync_words); } while (0)
         const int variant = (big ? 4 : 0) | (ctx->opt.fp_contract ? 2 : 0) | (sor ? 1 : 0);
         switch (variant) {
             case 0: RTDD_RBGS_GO(512, false, false); break;
@@ -242,9 +312,10 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
             default: RTDD_RBGS_GO(1024, true, true); break;
         }
 #undef RTDD_RBGS_GO
-        // pixels outside the written-back centre keep stale values in the output plane only where no tile writes them:
-        // every image pixel belongs to exactly one tile's centre, so the output plane is complete.
-        *plane = out;
+        // every image pixel belongs to exactly one tile's centre, so the result plane is complete; it is the spare plane, or --
+        // after an odd number of persistent exchanges -- the input plane again
+        const int nblocks = (m + block_sweeps - 1) / block_sweeps;
+        if (((nblocks - 1) & 1) == 0) *plane = out;
         done += m;
         (*launches)++;
     }

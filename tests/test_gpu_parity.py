@@ -226,6 +226,32 @@ def test_rbgs_blocked_bit_exact(ctx, oracle, lut, rows, cols, sweeps, contract, 
     ctx.set_option(rt.OPT_FP_CONTRACT, 1)
 
 
+@pytest.mark.parametrize("rows,cols,tile,depth", [(1080, 1920, 0, 0), (1080, 1920, 2, 6), (720, 1280, 1, 4), (900, 1600, 2, 4)])
+def test_rbgs_persistent_mode_bit_exact(ctx, oracle, lut, rows, cols, tile, depth):
+    """The red-black kernel's persistent mode (one launch, halo strips traded every `depth` sweeps) against the oracle's sweep,
+    with the launch-per-block path beside it; sweep counts that end in a short last block; plain and over-relaxed."""
+    p = make_problem(rows, cols, seed=rows + cols)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    idx = oracle.index_to_weight(p["gray"], None, 0, 0)
+    m, g = up(p["mask"]), up(p["gray"])
+    ctx.set_option(rt.OPT_TILE, tile); ctx.set_option(rt.OPT_TEMPORAL_DEPTH, depth)
+    for sweeps, omega in ((27, 1.0), (32, 1.9)):
+        x = p["depth"].copy()
+        for _ in range(sweeps):
+            oracle.rbgs_sweep(x, idx, p["mask"], lut, 1, omega)
+        for persistent in (1, 0):
+            ctx.set_option(rt.OPT_PERSISTENT, persistent)
+            ctx.profile_enable(True)
+            for rep in range(2):
+                d = up(p["depth"])
+                ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=sweeps, tolerance=0.0, relaxation=omega)
+                launches = ctx.profile().launches
+                assert (launches == 1) == bool(persistent), (launches, persistent)
+                assert_bit_equal(down(d), x, f"rbgs persistent={persistent} {rows}x{cols} tile {tile} depth {depth} x{sweeps} omega {omega} rep {rep}")
+            ctx.profile_enable(False)
+    ctx.set_option(rt.OPT_PERSISTENT, 1); ctx.set_option(rt.OPT_TILE, 0); ctx.set_option(rt.OPT_TEMPORAL_DEPTH, 0)
+
+
 def _sor_cycles_restated(oracle, x, idx, mask, lut, contract, tol, max_its, halve=False):
     """rtdd_solve_ex's RTDD_RELAXATION_AUTO schedule (include/rtdd.h, csrc/api.cpp) driven through the oracle's sweep and residual."""
     import math
