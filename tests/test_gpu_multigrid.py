@@ -90,3 +90,53 @@ def test_auto_method_vcycles_then_sor_cycles(ctx, oracle, lut, rows, cols, seed)
     assert (cycles, its, res) == (want_cycles, want_its, np.float32(want_res)) and res <= 1e-4
     assert cycles >= 3 and its > 0            # the rule needs two earlier residuals; at these sizes the sweeps always finish
     assert_bit_equal(down(d), x, "auto")
+
+
+def test_randomised_geometries_all_extension_methods(ctx, oracle, lut):
+    """40 random draws (shape incl. 1-pixel-wide and tiny, Dirichlet density from almost none to almost all, random start,
+    contraction, method): V-cycles with residual checks (and so the extrapolation), SOR with a random factor, SOR cycles and
+    the automatic method -- every result, count and residual identical to the restatement's."""
+    from test_gpu_parity import _sor_cycles_restated
+    rng = np.random.default_rng(20261004)
+    for trial in range(40):
+        rows = int(rng.integers(1, 330)); cols = int(rng.integers(1, 400))
+        if trial % 9 == 0: rows = int(rng.integers(1, 5))
+        if trial % 13 == 0: cols = int(rng.integers(1, 5))
+        contract = int(rng.integers(0, 2))
+        p = make_problem(rows, cols, seed=3000 + trial, coverage=float(rng.choice([0.002, 0.05, 0.1, 0.5, 0.95])))
+        if (p["mask"] == 255).sum() == 0:
+            p["mask"][rows // 2, cols // 2] = 255; p["depth"][rows // 2, cols // 2] = 128
+        free = p["mask"] != 255
+        p["depth"][free] = rng.uniform(0, 255, int(free.sum())).astype(np.float32)
+        ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+        ctx.set_option(rt.OPT_FP_CONTRACT, contract)
+        idx = oracle.index_to_weight(p["gray"], None, 0, 0)
+        d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+        x = p["depth"].copy()
+        kind = trial % 4
+        what = f"trial {trial}: {rows}x{cols} contract {contract} kind {kind}"
+        if kind == 0:                                   # V-cycles to a residual (check every cycle -> extrapolation allowed)
+            its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_MULTIGRID, maxIterations=12, tolerance=1e-4)
+            want_its, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, contract, 12, 1e-4, 1)
+            assert (its, res) == (want_its, np.float32(want_res)), what
+        elif kind == 1:                                 # red-black SOR, fixed count
+            om = float(rng.uniform(0.5, 1.98)); n = int(rng.integers(1, 40))
+            its, _ = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=n, relaxation=om)
+            for _ in range(n):
+                oracle.rbgs_sweep(x, idx, p["mask"], lut, contract, om)
+            assert its == n, what
+        elif kind == 2:                                 # SOR cycles, capped
+            its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=1500, tolerance=1e-4, relaxation=rt.RELAXATION_AUTO)
+            want_its, want_res = _sor_cycles_restated(oracle, x, idx, p["mask"], lut, contract, 1e-4, 1500)
+            assert (its, res) == (want_its, np.float32(want_res)), what
+        else:                                           # automatic: V-cycles, then SOR cycles of half length, capped
+            its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_AUTO, maxIterations=1200, tolerance=1e-4)
+            px = rows * cols
+            sor_seconds = (((max(rows, cols) + 1) // 2) * 1.25 + 20.0) * max(px / 700e9, 2.5e-6)
+            want_cycles, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, contract, 60, 1e-4, 1, alternative_seconds=sor_seconds)
+            want_its = 0
+            if want_res > 1e-4:
+                want_its, want_res = _sor_cycles_restated(oracle, x, idx, p["mask"], lut, contract, 1e-4, 1200, halve=True)
+            assert (ctx.last_cycles, its, res) == (want_cycles, want_its, np.float32(want_res)), what
+        assert_bit_equal(down(d), x, what)
+    ctx.set_option(rt.OPT_FP_CONTRACT, 1)
