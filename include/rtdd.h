@@ -50,7 +50,9 @@ enum rtdd_method {
     RTDD_METHOD_CHEBYSHEV_JACOBI = 0,
     RTDD_METHOD_RED_BLACK_GS = 1,
     RTDD_METHOD_MULTIGRID = 2,       /* V(2,2) cycles, operator-dependent interpolation; maxIterations counts CYCLES,
-                                      * checkEvery defaults to 1 cycle */
+                                      * checkEvery defaults to 1 cycle.  With tolerance > 0 and a check every cycle the driver
+                                      * also extrapolates (x + l/(1-l) (x - x_prev)) whenever the residual ratio l of two
+                                      * consecutive cycles has settled; tolerance <= 0 runs plain cycles */
     RTDD_METHOD_AUTO = 3             /* to a tolerance (required): V-cycles while they pay (until the tolerance, 60 cycles, or until
                                       * the cycles still needed at the current rate are modelled dearer than the sweeps), then red-black SOR cycles
                                       * (RTDD_RELAXATION_AUTO, started at half length: N = max(rows,cols)/2 rounded up) from there;
