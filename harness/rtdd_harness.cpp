@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 
+#include <zlib.h>
+
 #include "rtdd.h"
 
 struct Pnm { int w = 0, h = 0, ch = 0; std::vector<unsigned char> px; };
@@ -52,6 +54,91 @@ static bool write_pnm(const std::string &path, int w, int h, int ch, const unsig
     std::fclose(f);
     return ok;
 }
+
+// ---- PNG (the dataset's annotations are PNG, src/main.cpp:158-161; the reference saves PNG, :312-316) on zlib alone -----------
+// Reader: 8-bit, non-interlaced, gray / gray+alpha / RGB / RGBA / palette; alpha is dropped.  Writer: 8-bit gray or RGB, filter 0.
+static uint32_t be32(const unsigned char *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+static bool read_png(const std::string &path, Pnm &im) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<unsigned char> file;
+    unsigned char buf[65536]; size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
+    std::fclose(f);
+    static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    if (file.size() < 8 || std::memcmp(file.data(), sig, 8)) return false;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<unsigned char> idat, plte;
+    for (size_t p = 8; p + 12 <= file.size();) {
+        const uint32_t len = be32(&file[p]);
+        if (p + 12 + len > file.size()) return false;
+        const char *type = (const char *)&file[p + 4];
+        const unsigned char *data = &file[p + 8];
+        if (!std::memcmp(type, "IHDR", 4) && len >= 13) { im.w = (int)be32(data); im.h = (int)be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; }
+        else if (!std::memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
+        else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+        else if (!std::memcmp(type, "IEND", 4)) break;
+        p += 12 + len;
+    }
+    const int spp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;      // samples per pixel in the file
+    if (depth != 8 || !spp || interlace || im.w <= 0 || im.h <= 0) return false;
+    const size_t stride = (size_t)im.w * spp;
+    std::vector<unsigned char> raw((stride + 1) * im.h);
+    uLongf rawlen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
+    std::vector<unsigned char> prev(stride, 0), cur(stride);
+    im.ch = (ctype == 0 || ctype == 4) ? 1 : 3;
+    im.px.resize((size_t)im.w * im.h * im.ch);
+    for (int y = 0; y < im.h; y++) {
+        const unsigned char *line = &raw[(stride + 1) * y];
+        const int ft = line[0];
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= (size_t)spp ? cur[i - spp] : 0, b = prev[i], c = i >= (size_t)spp ? prev[i - spp] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a; else if (ft == 2) pred = b; else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) { const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            else if (ft != 0) return false;
+            cur[i] = (unsigned char)(line[1 + i] + pred);
+        }
+        for (int x = 0; x < im.w; x++) {
+            unsigned char *o = &im.px[((size_t)y * im.w + x) * im.ch];
+            const unsigned char *s = &cur[(size_t)x * spp];
+            if (ctype == 0 || ctype == 4) o[0] = s[0];
+            else if (ctype == 3) { if ((size_t)s[0] * 3 + 2 >= plte.size()) return false; o[0] = plte[s[0] * 3]; o[1] = plte[s[0] * 3 + 1]; o[2] = plte[s[0] * 3 + 2]; }
+            else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
+        }
+        prev.swap(cur);
+    }
+    return true;
+}
+
+static bool write_png(const std::string &path, int w, int h, int ch, const unsigned char *px) {
+    std::vector<unsigned char> raw(((size_t)w * ch + 1) * h);
+    for (int y = 0; y < h; y++) { raw[((size_t)w * ch + 1) * y] = 0; std::memcpy(&raw[((size_t)w * ch + 1) * y + 1], px + (size_t)y * w * ch, (size_t)w * ch); }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    auto chunk = [&](const char *type, const unsigned char *data, uint32_t len) {
+        unsigned char hdr[8] = {(unsigned char)(len >> 24), (unsigned char)(len >> 16), (unsigned char)(len >> 8), (unsigned char)len, (unsigned char)type[0], (unsigned char)type[1], (unsigned char)type[2], (unsigned char)type[3]};
+        uLong crc = crc32(0L, hdr + 4, 4);
+        if (len) crc = crc32(crc, data, len);
+        const unsigned char tail[4] = {(unsigned char)(crc >> 24), (unsigned char)(crc >> 16), (unsigned char)(crc >> 8), (unsigned char)crc};
+        std::fwrite(hdr, 1, 8, f); if (len) std::fwrite(data, 1, len, f); std::fwrite(tail, 1, 4, f);
+    };
+    static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    std::fwrite(sig, 1, 8, f);
+    const unsigned char ihdr[13] = {(unsigned char)(w >> 24), (unsigned char)(w >> 16), (unsigned char)(w >> 8), (unsigned char)w, (unsigned char)(h >> 24), (unsigned char)(h >> 16), (unsigned char)(h >> 8), (unsigned char)h,
+                                    8, (unsigned char)(ch == 3 ? 2 : 0), 0, 0, 0};
+    chunk("IHDR", ihdr, 13); chunk("IDAT", comp.data(), (uint32_t)clen); chunk("IEND", nullptr, 0);
+    return std::fclose(f) == 0;
+}
+
+static bool ends_with(const std::string &s, const char *suffix) { const size_t n = std::strlen(suffix); return s.size() >= n && !s.compare(s.size() - n, n, suffix); }
+static bool read_image(const std::string &path, Pnm &im) { return ends_with(path, ".png") ? read_png(path, im) : read_pnm(path, im); }
+static bool write_image(const std::string &path, int w, int h, int ch, const unsigned char *px) { return ends_with(path, ".png") ? write_png(path, w, h, ch, px) : write_pnm(path, w, h, ch, px); }
 
 #define CK(call) do { int rc_ = (call); if (rc_ != RTDD_OK) { std::printf("%s: %s (%s)\n", #call, rtdd_status_string(rc_), rtdd_last_error(ctx)); return rc_; } } while (0)
 
@@ -127,9 +214,16 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
 
 int main(int argc, const char *argv[]) {
     if (argc == 1) { std::printf("Usage: rtdd_harness -i image.ppm [-a annotation.pgm] [-o prefix] [--effect defocus|desaturation|haze] [--iters N] [--refine sor|mg|auto [--tolerance T]]\n"
-                                 "                    [--paint x,y,label,radius]... [--live N] [--devices D --batch B]\n"); return 0; }
+                                 "                    [--paint x,y,label,radius]... [--live N] [--devices D --batch B] [--png]\n"
+                                 "       rtdd_harness --convert in.(png|ppm|pgm) out.(png|ppm|pgm)       (8-bit PNG <-> PNM, no GPU)\n"); return 0; }
+    if (argc == 4 && !std::strcmp(argv[1], "--convert")) {               // file format conversion only (no GPU): PNG <-> PNM
+        Pnm im;
+        if (!read_image(argv[2], im)) { std::printf("cannot read %s\n", argv[2]); return 2; }
+        return write_image(argv[3], im.w, im.h, im.ch, im.px.data()) ? 0 : 5;
+    }
     Job job;
     std::string in, an, out = "";
+    bool png = false;
     int devices = 1, batch = 1, live = 0;
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -143,15 +237,21 @@ int main(int argc, const char *argv[]) {
         else if (!std::strcmp(argv[i], "--devices")) devices = std::atoi(next());
         else if (!std::strcmp(argv[i], "--batch")) batch = std::atoi(next());
         else if (!std::strcmp(argv[i], "--live")) live = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--png")) png = true;                       // DepthMap.png / ArtisticEffect.png like the reference
         else if (!std::strcmp(argv[i], "--paint")) { Paint p{0, 0, 0, 0}; if (std::sscanf(next(), "%d,%d,%d,%d", &p.x, &p.y, &p.label, &p.radius) == 4) job.paints.push_back(p); }
         else if (!std::strcmp(argv[i], "-h")) std::printf("Usage:\n -i input image (binary PPM)\n -a annotated image (binary PGM)\n");
     }
     Pnm rgb;
-    if (!read_pnm(in, rgb) || rgb.ch != 3) { std::printf("cannot read %s as a binary PPM\n", in.c_str()); return 2; }
+    if (!read_image(in, rgb) || rgb.ch != 3) { std::printf("cannot read %s as a binary PPM or an 8-bit RGB PNG\n", in.c_str()); return 2; }
     job.bgr = rgb;
     for (size_t i = 0; i < rgb.px.size(); i += 3) { job.bgr.px[i] = rgb.px[i + 2]; job.bgr.px[i + 2] = rgb.px[i]; }   // cv::imread gives BGR
     if (!an.empty()) {
-        if (!read_pnm(an, job.ann) || job.ann.ch != 1 || job.ann.w != rgb.w || job.ann.h != rgb.h) { std::printf("cannot read %s as a binary PGM of the image's size\n", an.c_str()); return 2; }
+        if (!read_image(an, job.ann) || job.ann.w != rgb.w || job.ann.h != rgb.h) { std::printf("cannot read %s as a binary PGM / 8-bit PNG of the image's size\n", an.c_str()); return 2; }
+        if (job.ann.ch == 3) {                                               // cv::imread(path, 0) of a colour file: BT.601 gray, as for the image
+            Pnm g1; g1.w = job.ann.w; g1.h = job.ann.h; g1.ch = 1; g1.px.resize((size_t)g1.w * g1.h);
+            for (size_t i = 0; i < g1.px.size(); i++) g1.px[i] = (unsigned char)((job.ann.px[3 * i] * 4899 + job.ann.px[3 * i + 1] * 9617 + job.ann.px[3 * i + 2] * 1868 + 8192) >> 14);
+            job.ann = g1;
+        }
         job.has_ann = true;
     }
     int ndev = 0;
@@ -174,11 +274,11 @@ int main(int argc, const char *argv[]) {
     const int total = live > 0 ? live : batch;
     std::printf("Processing Time: %.3f ms per estimate on device 0 (upload + estimate%s + download); %d estimate(s) on %d device(s) in %.1f ms wall incl. setup\n",
                 ms[0], job.effect.empty() ? "" : " + effect", total, devices, wall);
-    if (!write_pnm(out + "DepthMap.pgm", rgb.w, rgb.h, 1, depth[0].data())) { std::printf("cannot write %sDepthMap.pgm\n", out.c_str()); return 5; }
+    if (!write_image(out + (png ? "DepthMap.png" : "DepthMap.pgm"), rgb.w, rgb.h, 1, depth[0].data())) { std::printf("cannot write %sDepthMap\n", out.c_str()); return 5; }
     if (!job.effect.empty()) {
         std::vector<unsigned char> o(art[0]);
         for (size_t i = 0; i < o.size(); i += 3) { o[i] = art[0][i + 2]; o[i + 2] = art[0][i]; }     // BGR -> RGB for the file
-        if (!write_pnm(out + "ArtisticEffect.ppm", rgb.w, rgb.h, 3, o.data())) return 5;
+        if (!write_image(out + (png ? "ArtisticEffect.png" : "ArtisticEffect.ppm"), rgb.w, rgb.h, 3, o.data())) return 5;
     }
     std::printf("Saving images...\n");                                   // main.cpp:317
     return 0;

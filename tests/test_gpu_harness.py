@@ -40,6 +40,18 @@ def test_harness_reproduces_golden(tmp_path, name, effect, key):
     assert np.array_equal(_read_pnm(tmp_path / "ArtisticEffect.ppm"), g[key][..., ::-1])
 
 
+def test_harness_png_in_png_out(tmp_path):
+    """The dataset's own formats: RGB annotation PNG (R = G = B), PNG image, --png outputs as the reference saves them."""
+    from PIL import Image
+    g = load(NAMES[1])
+    Image.fromarray(np.ascontiguousarray(g["bgr"][..., ::-1]), "RGB").save(tmp_path / "img.png")
+    Image.fromarray(np.repeat(g["annotation"][..., None], 3, 2), "RGB").save(tmp_path / "ann.png")
+    out = subprocess.check_output([BIN, "-i", str(tmp_path / "img.png"), "-a", str(tmp_path / "ann.png"), "-o", str(tmp_path) + "/", "--effect", "defocus", "--png"], text=True)
+    assert "Saving images" in out
+    assert np.array_equal(np.array(Image.open(tmp_path / "DepthMap.png")), g["depth_u8"])
+    assert np.array_equal(np.array(Image.open(tmp_path / "ArtisticEffect.png")), g["defocus"][..., ::-1])
+
+
 def test_harness_batch_and_paint(tmp_path):
     g = load(NAMES[0])
     _write_pnm(tmp_path / "img.ppm", g["bgr"][..., ::-1])
