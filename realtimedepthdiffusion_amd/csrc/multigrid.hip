@@ -203,25 +203,36 @@ __global__ __launch_bounds__(256) void k_mg_prune(float *E, float *S, float *SE,
     if (!(at(D, pitch, rows, cols, y + 1, x - 1) > 0.0f)) SW[q] = 0.0f;
 }
 
-// level-0 residual from exact differences, on the true operator
+// level-0 residual from exact differences, on the true operator; 4 pixels per thread (16-byte loads)
 __global__ __launch_bounds__(256) void k_mg_residual0(const float *__restrict__ X, const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
                                                       int ip, int rows, int cols, float *R, int pitch) {
     __shared__ float lut[257];
     for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
     __syncthreads();
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    const size_t p = (size_t)y * ip + x;
-    const uint32_t m = M[p];
-    float r = 0.0f;
-    if (!(m & kMetaDirichlet)) {
-        const float xc = X[p];
-        if (x > 0) r += lut[M[p - 1] & 255] * (X[p - 1] - xc);
-        if (x + 1 < cols) r += lut[m & 255] * (X[p + 1] - xc);
-        if (y > 0) r += lut[(M[p - ip] >> 8) & 255] * (X[p - ip] - xc);
-        if (y + 1 < rows) r += lut[(m >> 8) & 255] * (X[p + ip] - xc);
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= cols || y >= rows) return;
+    const size_t p = (size_t)y * ip + x0;                          // the solver planes' guard rows/columns make these addresses valid
+    const float4 c4 = *(const float4 *)(X + p), u4 = *(const float4 *)(X + p - ip), d4 = *(const float4 *)(X + p + ip);
+    const uint4 m4 = *(const uint4 *)(M + p), mu4 = *(const uint4 *)(M + p - ip);
+    const float xc[4] = {c4.x, c4.y, c4.z, c4.w}, xu[4] = {u4.x, u4.y, u4.z, u4.w}, xd[4] = {d4.x, d4.y, d4.z, d4.w};
+    const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+    const float xl0 = X[p - 1], xr4 = X[p + 4];
+    const uint32_t ml0 = M[p - 1];
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x0 + i;
+        float v = 0.0f;
+        if (x < cols && !(mm[i] & kMetaDirichlet)) {
+            if (x > 0) v += lut[(i == 0 ? ml0 : mm[i - 1]) & 255] * ((i == 0 ? xl0 : xc[i - 1]) - xc[i]);
+            if (x + 1 < cols) v += lut[mm[i] & 255] * ((i == 3 ? xr4 : xc[i + 1]) - xc[i]);
+            if (y > 0) v += lut[(mu[i] >> 8) & 255] * (xu[i] - xc[i]);
+            if (y + 1 < rows) v += lut[(mm[i] >> 8) & 255] * (xd[i] - xc[i]);
+        }
+        r[i] = v;
     }
-    R[(size_t)y * pitch + x] = r;
+    float *o = R + (size_t)y * pitch + x0;                           // pitch is a multiple of 64: whole float4s stay inside the row
+    if (x0 + 3 < pitch) *(float4 *)o = make_float4(r[0], r[1], r[2], r[3]);
 }
 
 __device__ __forceinline__ float gs_sum(const Stencil &s, const float *e, const float *b, int y, int x) {
@@ -515,7 +526,7 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     if (last == 0) return launch_rbgs_blocked(ctx, L0, ip, rows, cols, 2 * kNu, 1.0f, plane, launches, -1);
     if ((rc = launch_rbgs_blocked(ctx, L0, ip, rows, cols, kNu, 1.0f, plane, &ln)) != RTDD_OK) return rc;
     *launches += ln;
-    hipLaunchKernelGGL(k_mg_residual0, grid_for(rows, cols), dim3(256), 0, ctx->stream, L0.P(*plane, ip), L0.M(ip), ctx->lut_dev, (int)ip, rows, cols, lv[0].r(), lv[0].pitch);
+    hipLaunchKernelGGL(k_mg_residual0, dim3((cols + 255) / 256, (rows + 3) / 4), dim3(256), 0, ctx->stream, L0.P(*plane, ip), L0.M(ip), ctx->lut_dev, (int)ip, rows, cols, lv[0].r(), lv[0].pitch);
     (*launches)++;
     for (int l = 0; l < last; l++) {                    // down
         MgLevel &f = lv[l], &c = lv[l + 1];
