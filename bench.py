@@ -227,15 +227,17 @@ def main():
                                       "residual": max(e[1] for e in executed), "start": "cold (depth 255 + labels)"}
     # HBM-side traffic of the sweep kernel comes from a separate rocprofv3 --pmc pass of this same command
     # (scripts/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), committed under profiles/.
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        if prof.get("workload") == args.workload and method == "jacobi" and not (args.sweep_kernel or args.tile or args.temporal_depth or args.persistent >= 0):
-            for name, k in prof["kernels"].items():
-                if "k_sweep" in name:
-                    out["roofline"]["traffic"] = k["hbm_bytes_per_launch_corrected"]
-                    out["roofline"]["traffic_source"] = prof.get("source", "profiles/traffic_latest.json")
-    except (OSError, ValueError, KeyError):
-        pass
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))) + [os.path.join(ROOT, "profiles", "traffic_latest.json")]:
+        try:
+            prof = json.load(open(path))
+            if prof.get("workload") == args.workload and method == "jacobi" and not (args.sweep_kernel or args.tile or args.temporal_depth or args.persistent >= 0):
+                sweeps_k = [k for name, k in prof["kernels"].items() if "k_sweep" in name]
+                if sweeps_k:                            # the dominant kernel of that profile; a later file (traffic_latest last) overrides an earlier one
+                    out["roofline"]["traffic"] = max(k["hbm_bytes_per_launch_corrected"] for k in sweeps_k)
+                    out["roofline"]["traffic_source"] = prof.get("source", os.path.relpath(path, ROOT))
+        except (OSError, ValueError, KeyError):
+            pass
     if rank == 0 and args.workload == "1080p_jacobi1000" and method == "jacobi" and not args.no_estimate:
         out["estimate"] = estimate_ms(rt, ctx, p, rows, cols, dev)      # second half of BASELINE's metric; outside the timed region
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
