@@ -153,7 +153,9 @@ __device__ __forceinline__ float pweight(const Interp &ip, int pitch, int rows, 
 //   A_c[c, c'] = sum_p sum_q P[p -> c] A[p, q] P[q -> c'],  p over the 3x3 support of c's basis function, q over p's stencil.
 // Each (p, q) pair feeds the up to four coarse points q interpolates from; with the loops unrolled every offset is a
 // compile-time constant.  For one target c' the terms arrive in (py, px, qy, qx) order -- the order of the restatement's
-// plain loops (terms with a zero weight add +-0 and change nothing).
+// plain loops (terms with a zero weight add +-0 and change nothing).  FIVE: the fine operator is the image's 5-point one
+// (its diagonal couplings are all zero), so the four diagonal q are skipped -- again only +-0 terms.
+template <bool FIVE>
 __global__ __launch_bounds__(256) void k_mg_galerkin(Stencil f, Interp ip, float *E, float *S, float *SE, float *SW, float *D, int crows, int ccols, int cpitch) {
     const int J = blockIdx.x * 64 + (threadIdx.x & 63), I = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (J >= ccols || I >= crows) return;
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void k_mg_galerkin(Stencil f, Interp ip, float
             for (int qy = -1; qy <= 1; qy++)
 #pragma unroll
                 for (int qx = -1; qx <= 1; qx++) {
+                    if (FIVE && qy != 0 && qx != 0) continue;
                     const int v = y + qy, u = x + qx;
                     if (v < 0 || v >= f.rows || u < 0 || u >= f.cols) continue;
                     const float a = (qy == 0 && qx == 0) ? f.D[(size_t)y * f.pitch + x] : -coupling(f, y, x, qy, qx);
@@ -473,7 +476,8 @@ static int mg_setup(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int col
         const MgLevel &f = lv[l], &c = lv[l + 1];
         hipLaunchKernelGGL(k_mg_build_p<0>, grid_for(f.rows, f.cols), dim3(256), 0, ctx->stream, view(f), f.Pw(0), f.Pw(1), f.Pw(2), f.Pw(3));
         hipLaunchKernelGGL(k_mg_build_p<1>, grid_for(f.rows, f.cols), dim3(256), 0, ctx->stream, view(f), f.Pw(0), f.Pw(1), f.Pw(2), f.Pw(3));
-        hipLaunchKernelGGL(k_mg_galerkin, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, view(f), interp(f), c.E(), c.S(), c.SE(), c.SW(), c.D(), c.rows, c.cols, c.pitch);
+        if (l == 0) hipLaunchKernelGGL(k_mg_galerkin<true>, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, view(f), interp(f), c.E(), c.S(), c.SE(), c.SW(), c.D(), c.rows, c.cols, c.pitch);
+        else hipLaunchKernelGGL(k_mg_galerkin<false>, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, view(f), interp(f), c.E(), c.S(), c.SE(), c.SW(), c.D(), c.rows, c.cols, c.pitch);
         hipLaunchKernelGGL(k_mg_prune, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, c.E(), c.S(), c.SE(), c.SW(), c.D(), c.rows, c.cols, c.pitch);
         *launches += 4;
     }
