@@ -279,7 +279,7 @@ ORC_API int orc_mg_solve(float *x, const int32_t *index2, const uint8_t *mask, s
                 const double rate = sqrt((double)*residual_out / (double)before2);
                 if (!(rate < 1.0)) break;
                 const double needed = ceil(log((double)*residual_out / (double)tolerance) / -log(rate));
-                if (needed * (275e-6 + (double)rows * cols * 56e-12) > alternative_seconds) break;
+                if (needed * (270e-6 + (double)rows * cols * 46e-12) > alternative_seconds) break;
             }
             /* vector extrapolation: the residual shrank by the same factor lambda twice in a row -> remove that family */
             since++;

@@ -558,8 +558,8 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
 }
 
 // Modelled duration of one V-cycle with its residual check (seconds): ~50 launch-bound launches on the small levels + the
-// streaming part (measured 0.39 / 0.72 / 2.12 ms at 1080p / 4K / 8K, scripts/config5_bench.py).
-static double cycle_seconds(int rows, int cols) { return 275e-6 + (double)rows * cols * 56e-12; }
+// streaming part (measured 0.36 / 0.65 / 1.78 ms at 1080p / 4K / 8K, scripts/config5_bench.py).
+static double cycle_seconds(int rows, int cols) { return 270e-6 + (double)rows * cols * 46e-12; }
 
 // alternative_seconds > 0 (RTDD_METHOD_AUTO): leave as soon as the cycles still needed at the rate of the last two,
 // priced by cycle_seconds, cost more than the alternative (SOR cycles from here).  A deterministic rule on the f32
