@@ -36,9 +36,11 @@ WORKLOADS = {
     "1080p_multigrid_1e-4": dict(rows=1080, cols=1920, iters=200, method="multigrid", tolerance=1e-4),
 }
 # Chebyshev-Jacobi x_k 4 + x_{k-1} 4 + x_{k+1} 4 + 4 weight indices 4 + mask 1 = 17 B per pixel-sweep;
-# red-black sweep (no x_{k-1}) 13 B.  A V-cycle is counted as its four level-0 red-black sweeps (everything else -- residual,
-# transfers, the coarse levels -- is overhead on top), so its figure is a lower bound.
-ALGO_BYTES = {"jacobi": 17.0, "rbgs": 13.0, "sor_cycles": 13.0, "multigrid": 13.0}
+# red-black sweep (no x_{k-1}) 13 B.  A V(2,2) cycle (no SURVEY figure: an extension) per image pixel: level 0 = 4 red-black
+# sweeps 52 + residual 13 (x 4, indices 4, mask 1, r 4) + restriction 20 (r 4, weights 16) + prolongation 24 (weights 16,
+# x read+write 8) = 109 B; the coarse levels hold 1/3 as many points, each 4 sweeps x 48 (9 coefficients 36, e 8, b 4) +
+# residual 48 + restriction 20 + prolongation 24 = 284 B -> 95 B per image pixel; 204 B per cycle = 51 B per counted sweep.
+ALGO_BYTES = {"jacobi": 17.0, "rbgs": 13.0, "sor_cycles": 13.0, "multigrid": 51.0}
 MG_SWEEPS_PER_CYCLE = 4
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -219,7 +221,7 @@ def main():
                    "sweeps_per_launch": sweeps_per_launch},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": {"jacobi": "k_sweep_blocked", "rbgs": "k_rbgs_blocked", "sor_cycles": "k_rbgs_blocked (+ residual checks)",
-                                                 "multigrid": "whole V-cycle, counted as its 4 level-0 sweeps"}[method], "launch_us": launch_us,
+                                                 "multigrid": "whole V(2,2) cycle, all levels: 204 B per image pixel and cycle"}[method], "launch_us": launch_us,
                      "algorithmic_bytes_per_launch": algo_bytes * rows * cols * sweeps_per_launch},
     }
     if executed:
