@@ -131,5 +131,25 @@ def main():
               "spread c0/c1 per level", [float(data[f"spread_c0_c1_L{l}"]) for l in range(LEVELS)])
 
 
+def make_full(name="Dog"):
+    """One FULL-SIZE bundled pair, decoded (inputs only + hashes of the oracle's outputs): the end-to-end parity test at the
+    dataset's own resolution computes the expected images with the oracle at test time."""
+    from cascade_ref import Cascade
+    oracle.build()
+    lut = oracle.load_weights(0.4)
+    rgb = np.array(Image.open(f"{REF}/images/{name}.jpg").convert("RGB"))
+    ann = np.array(Image.open(f"{REF}/annotations/{name}.png").convert("RGB"))[..., 0]
+    bgr = np.ascontiguousarray(rgb[..., ::-1])
+    c = Cascade(oracle, bgr, ann, lut, 1, threads=8)
+    c.estimate(1000)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{name}_full.npz"), name=name, bgr=bgr, annotation=np.ascontiguousarray(ann),
+                        levels=np.array(c.P), depth_u8_sha=sha(c.depth_u8), depth_sha=sha(c.depth[0]))
+    print(name, "full size", bgr.shape, "levels", c.P, "labels", np.unique(ann[ann != 32]))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--full":
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        make_full(*sys.argv[2:])
+    else:
+        main()

@@ -129,3 +129,33 @@ def test_refine_depth_converges_the_estimate(oracle, name):
         assert (its, res) == (want_its, np.float32(want_res)) and res <= 1e-4
         assert_bit_equal(got, x, "refined depth")
         assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), oracle.depth_to_u8(x))
+
+
+def test_full_size_dataset_pair_end_to_end(oracle, lut):
+    """A bundled image/annotation pair at its own resolution (tests/golden/Dog_full.npz: 672x624, 4 pyramid levels, stored
+    decoded): the whole estimate -- gray pyramid, annotation decode and pyramid, four solves, pyrUp + re-injection, u8 --
+    and the three effects, GPU against the oracle computed here, plus the hashes recorded when the fixture was made."""
+    import os
+    from golden_util import GOLDEN_DIR, sha
+    g = np.load(os.path.join(GOLDEN_DIR, "Dog_full.npz"), allow_pickle=False)
+    bgr, ann = g["bgr"], g["annotation"]
+    rows, cols = bgr.shape[:2]
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=min(8, oracle.max_threads()))
+    ref.estimate(1000)
+    assert ref.P == int(g["levels"]) and sha(ref.depth_u8) == str(g["depth_u8_sha"]) and sha(ref.depth[0]) == str(g["depth_sha"])
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        assert c.pyramid_create(rows, cols) == ref.P
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann))
+        c.estimate_depth(1000); c.synchronize()
+        for l in range(ref.P - 1, -1, -1):
+            assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, l), ref.depth[l], f"Dog full size, level {l}")
+        assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), ref.depth_u8)
+        o = up(bgr); d = up(ref.depth[0]); gray = up(ref.gray[0]); art = up(np.zeros_like(bgr))
+        c.GPUSimulateDesaturation(o, gray, d, art, rows, cols)
+        assert np.array_equal(down(art), oracle.desaturate(bgr, ref.gray[0], ref.depth[0], 1))
+        c.GPUSimulateDefocus(o, d, art, rows, cols)
+        assert np.array_equal(down(art), oracle.defocus(bgr, ref.depth[0], threads=min(8, oracle.max_threads())))
+        c.GPUSimulateHaze(o, d, art, rows, cols)
+        diff = np.abs(down(art).astype(np.int32) - oracle.haze(bgr, ref.depth[0], 1).astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4
