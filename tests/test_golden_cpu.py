@@ -112,3 +112,16 @@ def test_converges_to_scipy_direct_solution(oracle, name):
     # ... and stagnates at an exact f32 fixed point a few 1e-3 from the true solution: a small
     # residual does not imply a small error on these stiff systems (error/residual ~ 100)
     assert np.abs(y - g["direct_solution_L2"]).max() < 5e-3
+
+
+def test_full_size_pair_hashes(oracle):
+    """The full-resolution fixture (Dog, 672x624): the oracle cascade reproduces the depth hashes recorded when it was made."""
+    import os
+    from cascade_ref import Cascade
+    from golden_util import GOLDEN_DIR, sha
+    g = np.load(os.path.join(GOLDEN_DIR, "Dog_full.npz"), allow_pickle=False)
+    lut = oracle.load_weights(0.4)
+    c = Cascade(oracle, g["bgr"], g["annotation"], lut, 1, threads=min(8, oracle.max_threads()))
+    c.estimate(1000)
+    assert c.P == int(g["levels"]) == 4
+    assert sha(c.depth[0]) == str(g["depth_sha"]) and sha(c.depth_u8) == str(g["depth_u8_sha"])
