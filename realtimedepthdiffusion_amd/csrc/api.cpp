@@ -272,6 +272,132 @@ static int check_solve_args(rtdd_ctx *ctx, const float *depth, size_t depthPitch
     return RTDD_OK;
 }
 
+namespace {
+
+// One rtdd_solve_ex call between k_prepare and k_finish: which planes hold the iterate, what has run, the last residual.
+struct Solve {
+    rtdd_ctx *ctx;
+    const Level &L;
+    size_t ip;
+    int rows, cols;
+    const rtdd_solve_params *p;
+    int done = 0, launches = 0, cycles = 0;
+    int pk = 0, pm = 1;                            // planes holding x_k and x_{k-1}
+    float residual = NAN;
+
+    bool stop_on_residual() const { return p->tolerance > 0.0f; }
+    bool reached() const { return residual <= p->tolerance; }
+    int check() { return launch_residual(ctx, L, ip, pk, rows, cols, &residual); }
+
+    // the reference's scheme, optionally in chunks with a residual check after each
+    int chebyshev_jacobi() {
+        std::vector<float> omegas;
+        omega_schedule(p->maxIterations, omegas);
+        const bool blocked = ctx->opt.sweep_kernel != 1;       // 0 (auto) and 2 -> temporally blocked kernel
+        const float *omegas_dev = nullptr;
+        int rc;
+        if (blocked && p->maxIterations > 0) {
+            if ((rc = ensure_omegas(ctx, p->maxIterations)) != RTDD_OK) return rc;
+            omegas_dev = ctx->omega_dev;
+        }
+        const int chunk = stop_on_residual() ? (p->checkEvery > 0 ? p->checkEvery : 16) : p->maxIterations;
+        while (done < p->maxIterations) {
+            const int n = p->maxIterations - done < chunk ? p->maxIterations - done : chunk;
+            int ln = 0;
+            rc = blocked ? launch_sweeps_blocked(ctx, L, ip, rows, cols, omegas_dev + done, n, &pk, &pm, &ln)
+                         : launch_sweeps(ctx, L, ip, rows, cols, omegas.data() + done, n, &pk, &pm, &ln);
+            if (rc != RTDD_OK) return rc;
+            done += n; launches += ln;
+            if (stop_on_residual()) {
+                if ((rc = check()) != RTDD_OK) return rc;
+                if (reached()) break;
+            }
+        }
+        return RTDD_OK;
+    }
+
+    // n red-black sweeps (capped by maxIterations) at one relaxation factor
+    int red_black_sweeps(int n, float omega) {
+        if (n > p->maxIterations - done) n = p->maxIterations - done;
+        if (n <= 0) return RTDD_OK;
+        int ln = 2 * n, rc;
+        if (ctx->opt.sweep_kernel == 1) rc = launch_rbgs(ctx, L, ip, pk, rows, cols, n, omega);     // one launch per colour, in place
+        else rc = launch_rbgs_blocked(ctx, L, ip, rows, cols, n, omega, &pk, &ln);                  // register-blocked, ping-pong planes
+        done += n; launches += ln;
+        return rc;
+    }
+
+    // Gauss-Seidel / SOR at a fixed factor, optionally in chunks with a residual check after each
+    int red_black() {
+        const int chunk = stop_on_residual() ? (p->checkEvery > 0 ? p->checkEvery : 16) : (p->maxIterations > 0 ? p->maxIterations : 1);
+        const float omega = p->relaxation == 0.0f ? 1.0f : p->relaxation;
+        int rc;
+        while (done < p->maxIterations) {
+            if ((rc = red_black_sweeps(chunk, omega)) != RTDD_OK) return rc;
+            if (stop_on_residual()) {
+                if ((rc = check()) != RTDD_OK) return rc;
+                if (reached()) break;
+            }
+        }
+        return RTDD_OK;
+    }
+
+    // RTDD_RELAXATION_AUTO: SOR cycles.  Over-relaxation removes the smooth error a plain sweep hardly touches, but in f32 it idles
+    // at a residual ~ ulp(x)/(2 - omega); plain Gauss-Seidel has an exact f32 fixed point but is slow on smooth error.  So:
+    // n_hi sweeps at omega_hi, n_hi/4 at omega_mid, then a Gauss-Seidel polish of at most 100 sweeps with the residual checked
+    // every 20; a cycle that does not get there is followed by one twice as long and twice as close to omega = 2, until the
+    // tolerance or maxIterations.  After V-cycles the smooth error is gone and half the length does
+    // (scripts/auto_probe.py).
+    int sor_cycles(bool after_vcycles) {
+        const int longest = rows > cols ? rows : cols;
+        const int base = after_vcycles ? (longest + 1) / 2 : longest;
+        double w0 = 2.0 / (1.0 + sin(4.0 * 3.14159265358979323846 / (double)longest));
+        if (w0 > 1.99) w0 = 1.99;
+        if (w0 < 1.0) w0 = 1.0;
+        bool ok = false;
+        int rc;
+        for (int cycle = 0; done < p->maxIterations && !ok; cycle++) {
+            const int e = cycle < 6 ? cycle : 6;
+            double gap = (2.0 - w0) / (double)(1 << e);
+            if (gap < 0.005) gap = 0.005;
+            const float w_hi = (float)(2.0 - gap);
+            float w_mid = (float)(2.0 - 10.0 * gap);
+            if (w_mid < 1.0f) w_mid = 1.0f;
+            const int n_hi = base << e;
+            if ((rc = red_black_sweeps(n_hi, w_hi)) != RTDD_OK) return rc;
+            if ((rc = red_black_sweeps(n_hi / 4, w_mid)) != RTDD_OK) return rc;
+            for (int k = 0; k < 5 && done < p->maxIterations && !ok; k++) {
+                if ((rc = red_black_sweeps(20, 1.0f)) != RTDD_OK) return rc;
+                if (stop_on_residual()) {
+                    if ((rc = check()) != RTDD_OK) return rc;
+                    ok = reached();
+                }
+            }
+        }
+        return RTDD_OK;
+    }
+
+    // V-cycles; alternative_seconds > 0: leave when the cycles still needed are modelled dearer than that (RTDD_METHOD_AUTO)
+    int vcycles(int max_cycles, int check_every, double alternative_seconds) {
+        return launch_multigrid(ctx, L, ip, rows, cols, max_cycles, p->tolerance, check_every, alternative_seconds, &pk, &cycles, &residual, &launches);
+    }
+
+    // V-cycles while they pay: they stop at the tolerance, after kAutoMaxCycles, or when the cycles still needed (at the rate of the
+    // last two) are modelled to cost more than finishing with SOR cycles of half length -- thin high-contrast structures stall them
+    // (DESIGN.md section 7), and below ~4K a cycle is launch-bound and dear.  Then those SOR cycles.
+    int automatic() {
+        const int longest = rows > cols ? rows : cols;
+        const double px = (double)rows * cols;
+        const double sweep_seconds = px / 700e9 > 2.5e-6 ? px / 700e9 : 2.5e-6;            // k_rbgs_blocked, measured
+        const double sor_seconds = ((double)((longest + 1) / 2) * 1.25 + 20.0) * sweep_seconds;
+        const int rc = vcycles(kAutoMaxCycles, 1, sor_seconds);
+        if (rc != RTDD_OK || reached()) return rc;
+        return sor_cycles(true);
+    }
+};
+
+}  // namespace
+
 int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
                   const uint8_t *gray, size_t grayPitch, int rows, int cols, int level,
                   const rtdd_solve_params *params, rtdd_solve_info *info) {
@@ -296,121 +422,28 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     if (rc != RTDD_OK) return rc;
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
 
-    const bool stop_on_residual = params->tolerance > 0.0f;
-    const int every = params->checkEvery > 0 ? params->checkEvery : 16;
-    int done = 0, launches = 0, cycles = 0;
-    int pk = 0, pm = 1;                            // planes holding x_k and x_{k-1}
-    float residual = NAN;
-
-    if (params->method == RTDD_METHOD_CHEBYSHEV_JACOBI) {
-        std::vector<float> omegas;
-        omega_schedule(params->maxIterations, omegas);
-        const bool blocked = ctx->opt.sweep_kernel != 1;       // 0 (auto) and 2 -> temporally blocked kernel
-        const float *omegas_dev = nullptr;
-        if (blocked && params->maxIterations > 0) {
-            rc = ensure_omegas(ctx, params->maxIterations);
-            if (rc != RTDD_OK) return rc;
-            omegas_dev = ctx->omega_dev;
-        }
-        const int chunk = stop_on_residual ? every : params->maxIterations;
-        while (done < params->maxIterations) {
-            const int n = params->maxIterations - done < chunk ? params->maxIterations - done : chunk;
-            int ln = 0;
-            rc = blocked ? launch_sweeps_blocked(ctx, L, ip, rows, cols, omegas_dev + done, n, &pk, &pm, &ln)
-                         : launch_sweeps(ctx, L, ip, rows, cols, omegas.data() + done, n, &pk, &pm, &ln);
-            if (rc != RTDD_OK) return rc;
-            done += n; launches += ln;
-            if (stop_on_residual) {
-                rc = launch_residual(ctx, L, ip, pk, rows, cols, &residual);
-                if (rc != RTDD_OK) return rc;
-                if (residual <= params->tolerance) break;
-            }
-        }
-    } else if (params->method == RTDD_METHOD_MULTIGRID) {
-        rc = launch_multigrid(ctx, L, ip, rows, cols, params->maxIterations, params->tolerance, params->checkEvery > 0 ? params->checkEvery : 1, 0.0,
-                              &pk, &cycles, &residual, &launches);
-        if (rc != RTDD_OK) return rc;
-        done = cycles;
-    } else {
-        auto run = [&](int n, float omega) -> int {                                                   // n sweeps at one relaxation factor
-            if (n > params->maxIterations - done) n = params->maxIterations - done;
-            if (n <= 0) return RTDD_OK;
-            int ln = 2 * n, r;
-            if (ctx->opt.sweep_kernel == 1) r = launch_rbgs(ctx, L, ip, pk, rows, cols, n, omega);     // one launch per colour, in place
-            else r = launch_rbgs_blocked(ctx, L, ip, rows, cols, n, omega, &pk, &ln);                  // register-blocked, ping-pong planes
-            done += n; launches += ln;
-            return r;
-        };
-        bool reached = false;
-        if (params->method == RTDD_METHOD_AUTO) {
-            // V-cycles while they pay: they stop at the tolerance, after kAutoMaxCycles, or when the cycles still needed (at the
-            // rate of the last two) are modelled to cost more than finishing with SOR cycles of half length -- thin high-contrast
-            // structures stall them, and below ~4K a cycle is launch-bound and dear.
-            const int longest_ = rows > cols ? rows : cols;
-            const double px = (double)rows * cols;
-            const double sweep_seconds = px / 700e9 > 2.5e-6 ? px / 700e9 : 2.5e-6;            // k_rbgs_blocked, measured
-            const double sor_seconds = ((double)((longest_ + 1) / 2) * 1.25 + 20.0) * sweep_seconds;
-            rc = launch_multigrid(ctx, L, ip, rows, cols, kAutoMaxCycles, params->tolerance, 1, sor_seconds, &pk, &cycles, &residual, &launches);
-            if (rc != RTDD_OK) return rc;
-            reached = residual <= params->tolerance;
-        }
-        if (params->method == RTDD_METHOD_AUTO || params->relaxation < 0.0f) {
-            // RTDD_RELAXATION_AUTO: SOR cycles.  Over-relaxation removes the smooth error a plain sweep hardly touches, but in
-            // f32 it idles at a residual ~ ulp(x)/(2 - omega); plain Gauss-Seidel has an exact f32 fixed point but is slow on
-            // smooth error.  So: n_hi sweeps at omega_hi, n_hi/4 at omega_mid, then a Gauss-Seidel polish of at most 100
-            // sweeps with the residual checked every 20; repeat (longer, closer to 2) until the tolerance or maxIterations
-            // (DESIGN.md section 7).
-            const int longest = rows > cols ? rows : cols;
-            // after V-cycles the smooth error is gone and half the length does (scripts/auto_probe.py); a cycle that fails still doubles
-            const int base = params->method == RTDD_METHOD_AUTO ? (longest + 1) / 2 : longest;
-            double w0 = 2.0 / (1.0 + sin(4.0 * 3.14159265358979323846 / (double)longest));
-            if (w0 > 1.99) w0 = 1.99;
-            if (w0 < 1.0) w0 = 1.0;
-            for (int cycle = 0; done < params->maxIterations && !reached; cycle++) {
-                // a cycle that does not get there is followed by one twice as long and twice as close to omega = 2
-                const int e = cycle < 6 ? cycle : 6;
-                double gap = (2.0 - w0) / (double)(1 << e);
-                if (gap < 0.005) gap = 0.005;
-                const float w_hi = (float)(2.0 - gap);
-                float w_mid = (float)(2.0 - 10.0 * gap);
-                if (w_mid < 1.0f) w_mid = 1.0f;
-                const int n_hi = base << e;
-                if ((rc = run(n_hi, w_hi)) != RTDD_OK) return rc;
-                if ((rc = run(n_hi / 4, w_mid)) != RTDD_OK) return rc;
-                for (int k = 0; k < 5 && done < params->maxIterations && !reached; k++) {
-                    if ((rc = run(20, 1.0f)) != RTDD_OK) return rc;
-                    if (stop_on_residual) {
-                        rc = launch_residual(ctx, L, ip, pk, rows, cols, &residual);
-                        if (rc != RTDD_OK) return rc;
-                        reached = residual <= params->tolerance;
-                    }
-                }
-            }
-        } else {
-            const int chunk = stop_on_residual ? every : (params->maxIterations > 0 ? params->maxIterations : 1);
-            const float omega = params->relaxation == 0.0f ? 1.0f : params->relaxation;
-            while (done < params->maxIterations) {
-                if ((rc = run(chunk, omega)) != RTDD_OK) return rc;
-                if (stop_on_residual) {
-                    rc = launch_residual(ctx, L, ip, pk, rows, cols, &residual);
-                    if (rc != RTDD_OK) return rc;
-                    if (residual <= params->tolerance) break;
-                }
-            }
-        }
+    Solve s{ctx, L, ip, rows, cols, params};
+    switch (params->method) {
+        case RTDD_METHOD_CHEBYSHEV_JACOBI: rc = s.chebyshev_jacobi(); break;
+        case RTDD_METHOD_MULTIGRID:
+            rc = s.vcycles(params->maxIterations, params->checkEvery > 0 ? params->checkEvery : 1, 0.0);
+            s.done = s.cycles;
+            break;
+        case RTDD_METHOD_AUTO: rc = s.automatic(); break;
+        default: rc = params->relaxation < 0.0f ? s.sor_cycles(false) : s.red_black(); break;
     }
-    const int result_plane = pk;
+    if (rc != RTDD_OK) return rc;
 
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-    rc = launch_finish(ctx, L, ip, result_plane, depth, depthPitch, rows, cols);
+    rc = launch_finish(ctx, L, ip, s.pk, depth, depthPitch, rows, cols);
     if (rc != RTDD_OK) return rc;
     if (prof) {
         RTDD_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
         const int slot = ctx->prof_pending % rtdd_ctx::kProfSlots;
-        ctx->prof_launches[slot] = launches; ctx->prof_sweeps[slot] = done;
+        ctx->prof_launches[slot] = s.launches; ctx->prof_sweeps[slot] = s.done;
         ctx->prof_pending++;                        // resolved (and synchronised) by rtdd_profile_get, not here
     }
-    if (info) { info->iterations = done; info->residual = residual; info->cycles = cycles; }
+    if (info) { info->iterations = s.done; info->residual = s.residual; info->cycles = s.cycles; }
     return RTDD_OK;
 }
 
