@@ -11,11 +11,20 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def ctx():
+def _ctx():
     c = rt.Context(0)
     c.GPULoadWeights(0.4)
     yield c
     c.close()
+
+
+@pytest.fixture
+def ctx(_ctx):
+    """The shared context with every option back at its default."""
+    _ctx.set_option(rt.OPT_FP_CONTRACT, 1); _ctx.set_option(rt.OPT_PERSISTENT, 1)
+    for k in (rt.OPT_SWEEP_KERNEL, rt.OPT_TILE, rt.OPT_TEMPORAL_DEPTH, rt.OPT_ROWS_PER_WAVE):
+        _ctx.set_option(k, 0)
+    return _ctx
 
 
 @pytest.mark.parametrize("rows,cols,seed,cycles", [(96, 128, 12, 3), (75, 133, 4, 2), (200, 150, 3, 2), (270, 480, 1234, 2), (17, 300, 8, 2), (16, 16, 2, 2), (33, 7, 1, 2)])

@@ -18,11 +18,21 @@ TOL = 1e-4
 
 
 @pytest.fixture(scope="module")
-def ctx():
+def _ctx():
     c = rt.Context(0)
     c.GPULoadWeights(0.4)
     yield c
     c.close()
+
+
+@pytest.fixture
+def ctx(_ctx):
+    """The shared context with every option back at its default: no test may depend on what the one before it left set."""
+    _ctx.set_option(rt.OPT_FP_CONTRACT, 1); _ctx.set_option(rt.OPT_PERSISTENT, 1)
+    for k in (rt.OPT_SWEEP_KERNEL, rt.OPT_TILE, rt.OPT_TEMPORAL_DEPTH, rt.OPT_ROWS_PER_WAVE):
+        _ctx.set_option(k, 0)
+    _ctx.profile_enable(False)
+    return _ctx
 
 
 def _solve_gpu(ctx, p, iters, level, levels, contract, align=512, opts=None):
