@@ -40,7 +40,11 @@ enum rtdd_status {
     RTDD_ERR_HIP = 3,               /* a HIP runtime call failed; see rtdd_last_error() */
     RTDD_ERR_NOMEM = 4,
     RTDD_ERR_NO_DEVICE = 5,         /* no usable gfx950 device: there is NO CPU fallback */
-    RTDD_ERR_TIMEOUT = 6            /* reported by rtdd_ctx_synchronize: a persistent sweep launch gave up (GPU shared) */
+    RTDD_ERR_TIMEOUT = 6            /* a persistent sweep launch gave up waiting for a neighbouring workgroup (the GPU was shared, so
+                                       its workgroups were not all resident at once).  Reported by the next call that synchronises the
+                                       stream anyway: rtdd_ctx_synchronize, rtdd_download, a residual-stopped rtdd_solve_ex.  Everything
+                                       computed since the previous synchronisation is invalid; the failed launch and the launches queued
+                                       behind it drain at once instead of spinning */
 };
 
 /* Solver variants.  RTDD_METHOD_CHEBYSHEV_JACOBI is the reference's only scheme
@@ -68,10 +72,13 @@ enum rtdd_option {
     RTDD_OPT_ROWS_PER_WAVE = 4,     /* one-sweep kernel: rows each wave walks (0 = auto) */
     RTDD_OPT_PERSISTENT = 6,        /* 1 (default): levels whose tiles all fit on the chip at once run ALL sweeps in one launch,
                                        neighbouring workgroups trading halo strips in memory (no kernel boundaries) */
+    RTDD_OPT_DEBUG_WITHHOLD_TILE = 7, /* testing aid: tile number + 1 whose hand-off flag a persistent launch never publishes (0 = off),
+                                       so that its neighbours run into the poll limit -> RTDD_ERR_TIMEOUT */
+    RTDD_OPT_DEBUG_POLL_LIMIT_US = 8, /* testing aid: that poll limit in microseconds (0 = the default, 200 ms) */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),
-                                       12 = 128x96 (16 px/thread, 768 threads) */
+                                       12 = 128x96 (16 px/thread, 768 threads), 13 = 128x96 (24 px/thread, 512 threads) */
 };
 
 /* ---- context ------------------------------------------------------------------------------- */

@@ -35,6 +35,7 @@ def lib():
             build()
         _lib = C.CDLL(_SO)
         _lib.orc_residual.restype = C.c_float
+        _lib.orc_residual_mt.restype = C.c_float
         _lib.orc_solve.restype = C.c_int
         _lib.orc_max_threads.restype = C.c_int
     return _lib
@@ -164,6 +165,23 @@ def residual(x, idx, mask, lut, contract):
     rows, cols = x.shape
     x = np.ascontiguousarray(x, np.float32)
     return float(lib().orc_residual(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract)))
+
+
+def residual_mt(x, idx, mask, lut, contract, threads=None):
+    """orc_residual on several cores (bit-identical: a maximum)."""
+    rows, cols = x.shape
+    x = np.ascontiguousarray(x, np.float32)
+    return float(lib().orc_residual_mt(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract),
+                                       C.c_int(threads or max_threads())))
+
+
+def rbgs_sweeps_mt(x, idx, mask, lut, contract, omega, nsweeps, threads=None):
+    """nsweeps red-black sweeps in place, each colour's rows over several cores (bit-identical to rbgs_sweep)."""
+    rows, cols = x.shape
+    assert x.flags.c_contiguous and x.dtype == np.float32
+    lib().orc_rbgs_sweeps_mt(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract), C.c_float(omega),
+                             C.c_int(nsweeps), C.c_int(threads or max_threads()))
+    return x
 
 
 def rbgs_sweep(x, idx, mask, lut, contract, omega=1.0):

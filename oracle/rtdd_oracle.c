@@ -374,6 +374,47 @@ ORC_API void orc_rbgs_sweep(float *x, const int32_t *index2, const uint8_t *mask
             }
 }
 
+/* The same two loops on several host cores, for the full-size parity tests (4K x 64 sweeps in seconds): within one colour
+ * every update reads only pixels of the other colour, and a maximum does not depend on the order it is taken in, so the
+ * results are bit-identical to orc_rbgs_sweep / orc_residual. */
+ORC_API void orc_rbgs_sweeps_mt(float *x, const int32_t *index2, const uint8_t *mask, size_t maskPitch,
+                                int rows, int cols, const float *lut, int contract, float omega, int nsweeps, int threads) {
+    (void)threads;
+    for (int s = 0; s < nsweeps; s++)
+        for (int colour = 0; colour < 2; colour++) {
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+            for (int y = 0; y < rows; y++)
+                for (int xx = (y + colour) & 1; xx < cols; xx += 2) {
+                    if (mask[(size_t)y * maskPitch + xx] == 255) continue;
+                    size_t p = (size_t)y * cols + xx;
+                    float v = mean4(index2[2 * p] / 1000, index2[2 * p] % 1000, index2[2 * p + 1] / 1000,
+                                    index2[2 * p + 1] % 1000, lut, x, xx, y, cols, contract);
+                    if (omega != 1.0f) {
+                        v = contract ? fmaf(omega, v - x[p], x[p]) : x[p] + omega * (v - x[p]);
+                        v = fminf(fmaxf(v, 0.0f), 255.0f);
+                    }
+                    x[p] = v;
+                }
+        }
+}
+
+ORC_API float orc_residual_mt(const float *in, const int32_t *index2, const uint8_t *mask, size_t maskPitch,
+                              int rows, int cols, const float *lut, int contract, int threads) {
+    float worst = 0.0f;
+    (void)threads;
+#pragma omp parallel for schedule(static) reduction(max : worst) num_threads(threads > 0 ? threads : 1)
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            if (mask[(size_t)y * maskPitch + x] == 255) continue;
+            size_t p = (size_t)y * cols + x;
+            float r = mean4(index2[2 * p] / 1000, index2[2 * p] % 1000, index2[2 * p + 1] / 1000,
+                            index2[2 * p + 1] % 1000, lut, in, x, y, cols, contract);
+            float d = fabsf(r - in[p]);
+            if (d > worst) worst = d;
+        }
+    return worst;
+}
+
 ORC_API int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

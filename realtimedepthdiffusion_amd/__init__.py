@@ -16,7 +16,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librtdd.so")
+_SO = os.environ.get("RTDD_LIBRARY") or os.path.join(_HERE, "librtdd.so")     # RTDD_LIBRARY: developer knob for A/B builds (scripts/build_variant.sh)
 _CSRC = os.path.join(_HERE, "csrc")
 
 RTDD_OK = 0
@@ -26,6 +26,8 @@ METHOD_MULTIGRID = 2
 METHOD_AUTO = 3
 RELAXATION_AUTO = -1.0                     # rtdd_solve_params.relaxation: SOR cycles (include/rtdd.h)
 OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, _OPT_RESERVED_3, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
+OPT_DEBUG_WITHHOLD_TILE, OPT_DEBUG_POLL_LIMIT_US = 7, 8
+RTDD_ERR_TIMEOUT = 6
 
 # every symbol include/rtdd.h declares (checked by tests/test_abi.py against the header)
 C_ABI_SYMBOLS = [

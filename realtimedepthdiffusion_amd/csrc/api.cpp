@@ -6,6 +6,7 @@
 #include <new>
 
 #include "rtdd_internal.hpp"
+#include "persist_sync.hpp"
 
 namespace rtdd {
 
@@ -33,6 +34,33 @@ void omega_schedule(int n, std::vector<float> &out) {
         else omega = 4.0 / (4.0 - rho * rho * omega);
         out[it] = omega;
     }
+}
+
+int prepare_persistent_launch(rtdd_ctx *ctx) {
+    RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, kSyncMaxTiles * sizeof(int), ctx->stream));
+    const int limit = ctx->opt.debug_poll_limit_us > 0 ? ctx->opt.debug_poll_limit_us * 100 : 0;        // 10 ns ticks
+    if (ctx->sync_header[0] != ctx->opt.debug_withhold_tile || ctx->sync_header[1] != limit) {
+        RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncWithhold), ctx->opt.debug_withhold_tile, 1, ctx->stream));
+        RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncLimit), limit, 1, ctx->stream));
+        ctx->sync_header[0] = ctx->opt.debug_withhold_tile; ctx->sync_header[1] = limit;
+    }
+    ctx->persistent_used = true;
+    return RTDD_OK;
+}
+
+// The stream has just been synchronised by the caller.  A blocked-sweep launch since the last check may have given up (persist_sync.hpp).
+int check_persistent_status(rtdd_ctx *ctx) {
+    if (!ctx->persistent_used || !ctx->sync_words) return RTDD_OK;
+    int status = 0;
+    RTDD_HIP(ctx, hipMemcpy(&status, ctx->sync_words + kSyncStatus, sizeof(int), hipMemcpyDeviceToHost));
+    ctx->persistent_used = false;
+    if (status == 0) return RTDD_OK;
+    RTDD_HIP(ctx, hipMemset(ctx->sync_words + kSyncStatus, 0, sizeof(int)));
+    return fail(ctx, RTDD_ERR_TIMEOUT, status == 1 ? "persistent sweep kernel: a workgroup timed out waiting for a neighbouring tile (its workgroups were not all "
+                                                     "co-resident: is the GPU shared?); the results since the last synchronisation are invalid; "
+                                                     "set RTDD_OPT_PERSISTENT to 0 when the GPU is shared"
+                                                   : "blocked sweep kernel: a wave timed out waiting for a neighbouring wave of its own workgroup (internal error); "
+                                                     "the results since the last synchronisation are invalid");
 }
 
 static void free_levels(rtdd_ctx *ctx) {
@@ -85,7 +113,9 @@ int rtdd_ctx_create(int device, rtdd_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     bool ok = hipMalloc((void **)&ctx->lut_dev, 257 * sizeof(float)) == hipSuccess &&
-              hipMalloc((void **)&ctx->residual_dev, 64) == hipSuccess;
+              hipMalloc((void **)&ctx->residual_dev, 64) == hipSuccess &&
+              hipMalloc((void **)&ctx->sync_words, (kSyncFlags + kSyncMaxTiles) * sizeof(int)) == hipSuccess &&
+              hipMemset(ctx->sync_words, 0, (kSyncFlags + kSyncMaxTiles) * sizeof(int)) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) { rtdd_ctx_destroy(ctx); return RTDD_ERR_HIP; }
     *out = ctx;
@@ -119,18 +149,7 @@ int rtdd_ctx_synchronize(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     DeviceGuard g(ctx->device);
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->persistent_used && ctx->sync_words) {
-        // a persistent sweep launch gives up (instead of hanging) if a neighbouring workgroup never shows up,
-        // which can only happen when its workgroups were not all co-resident (the GPU was shared with other work)
-        int status = 0;
-        RTDD_HIP(ctx, hipMemcpy(&status, ctx->sync_words, sizeof(int), hipMemcpyDeviceToHost));
-        ctx->persistent_used = false;
-        if (status != 0) {
-            RTDD_HIP(ctx, hipMemset(ctx->sync_words, 0, 64));
-            return fail(ctx, RTDD_ERR_TIMEOUT, "persistent sweep kernel timed out waiting for a neighbouring workgroup: results are invalid; "
-                                               "set RTDD_OPT_PERSISTENT to 0 when the GPU is shared");
-        }
-    }
+    { const int rc = check_persistent_status(ctx); if (rc != RTDD_OK) return rc; }
     return RTDD_OK;
 }
 
@@ -141,8 +160,10 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 2, "sweep kernel must be 0..2"); ctx->opt.sweep_kernel = value; break;
         case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 28, "temporal depth must be 0..28"); ctx->opt.temporal_depth = value; break;
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
-        case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 12, "tile must be 0..12"); ctx->opt.tile = value; break;
+        case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 13, "tile must be 0..13"); ctx->opt.tile = value; break;
         case RTDD_OPT_PERSISTENT: ctx->opt.persistent = value ? 1 : 0; break;
+        case RTDD_OPT_DEBUG_WITHHOLD_TILE: REQUIRE(ctx, value >= 0 && value <= kSyncMaxTiles, "tile number + 1 out of range"); ctx->opt.debug_withhold_tile = value; break;
+        case RTDD_OPT_DEBUG_POLL_LIMIT_US: REQUIRE(ctx, value >= 0 && value <= 10000000, "poll limit must be 0..1e7 us"); ctx->opt.debug_poll_limit_us = value; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;
@@ -157,6 +178,8 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_ROWS_PER_WAVE: *value = ctx->opt.rows_per_wave; break;
         case RTDD_OPT_TILE: *value = ctx->opt.tile; break;
         case RTDD_OPT_PERSISTENT: *value = ctx->opt.persistent; break;
+        case RTDD_OPT_DEBUG_WITHHOLD_TILE: *value = ctx->opt.debug_withhold_tile; break;
+        case RTDD_OPT_DEBUG_POLL_LIMIT_US: *value = ctx->opt.debug_poll_limit_us; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;

@@ -233,7 +233,7 @@ int rtdd_download(rtdd_ctx *ctx, void *host, size_t hostPitch, const void *dev, 
     DeviceGuard g(ctx->device);
     RTDD_HIP(ctx, hipMemcpy2DAsync(host, hostPitch, dev, devPitch, widthBytes, rows, hipMemcpyDeviceToHost, ctx->stream));
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return RTDD_OK;
+    return check_persistent_status(ctx);        // what was just downloaded may come from a persistent launch that gave up
 }
 
 }  // extern "C"

@@ -1,0 +1,67 @@
+// persist_sync.hpp -- the inter-workgroup hand-off of the persistent kernels (sweep_blocked.hip, rbgs_blocked.hip), device side,
+// and the host helpers around it (api.cpp).
+//
+// Control words (rtdd_ctx::sync_words, device memory, one set per context):
+//   [kSyncStatus]    0 = fine; 1 = a workgroup gave up waiting for a neighbouring TILE (the launch was not fully co-resident:
+//                    GPU shared with another stream or process); 2 = a wave gave up waiting for a neighbouring WAVE of its own
+//                    workgroup (cannot happen -- every wave of a workgroup is resident -- so: a protocol bug).  Sticky until the
+//                    host reads it (rtdd_ctx_synchronize and every other call that synchronises anyway) and returns
+//                    RTDD_ERR_TIMEOUT.  Once it is set every workgroup that sees it stops exchanging and returns, and every
+//                    later persistent launch returns at once, so a failed estimate drains in microseconds instead of spinning
+//                    through its remaining exchanges.
+//   [kSyncWithhold]  debug (RTDD_OPT_DEBUG_WITHHOLD_TILE): tile number + 1 whose flag is never published (0 = off), to make the
+//                    timeout path testable.
+//   [kSyncLimit]     poll limit in 10 ns ticks of s_memrealtime (0 = kDefaultPollLimit).
+//   [kSyncFlags ..]  one block counter per tile, zeroed by the host before every persistent launch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rtdd {
+
+constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncFlags = 16, kSyncMaxTiles = 1024;
+constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: legitimate waits are microseconds
+
+#ifdef __HIPCC__
+// Called by EVERY thread of the workgroup after its payload stores are drained (s_waitcnt vmcnt(0)) and a __syncthreads().
+// Publishes this tile's counter, waits for the up-to-8 neighbouring tiles' counters, makes their payload visible (one agent
+// acquire by wave 0) and ends with a __syncthreads().  Returns true when the launch is dead (see kSyncStatus): the caller
+// leaves.  `dead_lds` is a __shared__ int, zero at kernel start.
+// Protocol (cdna_hip_programming.md Guideline 16, R1): write-through (sc1) payload stores; EVERY storing wave drains vmcnt;
+// workgroup barrier; ONE lane stores the flag (agent-scope atomic); 8 lanes poll the neighbours' flags relaxed with s_sleep;
+// ONE agent acquire; barrier; plain vector loads.
+__device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, int tid, int tile_id, int bx, int by, int gx, int gy, int value) {
+    int *flags = sync_words + kSyncFlags;
+    if (tid == 0 && __hip_atomic_load(&sync_words[kSyncWithhold], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tile_id + 1)
+        __hip_atomic_store(&flags[tile_id], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 9 && tid != 4) {                                           // lane i polls neighbour (i%3-1, i/3-1)
+        const int nx = bx + tid % 3 - 1, ny = by + tid / 3 - 1;
+        if (nx >= 0 && ny >= 0 && nx < gx && ny < gy) {
+            const int nb = ny * gx + nx;
+            unsigned long long t0 = 0, limit = 0;
+            unsigned spins = 0;
+            while (__hip_atomic_load(&flags[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+                __builtin_amdgcn_s_sleep(4);
+                if ((++spins & 63u) == 0) {                              // every 64 polls (tens of microseconds): clock and status word
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) {
+                        t0 = now;
+                        const int l = __hip_atomic_load(&sync_words[kSyncLimit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        limit = l > 0 ? (unsigned long long)l : kDefaultPollLimit;
+                    }
+                    const bool failed = __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (failed || now - t0 > limit) {
+                        if (!failed) __hip_atomic_store(&sync_words[kSyncStatus], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dead_lds, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    if (tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __syncthreads();
+    return __hip_atomic_load(dead_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+}
+#endif
+
+}  // namespace rtdd

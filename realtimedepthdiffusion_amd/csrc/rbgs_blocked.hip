@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "rtdd_internal.hpp"
+#include "persist_sync.hpp"
 
 namespace rtdd {
 namespace {
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
     __shared__ float lut[257];
     __shared__ float4 edge[2][NTR][2][LX];
     __shared__ int published[NT / 64];
+    __shared__ int dead_s;                     // the launch has failed (persist_sync.hpp): leave
 
     // XCD-aware placement as in sweep_blocked.hip: workgroup p (on XCD p % 8) takes tile (p % 8) * xcd_tiles + p / 8
     int bx = blockIdx.x, by = blockIdx.y;
@@ -91,7 +93,9 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
     const int tid = threadIdx.x;
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
     if (tid < NT / 64) published[tid] = 0;
+    if (tid == 0) dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     __syncthreads();
+    if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
 
     const int lx = tid % LX, tr = tid / LX;
     const int ntr = (int)blockDim.x / LX, eh = ntr * G;
@@ -211,20 +215,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every storing wave drains its write-through stores
         __syncthreads();
-        int *flags = sync_words + 16;
-        if (tid == 0) __hip_atomic_store(&flags[tile_id], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < 9 && tid != 4) {                                       // lane i polls neighbour (i%3-1, i/3-1)
-            const int nx = bx + tid % 3 - 1, ny = by + tid / 3 - 1;
-            if (nx >= 0 && ny >= 0 && nx < gx && ny < gy) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(&flags[ny * gx + nx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < blk + 1) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++spins > (1u << 22)) { __hip_atomic_store(&sync_words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never hang
-                }
-            }
-        }
-        if (tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        __syncthreads();
+        if (exchange_wait(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, blk + 1)) return;      // flag, bounded poll, acquire, barrier (persist_sync.hpp)
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int y = y0 + g, ty = tr * G + g;
@@ -283,11 +274,7 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
                                 n - done > m && m == depth && hx <= TW && hy <= TH;
         int block_sweeps = m;
         if (persistent) {
-            if (!ctx->sync_words) {
-                RTDD_HIP(ctx, hipMalloc((void **)&ctx->sync_words, 1024 * sizeof(int) + 64));
-                RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words, 0, 64, ctx->stream));
-            }
-            RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + 16, 0, 1024 * sizeof(int), ctx->stream));
+            { const int rc_ = prepare_persistent_launch(ctx); if (rc_ != RTDD_OK) return rc_; }   // zero the tile flags, debug words
             ctx->persistent_used = true;
             m = n - done;
         }

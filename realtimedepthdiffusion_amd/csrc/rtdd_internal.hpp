@@ -48,6 +48,8 @@ struct Options {
     int rows_per_wave = 0;
     int tile = 0;
     int persistent = 1;
+    int debug_withhold_tile = 0;     // RTDD_OPT_DEBUG_WITHHOLD_TILE: tile number + 1 whose exchange flag is never published (0 = off)
+    int debug_poll_limit_us = 0;     // RTDD_OPT_DEBUG_POLL_LIMIT_US: exchange poll limit (0 = default, 200 ms)
 };
 
 }  // namespace rtdd
@@ -67,8 +69,8 @@ struct rtdd_ctx {
     float *omega_dev = nullptr;     // device copy of the omega schedule (temporally blocked kernel)
     int omega_cap = 0;
     float *residual_dev = nullptr;  // extension: residual reduction target
-    int *sync_words = nullptr;      // persistent sweep kernel: [0] = status, [16..] = per-tile block flags
-    int *sync_status_host = nullptr; // pinned host copy of the status word
+    int *sync_words = nullptr;      // control words of the persistent kernels (persist_sync.hpp); allocated with the context
+    int sync_header[2] = {0, 0};    // what sync_words[kSyncWithhold], [kSyncLimit] currently hold on the device
     bool persistent_used = false;   // a persistent launch happened since the last status check
     uint32_t *sat = nullptr;        // defocus summed-area table scratch
     size_t sat_elems = 0;
@@ -160,6 +162,11 @@ int launch_decode_annotation(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, const
                              uint8_t *scribble, size_t sp, int rows, int cols);
 int launch_fill_f32(rtdd_ctx *ctx, float *dst, size_t dp, int rows, int cols, float v);
 void pyramid_free(rtdd_ctx *ctx);
+
+// persistent kernels (persist_sync.hpp): zero the per-tile flags and refresh the debug words before a persistent launch;
+// read the status word where the stream has just been synchronised (-> RTDD_ERR_TIMEOUT, status cleared)
+int prepare_persistent_launch(rtdd_ctx *ctx);
+int check_persistent_status(rtdd_ctx *ctx);
 
 // the reference's host-side omega recurrence (src/GPUSolver.cu:282-299)
 void omega_schedule(int n, std::vector<float> &out);

@@ -361,7 +361,7 @@ int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int row
     RTDD_LAUNCH_CHECK(ctx, "k_residual");
     RTDD_HIP(ctx, hipMemcpyAsync(host_out, ctx->residual_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return RTDD_OK;
+    return check_persistent_status(ctx);        // the sweeps this residual judges may have been a persistent launch that gave up
 }
 
 int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps, float omega) {

@@ -25,14 +25,17 @@
 #include <type_traits>
 
 #include "rtdd_internal.hpp"
+#include "persist_sync.hpp"
 
 namespace rtdd {
 
+// bound_ctrl: the lane without a source (lane 0 / lane 63) reads 0 -- its value is never used (the weight towards it is 0
+// or the lane lies in the discarded halo) -- and the builtin needs no copy of `v` for the unwritten lane.
 __device__ __forceinline__ float lane_from_prev(float v) {   // lane l <- lane l-1  (DPP wave_shr:1)
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float lane_from_next(float v) {   // lane l <- lane l+1  (DPP wave_shl:1)
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 
 // write-through (sc1) 16-byte store for inter-workgroup hand-offs (no release fence needed; the storing wave drains vmcnt itself)
@@ -46,6 +49,18 @@ __device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
 #ifndef RTDD_STORE_MODE
 #define RTDD_STORE_MODE 0
 #endif
+// Sweep body variants (diagnostic knob for A/B builds, scripts/build_variant.sh): 0 = the round-1 body; otherwise features:
+#ifndef RTDD_SWEEP_V
+#define RTDD_SWEEP_V 9
+#endif
+#define RTDD_F_EARLY    (RTDD_SWEEP_V >= 2)                        /* edge rows first, published before the interior rows */
+#define RTDD_F_ONEPOLL  (RTDD_SWEEP_V >= 3)                        /* both neighbours' counters in one LDS access */
+#define RTDD_F_SPEC     (RTDD_SWEEP_V == 4 || RTDD_SWEEP_V == 5)   /* no-wait publish + speculative row fetch (slower: see DESIGN.md) */
+#define RTDD_F_ROWGROUP (RTDD_SWEEP_V == 5 || RTDD_SWEEP_V == 7 || RTDD_SWEEP_V >= 9)   /* one row per group */
+#define RTDD_F_PRIO     (RTDD_SWEEP_V >= 6 && RTDD_SWEEP_V <= 8)   /* waves whose neighbours are both ahead raise their issue priority (no gain) */
+#define RTDD_F_PRIO2    (RTDD_SWEEP_V >= 10)                       /* issue priority = distance behind the workgroup's leading wave */
+#define RTDD_F_NOWAIT   (RTDD_F_SPEC || RTDD_SWEEP_V == 8)         /* no s_waitcnt between the row stores and the counter store */
+
 __device__ __forceinline__ void store_result(float4 *p, float4 v) {
 #if RTDD_STORE_MODE == 1
     __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
@@ -136,7 +151,7 @@ __device__ __forceinline__ float rcp_rn(float d) {
 }
 
 template <int LX, int NT, int G, bool CONTRACT, bool PERSIST>
-__global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_blocked(float *Xk, float *Xm, float *Yk, float *Ym,
+__global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) void k_sweep_blocked(float *Xk, float *Xm, float *Yk, float *Ym,
                                                       const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
                                                       const float *__restrict__ omegas, int ip, int rows, int cols,
                                                       int hx, int hy, int nsweeps, float gamma,
@@ -148,7 +163,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     constexpr int EW = 4 * LX, NTR = NT / LX;
     __shared__ float lut[257];
     __shared__ float4 edge[2][NTR][2][LX];     // [buffer][thread row][0 = its top row, 1 = its bottom row][lane]
-    __shared__ int published[NT / 64];         // per wave: number of sweeps whose edge rows it has published
+    __shared__ int published[NT / 64 + 1];     // per wave: number of sweeps whose edge rows it has published; [NT/64]: the maximum over the waves
+    __shared__ int dead_s;                     // the launch has failed (persist_sync.hpp): leave
 
     // (gx, gy) = the grid of tiles.  xcd_tiles > 0 (every multi-tile launch): a 1-D launch of 8 * xcd_tiles workgroups in which
     // workgroup p -- dispatched to XCD p % 8 -- takes tile number (p % 8) * xcd_tiles + p / 8, so that each XCD owns a run
@@ -163,8 +179,10 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     RTDD_STAMP(0);
     const int tid = threadIdx.x;
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];       // blockDim.x <= NT: small levels launch only the thread rows they need
-    if (tid < NT / 64) published[tid] = 0;
+    if (tid <= NT / 64) published[tid] = 0;
+    if (tid == 0) dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     __syncthreads();
+    if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
 
     const int lx = tid % LX, tr = tid / LX;
     const int ntr = (int)blockDim.x / LX;          // thread rows actually launched
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
 
     RTDD_STAMP(1);
     // ---- n sweeps in registers -------------------------------------------------------------------
+#if RTDD_SWEEP_V == 0
     auto sweep = [&](f4r (&cur)[G], f4r (&oth)[G], int s, auto fast) {
         constexpr bool FAST = decltype(fast)::value;
         const int buf = s & 1;
@@ -278,14 +297,223 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
         }
     };
 
+#else
+    // One sweep, written for instruction-level parallelism: the weighted sums and quotients of a GROUP of rows first (12 independent
+    // 7-deep chains the scheduler can interleave -- a wave alone on its SIMD issues a dependent VALU instruction only every ~6.6 cycles,
+    // an independent one every 4), ONE wave-uniform test for numerators too small for the 3-op divide (below), then the updates.
+    //   * "tiny" test: the 3-op divide needs sum == 0 or |sum| >= 2^-100.  Per pixel t = 2 * bits(|sum|) - 1 (one v_lshl_add_u32:
+    //     the shift drops the sign, the wrap-around sends an exact zero to 0xFFFFFFFF), a running v_min3_u32 over the group, one
+    //     compare: 1.5 VALU ops per pixel and no branch, instead of two compares, two SALU ops and a branch per pixel.  A wave that
+    //     does see such a numerator (values decaying through 1e-31, pixels whose four weights are all ~1e-38) recomputes the group
+    //     with the full IEEE divide; x_{k-1} is still intact then because the updates come after the test.
+    //   * RTDD_SWEEP_V >= 2: the rows the neighbours need (a thread's first and last) form the first group and are PUBLISHED as soon
+    //     as they are updated, before the interior rows are computed; the wait for the neighbours' rows at the top of the next sweep
+    //     then finds them already there.  Buffer reuse: I write buffer (s+1)&1 in sweep s after my wait for the neighbours' flags
+    //     >= s+1, which they set after consuming (reading and waiting for) my sweep-(s-1) rows from that buffer.
+    constexpr uint32_t kTinyT = 2u * 0x0D800000u - 1u;          // bits(2^-100) = 27 << 23
+    const int wv = tid >> 6, nwv = (int)blockDim.x >> 6;
+    auto publish = [&](const f4r &top, const f4r &bottom, int sweep_no, int buf) {      // rows that sweep `sweep_no` of the neighbours reads
+        // (buf = sweep_no & 1, passed separately so that it is a compile-time constant in the unrolled sweep pair: every block
+        // starts at an even sweep)
+        *(f4r *)&edge[buf][tr][0][lx] = top;
+        *(f4r *)&edge[buf][tr][1][lx] = bottom;
+#if RTDD_F_NOWAIT
+        // The LDS executes one wave's instructions in issue order, so the counter store below cannot overtake the two row stores:
+        // no s_waitcnt between them (a workgroup-scope release would drain lgkmcnt here, ~100 cycles per sweep with the wave parked).
+        // The wavefront-scope fences only pin the order in the compiler.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __hip_atomic_store(&published[wv], sweep_no + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#else
+        __hip_atomic_store(&published[wv], sweep_no + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+#if RTDD_F_PRIO2
+        __hip_atomic_fetch_max(&published[NT / 64], sweep_no + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    };
+#if RTDD_F_SPEC
+    // Speculative fetch of the rows sweep `sweep_no` needs: counters first, rows behind them, nothing waited for.  Issued right
+    // after the own rows are published and consumed one group of rows later; if the counters (read BEFORE the rows, in order)
+    // already showed the neighbours' rows as published the rows are valid, otherwise fetch again.
+    const int flag_idx = (tid & 63) == 0 ? (wv > 0 ? wv - 1 : wv) : (wv < nwv - 1 ? wv + 1 : wv);
+    int pre_flag = 0;
+    bool broken = false;
+    f4r pre_up = {0, 0, 0, 0}, pre_dn = {0, 0, 0, 0};
+    auto prefetch = [&](int buf) {
+        pre_flag = __hip_atomic_load(&published[flag_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tr > 0) pre_up = *(const f4r *)&edge[buf][tr - 1][1][lx];
+        if (tr < ntr - 1) pre_dn = *(const f4r *)&edge[buf][tr + 1][0][lx];
+    };
+#endif
+    auto await = [&](int sweep_no) {
+#if RTDD_F_ONEPOLL
+        // both neighbours' counters in one LDS access: lane 0 reads the wave above, every other lane the wave below
+#if RTDD_F_PRIO2
+        const int idx = (tid & 63) == 0 ? (wv > 0 ? wv - 1 : wv) : (tid & 63) == 2 ? NT / 64 : (wv < nwv - 1 ? wv + 1 : wv);      // lane 2: the maximum
+#else
+        const int idx = (tid & 63) == 0 ? (wv > 0 ? wv - 1 : wv) : (wv < nwv - 1 ? wv + 1 : wv);
+#endif
+        for (;;) {
+            const int f = __hip_atomic_load(&published[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int f0 = __builtin_amdgcn_readlane(f, 0), f1 = __builtin_amdgcn_readlane(f, 1);
+            const int fmin = f0 < f1 ? f0 : f1;
+            if (fmin >= sweep_no + 1) {
+#if RTDD_F_PRIO2
+                // The SIMD arbitrates by priority, then AGE: left alone, the oldest waves of a SIMD take the issue slots until they block
+                // on a neighbour and the workgroup advances as a staircase, one sweep per wave (wave 0 finishes a block of 8 sweeps in
+                // half the time of the last wave): a 16-stage pipeline that fills and drains once per block.  So: the further a wave
+                // is behind the workgroup's leading wave, the higher its priority.
+                const int behind = __builtin_amdgcn_readlane(f, 2) - (sweep_no + 1);
+                if (behind <= 0) __builtin_amdgcn_s_setprio(0);
+                else if (behind == 1) __builtin_amdgcn_s_setprio(1);
+                else if (behind == 2) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+#endif
+#if RTDD_F_PRIO
+                // The SIMD arbitrates by priority, then AGE: left alone, the oldest two waves of a SIMD take every issue slot until
+                // they block on a neighbour, the youngest starve, and the workgroup advances as a staircase (wave 0 finishes a block
+                // of 8 sweeps in half the time of wave 15) with its SIMDs half idle.  So a wave whose neighbours are already a sweep
+                // ahead -- it is what they will wait for next -- raises its priority, and one that is level or ahead drops it.
+                if (fmin >= sweep_no + 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+        if (wv > 0)
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < sweep_no + 1) __builtin_amdgcn_s_sleep(1);
+        if (wv < nwv - 1)
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < sweep_no + 1) __builtin_amdgcn_s_sleep(1);
+#endif
+    };
+    auto sweep = [&](f4r (&cur)[G], f4r (&oth)[G], int s, auto fast, bool last_of_block, auto parity) {
+        constexpr bool FAST = decltype(fast)::value;
+        constexpr int buf = decltype(parity)::value;         // = s & 1
+#if RTDD_F_SPEC
+        (void)buf;
+        for (unsigned spins = 0;;) {
+            const int f0 = __builtin_amdgcn_readlane(pre_flag, 0), f1 = __builtin_amdgcn_readlane(pre_flag, 1);
+            if ((f0 < f1 ? f0 : f1) >= s + 1 || broken) break;
+            __builtin_amdgcn_s_sleep(1);
+            prefetch(buf);
+            if (++spins > (1u << 20)) {          // ~0.1 s: every wave of a workgroup is resident, so this is a protocol bug -- never hang, say so
+                __hip_atomic_store(&sync_words[kSyncStatus], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                broken = true;
+            }
+        }
+        const float up[4] = {pre_up[0], pre_up[1], pre_up[2], pre_up[3]}, dn[4] = {pre_dn[0], pre_dn[1], pre_dn[2], pre_dn[3]};
+#else
+#if !RTDD_F_EARLY
+        publish(cur[0], cur[G - 1], s, buf);
+#endif
+        await(s);
+        float4 up4 = make_float4(0, 0, 0, 0), dn4 = up4;
+        if (tr > 0) up4 = edge[buf][tr - 1][1][lx];
+        if (tr < ntr - 1) dn4 = edge[buf][tr + 1][0][lx];
+        const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
+#endif
+        const float omega = omegas[s];
+        float xl0[G], xr3[G];                    // filled per group (each costs a register until its row is done)
+        // weighted sum of pixel (g, i): solveDiffusion, src/GPUSolver.cu:73-106, absent neighbours carried as (w = 0, x = 0)
+        auto wsum = [&](int g, int i) {
+            const float xl = i == 0 ? xl0[g] : cur[g][i - 1];
+            const float xr = i == 3 ? xr3[g] : cur[g][i + 1];
+            const float xu = g == 0 ? up[i] : cur[g - 1][i];
+            const float xd = g == G - 1 ? dn[i] : cur[g + 1][i];
+            const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
+            const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
+            float sum = 0.0f;
+            sum = CONTRACT ? __builtin_fmaf(wl, xl, sum) : sum + wl * xl;
+            sum = CONTRACT ? __builtin_fmaf(wr[g][i], xr, sum) : sum + wr[g][i] * xr;
+            sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
+            sum = CONTRACT ? __builtin_fmaf(wd[g][i], xd, sum) : sum + wd[g][i] * xd;
+            return sum;
+        };
+        // rows g of the group selected by `pick`: quotients, the tiny test, updates
+        auto group = [&](auto pick) {
+            float q[G][4];
+            uint32_t tmin = 0xFFFFFFFFu;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (!pick(g)) continue;
+                xl0[g] = lane_from_prev(cur[g][3]); xr3[g] = lane_from_next(cur[g][0]);
+                uint32_t t[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float sum = wsum(g, i);
+#ifdef RTDD_DIAG_NODIV        // (diagnostic ablation: timing only)
+                    q[g][i] = sum * rcp[g][i]; t[i] = 0xFFFFFFFFu;
+#else
+                    if (FAST) { q[g][i] = div_tail(sum, cnt[g][i], rcp[g][i]); t[i] = (__float_as_uint(sum) << 1) + 0xFFFFFFFFu; }
+                    else q[g][i] = sum / cnt[g][i];
+#endif
+                }
+                if (FAST) { tmin = min(min(tmin, t[0]), t[1]); tmin = min(min(tmin, t[2]), t[3]); }
+            }
+#ifdef RTDD_DIAG_NOTINY          // (diagnostic ablation: timing only)
+            tmin = 0xFFFFFFFFu;
+#endif
+            if (FAST && __builtin_expect(__builtin_amdgcn_ballot_w64(tmin < kTinyT) != 0, 0)) {      // wave-uniform, rare
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    if (!pick(g)) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) q[g][i] = wsum(g, i) / cnt[g][i];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (!pick(g)) continue;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    // :104 min(max(r,0),255): v_med3_f32 returns min3 when an operand is NaN, i.e. 0 here, like fmax/fmin
+                    const float r = __builtin_amdgcn_fmed3f(q[g][i], 0.0f, 255.0f);        // cnt == 0 was replaced by 1 (sum is 0 there): r = 0 (:103)
+                    const float x = cur[g][i], prev = oth[g][i];
+                    const float v = CONTRACT ? __builtin_fmaf(omega, __builtin_fmaf(gamma, r - x, x) - prev, prev)      // src/GPUSolver.cu:259
+                                             : (omega * (gamma * (r - x) + x - prev)) + prev;
+                    oth[g][i] = (dirichlet >> (g * 4 + i)) & 1u ? x : v;                    // x_{k+1} replaces x_{k-1}
+                }
+            }
+        };
+#if RTDD_F_EARLY
+#if RTDD_F_ROWGROUP
+        // one row per group: 4 chains are enough to cover the VALU latency, and only 4 quotients + 4 sums are live at a time
+        group([](int g) { return g == 0; });
+        if (G > 1) group([](int g) { return g == G - 1; });
+#else
+        group([](int g) { return g == 0 || g == G - 1; });
+#endif
+        if (!last_of_block) {
+            publish(oth[0], oth[G - 1], s + 1, buf ^ 1);
+#if RTDD_F_SPEC
+            prefetch(buf ^ 1);
+#endif
+        }
+#if RTDD_F_ROWGROUP
+#pragma unroll
+        for (int gi = 1; gi < G - 1; gi++) group([gi](int g) { return g == gi; });
+#else
+        if (G > 2) group([](int g) { return g != 0 && g != G - 1; });
+#endif
+#else
+        (void)last_of_block;
+        group([](int) { return true; });
+#endif
+    };
+#define RTDD_SWEEP_NEW 1
+#endif
+
     // (the divide variant is chosen per wave; the neighbour handshake above does not care which one a wave runs)
-    const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
     const int tile_id = by * gx + bx, ntiles = gx * gy;
     int s = 0, blk = 0;
     bool odd = false;
     RTDD_XT_BEGIN;
     for (;; blk++) {
         const int s_end = min(s + block_sweeps, nsweeps);
+#if RTDD_SWEEP_V == 0
         if (!wave_unsafe) {
             for (; s + 1 < s_end; s += 2) {
                 sweep(a, b, s, std::true_type{});
@@ -299,17 +527,46 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
             }
             if (s < s_end) { sweep(a, b, s, std::false_type{}); s++; odd = true; }
         }
+#else
+#if RTDD_F_EARLY
+        publish(a[0], a[G - 1], s, 0);               // block prologue: the rows the first sweep of this block reads (a = newest here; s is even)
+#endif
+#if RTDD_F_SPEC
+        prefetch(0);
+#endif
+        using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+        if (!wave_unsafe) {
+            for (; s + 1 < s_end; s += 2) {
+                sweep(a, b, s, std::true_type{}, false, P0{});
+                sweep(b, a, s + 1, std::true_type{}, s + 2 >= s_end, P1{});
+            }
+            if (s < s_end) { sweep(a, b, s, std::true_type{}, true, P0{}); s++; odd = true; }
+        } else {
+            for (; s + 1 < s_end; s += 2) {
+                sweep(a, b, s, std::false_type{}, false, P0{});
+                sweep(b, a, s + 1, std::false_type{}, s + 2 >= s_end, P1{});
+            }
+            if (s < s_end) { sweep(a, b, s, std::false_type{}, true, P0{}); s++; odd = true; }
+        }
+#endif
         if (!PERSIST || s >= nsweeps) break;
         RTDD_XT(0);
 
         // ---- persistent mode: refresh the halo from the neighbours (block_sweeps is even here, so a = newest) ----
-        // Protocol (cdna_hip_programming.md Guideline 16, R1): write-through (sc1) payload stores; EVERY storing wave
-        // drains vmcnt; workgroup barrier; ONE lane stores the flag (agent-scope atomic); one wave polls the 8
-        // neighbour flags relaxed with s_sleep (bounded); ONE agent acquire; barrier; plain vector loads.
+        // Protocol: persist_sync.hpp (write-through payload stores, every storing wave drains, barrier, then exchange_wait()).
         // Exchange buffers alternate between (Yk,Ym) and (Xk,Xm) by block parity: a neighbour publishes block b+1 only
         // after consuming my block-b strips, and I overwrite that buffer (block b+2) only after waiting for its b+1.
         {
             float *Ek = (blk & 1) ? Xk : Yk, *Em = (blk & 1) ? Xm : Ym;
+            // The exchange's addresses and predicates are recomputed here from "laundered" copies of the thread coordinates: left
+            // to itself the compiler hoists them (six 64-bit offsets, a dozen lane masks) out of the block loop, where they stay
+            // live across the sweeps and push the sweep loop's operands into scratch.
+            int tid_x = tid;
+            asm volatile("" : "+v"(tid_x));
+            const int lx = tid_x % LX, tr = tid_x / LX;
+            const int x0 = bx * TW - hx + 4 * lx, y0 = by * TH - hy + tr * G;
+            const bool colok = x0 >= 0 && x0 < cols;
+            const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const int y = y0 + g, ty = tr * G + g;
@@ -324,22 +581,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
             __syncthreads();
             RTDD_XT(1);
-            int *flags = sync_words + 16;
-            if (tid == 0) __hip_atomic_store(&flags[tile_id], blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid < 9 && tid != 4) {                                   // lane i polls neighbour (i%3-1, i/3-1)
-                const int nx = bx + tid % 3 - 1, ny = by + tid / 3 - 1;
-                if (nx >= 0 && ny >= 0 && nx < gx && ny < gy) {
-                    const int nb = ny * gx + nx;
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(&flags[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < blk + 1) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 22)) { __hip_atomic_store(&sync_words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never hang: flag the solve as failed
-                    }
-                }
-            }
+            if (exchange_wait(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, blk + 1)) return;      // flag, bounded poll, acquire, barrier
             RTDD_XT(2);
-            if (tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            __syncthreads();
             RTDD_XT(3);
 #pragma unroll
             for (int g = 0; g < G; g++) {
@@ -364,10 +607,15 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
     RTDD_STAMP(2);
 
     // ---- write back the part that is still exact ---------------------------------------------------
+    int tid_w = tid;
+    asm volatile("" : "+v"(tid_w));                  // (as in the exchange: keep this address arithmetic out of the sweep loops)
+    const int lx_w = tid_w % LX, tr_w = tid_w / LX;
+    const int x0_w = bx * TW - hx + 4 * lx_w, y0_w = by * TH - hy + tr_w * G;
+    const bool xin_w = x0_w >= 0 && x0_w < cols && 4 * lx_w >= hx && 4 * lx_w < EW - hx;
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        const int y = y0 + g, ty = tr * G + g;
-        if (xin && ty >= hy && ty < eh - hy && y < rows) {
+        const int y = y0_w + g, ty = tr_w * G + g, x0 = x0_w;
+        if (xin_w && ty >= hy && ty < eh - hy && y < rows) {
             const size_t off = (size_t)y * ip + x0;
             // newest iterate -> Yk, the one before it -> Ym (componentwise selects: a pointer-select would go through scratch)
             const float4 vk = make_float4(odd ? b[g][0] : a[g][0], odd ? b[g][1] : a[g][1], odd ? b[g][2] : a[g][2], odd ? b[g][3] : a[g][3]);
@@ -389,8 +637,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : 3)) void k_sweep_bl
 struct TileCfg { int lx, nt, g; };
 // id -> (lanes per tile row, threads, rows per thread); extended tile = 4*lx wide, nt/lx*g tall
 static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 1024, 4}, {32, 1024, 3}, {32, 512, 3}, {16, 512, 3}, {16, 256, 3}, {32, 1024, 2},
-                                 {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}, {32, 768, 4}};
-constexpr int kNumTiles = 12;
+                                 {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}, {32, 768, 4}, {32, 512, 6}};
+constexpr int kNumTiles = 13;
 
 template <int LX, int NT, int G>
 static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, float *Xk, float *Xm, float *Yk, float *Ym, const uint32_t *M,
@@ -416,7 +664,7 @@ static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, fl
 //   persistent                 T sweeps + ~8 us halo exchange (6 us for the small tiles); needs nWG <= #CUs, T even,
 //                              halo no wider than a neighbour's centre
 // It only has to rank candidates; it reproduces the measured launch times within ~15 %.
-static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1};
+static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1};
 
 static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int tile, int T, bool persist) {
     const int G = kTiles[tile].g;
@@ -522,12 +770,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
                                 (T % 2 == 0) && n - done > T && hy == T &&
                                 hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
         if (persistent) {
-            if (!ctx->sync_words) {
-                RTDD_HIP(ctx, hipMalloc((void **)&ctx->sync_words, 1024 * sizeof(int) + 64));
-                RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words, 0, 64, ctx->stream));
-            }
-            // per-tile flags are zeroed every call; the status word [0] is sticky until rtdd_ctx_synchronize() reads it
-            RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + 16, 0, 1024 * sizeof(int), ctx->stream));
+            { const int rc_ = prepare_persistent_launch(ctx); if (rc_ != RTDD_OK) return rc_; }   // zero the tile flags, debug words
             ctx->persistent_used = true;
             block_sweeps = T;
             m = n - done;
@@ -556,6 +799,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             RTDD_TILE_CASE(10, 16, 512, 2)
             RTDD_TILE_CASE(11, 32, 1024, 1)
             RTDD_TILE_CASE(12, 32, 768, 4)
+            RTDD_TILE_CASE(13, 32, 512, 6)
         }
 #undef RTDD_TILE_CASE
         // where the results are: the plain launch writes the spare pair; the persistent one the exchange buffer of its

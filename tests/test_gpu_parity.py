@@ -72,7 +72,7 @@ def test_solver_bit_exact(ctx, oracle, lut, shape, level, levels, iters, contrac
     assert_bit_equal(got, want, f"solver {shape} level {level}")
 
 
-@pytest.mark.parametrize("tile,depth", [(1, 1), (1, 4), (1, 7), (1, 8), (1, 16), (2, 4), (2, 8), (2, 5), (3, 4), (3, 12), (3, 16)])
+@pytest.mark.parametrize("tile,depth", [(1, 1), (1, 4), (1, 7), (1, 8), (1, 16), (2, 4), (2, 8), (2, 5), (3, 4), (3, 12), (3, 16), (12, 8), (13, 8), (13, 5)])
 @pytest.mark.parametrize("shape,iters,level,levels", [((200, 333), 37, 0, 1), ((67, 120), 64, 1, 2), ((300, 130), 24, 0, 2), ((129, 129), 19, 0, 1)])
 def test_blocked_kernel_bit_exact(ctx, oracle, lut, tile, depth, shape, iters, level, levels):
     """Temporal blocking is only a re-schedule: any tile shape / depth must reproduce the oracle bit for bit."""
@@ -95,6 +95,9 @@ def test_blocked_kernel_bit_exact(ctx, oracle, lut, tile, depth, shape, iters, l
     ((135, 240), 500, 9, 16),      # depth 16: 8x5 tiles of 32x32 centres
     ((540, 960), 125, 4, 8),
     ((1080, 1920), 200, 4, 8),     # 252 workgroups: the headline configuration
+    ((1080, 1920), 120, 12, 8),    # the same tile held by 12 waves of 16 pixels per thread
+    ((1080, 1920), 120, 13, 8),    # ... and by 8 waves of 24 pixels per thread
+    ((270, 480), 50, 13, 8),
     ((300, 130), 64, 7, 16),
 ])
 def test_persistent_mode_bit_exact(ctx, oracle, lut, shape, iters, tile, depth):
@@ -127,7 +130,7 @@ def test_randomised_shapes_and_options(ctx, oracle, lut):
         kernel = int(rng.choice([0, 0, 1, 2]))
         opts = {rt.OPT_SWEEP_KERNEL: kernel, rt.OPT_PERSISTENT: int(rng.integers(0, 2))}
         if kernel != 1 and rng.random() < 0.6:
-            opts[rt.OPT_TILE] = int(rng.integers(1, 13)); opts[rt.OPT_TEMPORAL_DEPTH] = int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 24]))
+            opts[rt.OPT_TILE] = int(rng.integers(1, 14)); opts[rt.OPT_TEMPORAL_DEPTH] = int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 24]))
         p = make_problem(rows, cols, seed=1000 + trial)
         if (p["mask"] == 255).sum() == 0:
             p["mask"][rows // 2, cols // 2] = 255; p["depth"][rows // 2, cols // 2] = 128
