@@ -72,6 +72,13 @@ enum rtdd_option {
     RTDD_OPT_ROWS_PER_WAVE = 4,     /* one-sweep kernel: rows each wave walks (0 = auto) */
     RTDD_OPT_PERSISTENT = 6,        /* 1 (default): levels whose tiles all fit on the chip at once run ALL sweeps in one launch,
                                        neighbouring workgroups trading halo strips in memory (no kernel boundaries) */
+    /* RTDD_METHOD_AUTO prices the V-cycles still needed against finishing with SOR cycles.  The prices are these four CONSTANTS
+     * (never a clock: a solve is reproducible); they are options so that the decision can be restated from outside and re-tuned
+     * without touching bits by accident.  cycle = FIXED_NS + pixels * CYCLE_FS_PER_PX; sweep = max(FLOOR_NS, pixels * SWEEP_FS_PER_PX). */
+    RTDD_OPT_AUTO_CYCLE_FIXED_NS = 9,    /* default 270000 */
+    RTDD_OPT_AUTO_CYCLE_FS_PER_PX = 10,  /* default 46000 (femtoseconds per level-0 pixel) */
+    RTDD_OPT_AUTO_SWEEP_FS_PER_PX = 11,  /* default 1429 */
+    RTDD_OPT_AUTO_SWEEP_FLOOR_NS = 12,   /* default 2500 */
     RTDD_OPT_DEBUG_WITHHOLD_TILE = 7, /* testing aid: tile number + 1 whose hand-off flag a persistent launch never publishes (0 = off),
                                        so that its neighbours run into the poll limit -> RTDD_ERR_TIMEOUT */
     RTDD_OPT_DEBUG_POLL_LIMIT_US = 8, /* testing aid: that poll limit in microseconds (0 = the default, 200 ms) */
@@ -136,6 +143,14 @@ typedef struct rtdd_solve_info {
     int iterations;                 /* sweeps actually executed (RTDD_METHOD_MULTIGRID: cycles) */
     float residual;                 /* last evaluated max|J(x)-x| (NaN if never evaluated) */
     int cycles;                     /* V-cycles executed (RTDD_METHOD_MULTIGRID, RTDD_METHOD_AUTO), else 0 */
+    /* what actually ran, so that a log line identifies the code path (the automatic choices depend on the image size): */
+    int kernel;                     /* sweep kernel of the LAST sweep launch: 1 one Jacobi sweep per launch, 2 temporally blocked Jacobi,
+                                     * 3 one red-black colour per launch, 4 register-blocked red-black; 0 = no sweep launch */
+    int tile;                       /* blocked kernels: tile id (RTDD_OPT_TILE numbering; red-black: 1 = 128x64, 2 = 128x128) */
+    int temporal_depth;             /* blocked kernels: sweeps per launch (persistent: per exchange) */
+    int persistent;                 /* 1: that launch was persistent (all its sweeps in one launch) */
+    int fp_contract;                /* RTDD_OPT_FP_CONTRACT in force */
+    int launches;                   /* kernel launches of the solve, k_prepare / k_finish excluded */
 } rtdd_solve_info;
 
 int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch,
@@ -143,6 +158,10 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch,
                   const uint8_t *gray, size_t grayPitch,
                   int rows, int cols, int level,
                   const rtdd_solve_params *params, rtdd_solve_info *info);
+
+/* The rtdd_solve_info of the most recent rtdd_solve_ex / rtdd_matrix_free_solver call on this context (also of the per-level
+ * solves inside rtdd_estimate_depth: the finest level's). */
+int rtdd_last_solve_info(rtdd_ctx *ctx, rtdd_solve_info *info);
 
 /* Diagnostic for the parity tests: after a RTDD_METHOD_MULTIGRID solve, copy plane `which` (0-4: couplings E,S,SE,SW and
  * diagonal D; 5-8: interpolation weights; 9-11: e, b, r) of hierarchy level `level` to host memory, dense rows x cols

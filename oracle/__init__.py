@@ -191,13 +191,14 @@ def rbgs_sweep(x, idx, mask, lut, contract, omega=1.0):
     return x
 
 
-def mg_solve(x, idx, mask, lut, contract, max_cycles, tolerance=0.0, check_every=1, alternative_seconds=0.0):
+def mg_solve(x, idx, mask, lut, contract, max_cycles, tolerance=0.0, check_every=1, alternative_seconds=0.0, cycle_seconds=0.0):
     """Multigrid V-cycles (extension; rtdd_mg_oracle.c) in place on x.  Returns (cycles, residual, levels)."""
     rows, cols = x.shape
     assert x.flags.c_contiguous and x.dtype == np.float32
     cyc = C.c_int(0); res = C.c_float(0)
     nlev = lib().orc_mg_solve(_p(x), _p(idx), _p(mask), _pitch(mask), C.c_int(rows), C.c_int(cols), _p(lut), C.c_int(contract),
-                              C.c_int(max_cycles), C.c_float(tolerance), C.c_int(check_every), C.c_double(alternative_seconds), C.byref(cyc), C.byref(res))
+                              C.c_int(max_cycles), C.c_float(tolerance), C.c_int(check_every), C.c_double(alternative_seconds), C.c_double(cycle_seconds),
+                              C.byref(cyc), C.byref(res))
     return cyc.value, res.value, nlev
 
 

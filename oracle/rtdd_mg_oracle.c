@@ -210,7 +210,7 @@ static void prolong_add(const mg_level *c, const mg_level *f, float *target) {
 
 /* x: rows x cols dense, Dirichlet values in place where mask == 255; index2 as orc_index_to_weight writes it. */
 ORC_API int orc_mg_solve(float *x, const int32_t *index2, const uint8_t *mask, size_t maskPitch, int rows, int cols, const float *lut, int contract,
-                         int max_cycles, float tolerance, int check_every, double alternative_seconds, int *cycles_done, float *residual_out) {
+                         int max_cycles, float tolerance, int check_every, double alternative_seconds, double cycle_seconds, int *cycles_done, float *residual_out) {
     mg_free();
     int r = rows, c = cols;
     for (int l = 0; l < MG_MAXLEV; l++) {
@@ -279,7 +279,7 @@ ORC_API int orc_mg_solve(float *x, const int32_t *index2, const uint8_t *mask, s
                 const double rate = sqrt((double)*residual_out / (double)before2);
                 if (!(rate < 1.0)) break;
                 const double needed = ceil(log((double)*residual_out / (double)tolerance) / -log(rate));
-                if (needed * (270e-6 + (double)rows * cols * 46e-12) > alternative_seconds) break;
+                if (needed * cycle_seconds > alternative_seconds) break;       /* both prices are the caller's constants */
             }
             /* vector extrapolation: the residual shrank by the same factor lambda twice in a row -> remove that family */
             since++;

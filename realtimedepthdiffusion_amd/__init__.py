@@ -27,13 +27,14 @@ METHOD_AUTO = 3
 RELAXATION_AUTO = -1.0                     # rtdd_solve_params.relaxation: SOR cycles (include/rtdd.h)
 OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, _OPT_RESERVED_3, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
 OPT_DEBUG_WITHHOLD_TILE, OPT_DEBUG_POLL_LIMIT_US = 7, 8
+OPT_AUTO_CYCLE_FIXED_NS, OPT_AUTO_CYCLE_FS_PER_PX, OPT_AUTO_SWEEP_FS_PER_PX, OPT_AUTO_SWEEP_FLOOR_NS = 9, 10, 11, 12
 RTDD_ERR_TIMEOUT = 6
 
 # every symbol include/rtdd.h declares (checked by tests/test_abi.py against the header)
 C_ABI_SYMBOLS = [
     "rtdd_ctx_create", "rtdd_ctx_destroy", "rtdd_ctx_set_stream", "rtdd_ctx_synchronize", "rtdd_set_option",
     "rtdd_get_option", "rtdd_last_error", "rtdd_status_string", "rtdd_version", "rtdd_allocate", "rtdd_free",
-    "rtdd_load_weights", "rtdd_matrix_free_solver", "rtdd_solve_ex", "rtdd_multigrid_level", "rtdd_index_to_weight", "rtdd_convert_to_float",
+    "rtdd_load_weights", "rtdd_matrix_free_solver", "rtdd_solve_ex", "rtdd_last_solve_info", "rtdd_multigrid_level", "rtdd_index_to_weight", "rtdd_convert_to_float",
     "rtdd_pyrdown_annotation", "rtdd_paint_image", "rtdd_simulate_defocus", "rtdd_simulate_desaturation",
     "rtdd_simulate_haze", "rtdd_profile_enable", "rtdd_profile_get",
     "rtdd_pyramid_levels", "rtdd_pyramid_create", "rtdd_pyramid_destroy", "rtdd_pyramid_set_image",
@@ -61,7 +62,12 @@ class SolveParams(C.Structure):
 
 
 class SolveInfo(C.Structure):
-    _fields_ = [("iterations", C.c_int), ("residual", C.c_float), ("cycles", C.c_int)]
+    _fields_ = [("iterations", C.c_int), ("residual", C.c_float), ("cycles", C.c_int), ("kernel", C.c_int), ("tile", C.c_int),
+                ("temporal_depth", C.c_int), ("persistent", C.c_int), ("fp_contract", C.c_int), ("launches", C.c_int)]
+
+    def describe(self):
+        return (f"kernel {self.kernel} tile {self.tile} depth {self.temporal_depth} persistent {self.persistent} contract {self.fp_contract} "
+                f"launches {self.launches} iterations {self.iterations} cycles {self.cycles} residual {self.residual:.3g}")
 
 
 class Profile(C.Structure):
@@ -163,6 +169,15 @@ class Context:
         self._check(lib().rtdd_get_option(self._h, C.c_int(key), C.byref(v)))
         return v.value
 
+    def auto_model(self, rows, cols):
+        """(seconds RTDD_METHOD_AUTO prices its SOR-cycle alternative at, seconds per V-cycle): csrc/api.cpp Solve::automatic(),
+        from the RTDD_OPT_AUTO_* constants the library holds."""
+        px = float(rows * cols)
+        sweep = max(px * self.get_option(OPT_AUTO_SWEEP_FS_PER_PX) * 1e-15, self.get_option(OPT_AUTO_SWEEP_FLOOR_NS) * 1e-9)
+        sor = (((max(rows, cols) + 1) // 2) * 1.25 + 20.0) * sweep
+        cycle = self.get_option(OPT_AUTO_CYCLE_FIXED_NS) * 1e-9 + px * self.get_option(OPT_AUTO_CYCLE_FS_PER_PX) * 1e-15
+        return sor, cycle
+
     def profile_enable(self, on=True):
         self._check(lib().rtdd_profile_enable(self._h, C.c_int(1 if on else 0)))
 
@@ -195,6 +210,12 @@ class Context:
                                         C.byref(params), C.byref(info)))
         self.last_cycles = info.cycles          # V-cycles of the last solve (METHOD_MULTIGRID / METHOD_AUTO)
         return info.iterations, info.residual
+
+    def last_solve_info(self):
+        """What the most recent solve on this context actually ran (kernel, tile, depth, persistence, contraction, counts)."""
+        info = SolveInfo()
+        self._check(lib().rtdd_last_solve_info(self._h, C.byref(info)))
+        return info
 
     def multigrid_level(self, level, which):
         """Diagnostic: plane `which` of hierarchy level `level` after a METHOD_MULTIGRID solve, as a numpy array."""

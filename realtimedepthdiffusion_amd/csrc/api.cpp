@@ -162,6 +162,10 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
         case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 13, "tile must be 0..13"); ctx->opt.tile = value; break;
         case RTDD_OPT_PERSISTENT: ctx->opt.persistent = value ? 1 : 0; break;
+        case RTDD_OPT_AUTO_CYCLE_FIXED_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fixed_ns = value; break;
+        case RTDD_OPT_AUTO_CYCLE_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fs_per_px = value; break;
+        case RTDD_OPT_AUTO_SWEEP_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_sweep_fs_per_px = value; break;
+        case RTDD_OPT_AUTO_SWEEP_FLOOR_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_sweep_floor_ns = value; break;
         case RTDD_OPT_DEBUG_WITHHOLD_TILE: REQUIRE(ctx, value >= 0 && value <= kSyncMaxTiles, "tile number + 1 out of range"); ctx->opt.debug_withhold_tile = value; break;
         case RTDD_OPT_DEBUG_POLL_LIMIT_US: REQUIRE(ctx, value >= 0 && value <= 10000000, "poll limit must be 0..1e7 us"); ctx->opt.debug_poll_limit_us = value; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
@@ -178,6 +182,10 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_ROWS_PER_WAVE: *value = ctx->opt.rows_per_wave; break;
         case RTDD_OPT_TILE: *value = ctx->opt.tile; break;
         case RTDD_OPT_PERSISTENT: *value = ctx->opt.persistent; break;
+        case RTDD_OPT_AUTO_CYCLE_FIXED_NS: *value = ctx->opt.auto_cycle_fixed_ns; break;
+        case RTDD_OPT_AUTO_CYCLE_FS_PER_PX: *value = ctx->opt.auto_cycle_fs_per_px; break;
+        case RTDD_OPT_AUTO_SWEEP_FS_PER_PX: *value = ctx->opt.auto_sweep_fs_per_px; break;
+        case RTDD_OPT_AUTO_SWEEP_FLOOR_NS: *value = ctx->opt.auto_sweep_floor_ns; break;
         case RTDD_OPT_DEBUG_WITHHOLD_TILE: *value = ctx->opt.debug_withhold_tile; break;
         case RTDD_OPT_DEBUG_POLL_LIMIT_US: *value = ctx->opt.debug_poll_limit_us; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
@@ -402,7 +410,9 @@ struct Solve {
 
     // V-cycles; alternative_seconds > 0: leave when the cycles still needed are modelled dearer than that (RTDD_METHOD_AUTO)
     int vcycles(int max_cycles, int check_every, double alternative_seconds) {
-        return launch_multigrid(ctx, L, ip, rows, cols, max_cycles, p->tolerance, check_every, alternative_seconds, &pk, &cycles, &residual, &launches);
+        const double px = (double)rows * cols;
+        const double cycle_seconds = ctx->opt.auto_cycle_fixed_ns * 1e-9 + px * ctx->opt.auto_cycle_fs_per_px * 1e-15;
+        return launch_multigrid(ctx, L, ip, rows, cols, max_cycles, p->tolerance, check_every, alternative_seconds, cycle_seconds, &pk, &cycles, &residual, &launches);
     }
 
     // V-cycles while they pay: they stop at the tolerance, after kAutoMaxCycles, or when the cycles still needed (at the rate of the
@@ -411,7 +421,8 @@ struct Solve {
     int automatic() {
         const int longest = rows > cols ? rows : cols;
         const double px = (double)rows * cols;
-        const double sweep_seconds = px / 700e9 > 2.5e-6 ? px / 700e9 : 2.5e-6;            // k_rbgs_blocked, measured
+        const double per_px = px * ctx->opt.auto_sweep_fs_per_px * 1e-15, floor_s = ctx->opt.auto_sweep_floor_ns * 1e-9;
+        const double sweep_seconds = per_px > floor_s ? per_px : floor_s;                   // k_rbgs_blocked (constants: RTDD_OPT_AUTO_*)
         const double sor_seconds = ((double)((longest + 1) / 2) * 1.25 + 20.0) * sweep_seconds;
         const int rc = vcycles(kAutoMaxCycles, 1, sor_seconds);
         if (rc != RTDD_OK || reached()) return rc;
@@ -445,6 +456,8 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     if (rc != RTDD_OK) return rc;
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
 
+    ctx->last_info = rtdd_solve_info{};
+    ctx->last_info.residual = NAN;
     Solve s{ctx, L, ip, rows, cols, params};
     switch (params->method) {
         case RTDD_METHOD_CHEBYSHEV_JACOBI: rc = s.chebyshev_jacobi(); break;
@@ -466,7 +479,15 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
         ctx->prof_launches[slot] = s.launches; ctx->prof_sweeps[slot] = s.done;
         ctx->prof_pending++;                        // resolved (and synchronised) by rtdd_profile_get, not here
     }
-    if (info) { info->iterations = s.done; info->residual = s.residual; info->cycles = s.cycles; }
+    ctx->last_info.iterations = s.done; ctx->last_info.residual = s.residual; ctx->last_info.cycles = s.cycles;
+    ctx->last_info.fp_contract = ctx->opt.fp_contract; ctx->last_info.launches = s.launches;
+    if (info) *info = ctx->last_info;
+    return RTDD_OK;
+}
+
+int rtdd_last_solve_info(rtdd_ctx *ctx, rtdd_solve_info *info) {
+    if (!ctx || !info) return RTDD_ERR_INVALID;
+    *info = ctx->last_info;
     return RTDD_OK;
 }
 

@@ -557,15 +557,11 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     return RTDD_OK;
 }
 
-// Modelled duration of one V-cycle with its residual check (seconds): ~50 launch-bound launches on the small levels + the
-// streaming part (measured 0.36 / 0.65 / 1.78 ms at 1080p / 4K / 8K, scripts/config5_bench.py).
-static double cycle_seconds(int rows, int cols) { return 270e-6 + (double)rows * cols * 46e-12; }
-
 // alternative_seconds > 0 (RTDD_METHOD_AUTO): leave as soon as the cycles still needed at the rate of the last two,
-// priced by cycle_seconds, cost more than the alternative (SOR cycles from here).  A deterministic rule on the f32
-// residuals -- no clocks -- so that a solve is reproducible.
+// priced at cycle_seconds each, cost more than the alternative (SOR cycles from here).  Both prices come from the caller's
+// constants (rtdd_set_option RTDD_OPT_AUTO_*): a deterministic rule on the f32 residuals -- no clocks -- so a solve is reproducible.
 int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every, double alternative_seconds,
-                     int *plane, int *cycles_done, float *residual, int *launches) {
+                     double cycle_seconds, int *plane, int *cycles_done, float *residual, int *launches) {
     int rc = mg_setup(ctx, L0, ip, rows, cols, launches);
     if (rc != RTDD_OK) return rc;
     *cycles_done = 0;
@@ -582,7 +578,7 @@ int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
                 const double rate = sqrt((double)*residual / (double)before2);         // per cycle, over the last two
                 if (!(rate < 1.0)) break;
                 const double needed = ceil(log((double)*residual / (double)tolerance) / -log(rate));
-                if (needed * cycle_seconds(rows, cols) > alternative_seconds) break;
+                if (needed * cycle_seconds > alternative_seconds) break;
             }
             // Vector extrapolation.  Once the residual shrinks by the same factor lambda two cycles in a row, what is left is
             // one slowly decaying family, e_k = lambda e_{k-1}, and x_k + lambda/(1-lambda) (x_k - x_{k-1}) removes it

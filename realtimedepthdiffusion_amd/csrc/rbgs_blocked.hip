@@ -299,6 +299,7 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
             default: RTDD_RBGS_GO(1024, true, true); break;
         }
 #undef RTDD_RBGS_GO
+        ctx->last_info.kernel = 4; ctx->last_info.tile = big ? 2 : 1; ctx->last_info.temporal_depth = persistent ? block_sweeps : m; ctx->last_info.persistent = persistent ? 1 : 0;
         // every image pixel belongs to exactly one tile's centre, so the result plane is complete; it is the spare plane, or --
         // after an odd number of persistent exchanges -- the input plane again
         const int nblocks = (m + block_sweeps - 1) / block_sweeps;

@@ -48,6 +48,12 @@ struct Options {
     int rows_per_wave = 0;
     int tile = 0;
     int persistent = 1;
+    // RTDD_METHOD_AUTO's cost model (constants, not clocks: a solve is reproducible).  Readable and settable as options so that
+    // what decided a solve can be restated from outside (tests/test_gpu_multigrid.py).
+    int auto_cycle_fixed_ns = 270000;    // a V-cycle with its residual check: launch-bound part ...
+    int auto_cycle_fs_per_px = 46000;    // ... plus streaming part per level-0 pixel (femtoseconds)
+    int auto_sweep_fs_per_px = 1429;     // one red-black sweep per pixel (1 / 700 Gpx-sweeps/s) ...
+    int auto_sweep_floor_ns = 2500;      // ... but never below one launch-bound sweep
     int debug_withhold_tile = 0;     // RTDD_OPT_DEBUG_WITHHOLD_TILE: tile number + 1 whose exchange flag is never published (0 = off)
     int debug_poll_limit_us = 0;     // RTDD_OPT_DEBUG_POLL_LIMIT_US: exchange poll limit (0 = default, 200 ms)
 };
@@ -71,6 +77,7 @@ struct rtdd_ctx {
     float *residual_dev = nullptr;  // extension: residual reduction target
     int *sync_words = nullptr;      // control words of the persistent kernels (persist_sync.hpp); allocated with the context
     int sync_header[2] = {0, 0};    // what sync_words[kSyncWithhold], [kSyncLimit] currently hold on the device
+    rtdd_solve_info last_info{};    // of the most recent solve; kernel/tile/temporal_depth/persistent are filled in by the sweep launchers
     bool persistent_used = false;   // a persistent launch happened since the last status check
     uint32_t *sat = nullptr;        // defocus summed-area table scratch
     size_t sat_elems = 0;
@@ -132,7 +139,7 @@ int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int row
 int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps, float omega);
 // ---- multigrid.hip ------------------------------------------------------------------------------
 int launch_multigrid(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int cols, int max_cycles, float tolerance, int check_every, double alternative_seconds,
-                     int *plane, int *cycles_done, float *residual, int *launches);
+                     double cycle_seconds, int *plane, int *cycles_done, float *residual, int *launches);
 void mg_release(rtdd_ctx *ctx);
 int mg_download(rtdd_ctx *ctx, int level, int which, float *host, int *rows, int *cols);
 

@@ -327,6 +327,7 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
                   int *pk, int *pm, int *launches) {
     const float gamma = 0.99;                 // src/GPUSolver.cu:285 (double literal narrowed to float)
     const int R = pick_rows_per_wave(ctx, rows, cols);
+    ctx->last_info.kernel = 1; ctx->last_info.tile = 0; ctx->last_info.temporal_depth = 1; ctx->last_info.persistent = 0;
     const dim3 grid((cols + 255) / 256, (rows + 4 * R - 1) / (4 * R));
     int a = *pk, b = *pm;                     // plane a holds x_k, plane b holds x_{k-1} and receives x_{k+1}
     for (int it = 0; it < n; it++) {
@@ -365,6 +366,7 @@ int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int row
 }
 
 int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps, float omega) {
+    ctx->last_info.kernel = 3; ctx->last_info.tile = 0; ctx->last_info.temporal_depth = 1; ctx->last_info.persistent = 0;
     const dim3 grid(((cols + 1) / 2 + 63) / 64, (rows + 3) / 4);
     for (int s = 0; s < nsweeps; s++)
         for (int colour = 0; colour < 2; colour++) {

@@ -640,6 +640,25 @@ static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 102
                                  {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}, {32, 768, 4}, {32, 512, 6}};
 constexpr int kNumTiles = 13;
 
+// Can every workgroup of a persistent launch be resident at once?  Asked of the runtime once per kernel (the answer depends on the
+// kernel's registers and LDS): at least one workgroup of `nthreads` threads per CU, and no more workgroups than CUs.  A launch that
+// fails this falls back to one launch per block.  (A cooperative launch would make the same check at +15..19 us of host time per
+// launch and gives no other guarantee -- MI355X_MICROARCH.md, "Residency and cooperative launch"; a GPU shared with other work
+// can still starve a resident-by-count launch, which is what the bounded poll in persist_sync.hpp is for.)
+template <typename K>
+static bool fits_one_per_cu(K kernel, int nthreads) {
+    int nb = 0;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, nthreads, 0) == hipSuccess && nb >= 1;
+}
+
+template <int LX, int NT, int G>
+static bool persistent_possible(const rtdd_ctx *ctx, int nthreads) {
+    static int cache[2] = {-1, -1};
+    int &c = cache[ctx->opt.fp_contract ? 1 : 0];
+    if (c < 0) c = ctx->opt.fp_contract ? fits_one_per_cu(k_sweep_blocked<LX, NT, G, true, true>, nthreads) : fits_one_per_cu(k_sweep_blocked<LX, NT, G, false, true>, nthreads);
+    return c == 1;
+}
+
 template <int LX, int NT, int G>
 static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, float *Xk, float *Xm, float *Yk, float *Ym, const uint32_t *M,
                        const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma, int block_sweeps) {
@@ -724,6 +743,11 @@ static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fi
         fprintf(stderr, "[rtdd] %dx%d n=%d -> tile %d depth %d persistent %d (model %.3f us/sweep)\n", cols, rows, n, *tile, *T, (int)*persist, best);
 }
 
+#define RTDD_ALL_TILES \
+    RTDD_TILE_CASE(1, 16, 256, 4) RTDD_TILE_CASE(2, 32, 512, 4) RTDD_TILE_CASE(3, 32, 1024, 4) RTDD_TILE_CASE(4, 32, 1024, 3) RTDD_TILE_CASE(5, 32, 512, 3) \
+    RTDD_TILE_CASE(6, 16, 512, 3) RTDD_TILE_CASE(7, 16, 256, 3) RTDD_TILE_CASE(8, 32, 1024, 2) RTDD_TILE_CASE(9, 16, 1024, 1) RTDD_TILE_CASE(10, 16, 512, 2) \
+    RTDD_TILE_CASE(11, 32, 1024, 1) RTDD_TILE_CASE(12, 32, 768, 4) RTDD_TILE_CASE(13, 32, 512, 6)
+
 // Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
 // holding x_{k+n} / x_{k+n-1}.  omegas_dev[0..n) must already be on the device.
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
@@ -766,9 +790,14 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         // PERSISTENT mode: all remaining sweeps in ONE launch, neighbouring workgroups trade halo strips every T sweeps.
         // Only when every workgroup is certainly co-resident (grid <= #CUs), T is even, and there is more than one block.
         int block_sweeps = m;
-        const bool persistent = !single && want_persistent && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= 1000 &&
+        bool persistent = !single && want_persistent && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= (unsigned)kSyncMaxTiles &&
                                 (T % 2 == 0) && n - done > T && hy == T &&
                                 hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
+        if (persistent) {
+#define RTDD_TILE_CASE(id, LX_, NT_, G_) case id: persistent = persistent_possible<LX_, NT_, G_>(ctx, kTiles[tile].nt); break;
+            switch (tile) { RTDD_ALL_TILES }
+#undef RTDD_TILE_CASE
+        }
         if (persistent) {
             { const int rc_ = prepare_persistent_launch(ctx); if (rc_ != RTDD_OK) return rc_; }   // zero the tile flags, debug words
             ctx->persistent_used = true;
@@ -786,22 +815,9 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         float *Yk = L.P(free0, ip), *Ym = L.P(free1, ip);
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) \
     case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps); break;
-        switch (tile) {
-            RTDD_TILE_CASE(1, 16, 256, 4)
-            RTDD_TILE_CASE(2, 32, 512, 4)
-            RTDD_TILE_CASE(3, 32, 1024, 4)
-            RTDD_TILE_CASE(4, 32, 1024, 3)
-            RTDD_TILE_CASE(5, 32, 512, 3)
-            RTDD_TILE_CASE(6, 16, 512, 3)
-            RTDD_TILE_CASE(7, 16, 256, 3)
-            RTDD_TILE_CASE(8, 32, 1024, 2)
-            RTDD_TILE_CASE(9, 16, 1024, 1)
-            RTDD_TILE_CASE(10, 16, 512, 2)
-            RTDD_TILE_CASE(11, 32, 1024, 1)
-            RTDD_TILE_CASE(12, 32, 768, 4)
-            RTDD_TILE_CASE(13, 32, 512, 6)
-        }
+        switch (tile) { RTDD_ALL_TILES }
 #undef RTDD_TILE_CASE
+        ctx->last_info.kernel = 2; ctx->last_info.tile = tile; ctx->last_info.temporal_depth = persistent ? block_sweeps : m; ctx->last_info.persistent = persistent ? 1 : 0;
         // where the results are: the plain launch writes the spare pair; the persistent one the exchange buffer of its
         // last block's parity (blocks 0,2,.. -> spare pair, 1,3,.. -> the input pair)
         const int nblocks = (m + block_sweeps - 1) / block_sweeps;

@@ -90,9 +90,8 @@ def test_auto_method_vcycles_then_sor_cycles(ctx, oracle, lut, rows, cols, seed)
     its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_AUTO, maxIterations=200000, tolerance=1e-4)
     cycles = ctx.last_cycles
     x = p["depth"].copy()
-    px = rows * cols
-    sor_seconds = (((max(rows, cols) + 1) // 2) * 1.25 + 20.0) * max(px / 700e9, 2.5e-6)       # csrc/api.cpp
-    want_cycles, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, 1, 60, 1e-4, 1, alternative_seconds=sor_seconds)
+    sor_seconds, cycle_seconds = ctx.auto_model(rows, cols)          # the library's own constants (RTDD_OPT_AUTO_*), not a copy
+    want_cycles, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, 1, 60, 1e-4, 1, alternative_seconds=sor_seconds, cycle_seconds=cycle_seconds)
     want_its = 0
     if want_res > 1e-4:
         want_its, want_res = _sor_cycles_restated(oracle, x, idx, p["mask"], lut, 1, 1e-4, 200000, halve=True)
@@ -140,9 +139,8 @@ def test_randomised_geometries_all_extension_methods(ctx, oracle, lut):
             assert (its, res) == (want_its, np.float32(want_res)), what
         else:                                           # automatic: V-cycles, then SOR cycles of half length, capped
             its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_AUTO, maxIterations=1200, tolerance=1e-4)
-            px = rows * cols
-            sor_seconds = (((max(rows, cols) + 1) // 2) * 1.25 + 20.0) * max(px / 700e9, 2.5e-6)
-            want_cycles, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, contract, 60, 1e-4, 1, alternative_seconds=sor_seconds)
+            sor_seconds, cycle_seconds = ctx.auto_model(rows, cols)
+            want_cycles, want_res, _ = oracle.mg_solve(x, idx, p["mask"], lut, contract, 60, 1e-4, 1, alternative_seconds=sor_seconds, cycle_seconds=cycle_seconds)
             want_its = 0
             if want_res > 1e-4:
                 want_its, want_res = _sor_cycles_restated(oracle, x, idx, p["mask"], lut, contract, 1e-4, 1200, halve=True)

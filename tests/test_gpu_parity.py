@@ -432,3 +432,66 @@ def test_full_size_1080p_1000_sweeps_matches_oracle(ctx, oracle, lut):
     dir_ = p["mask"] == 255
     assert np.array_equal(got[dir_], p["depth"][dir_])
     assert got.min() > -64 and got.max() < 320
+
+
+def test_persistent_timeout_is_reported_bounded_and_recoverable(ctx, oracle, lut):
+    """The hand-off of the persistent kernels must never hang or return garbage silently: with one tile's flag withheld
+    (RTDD_OPT_DEBUG_WITHHOLD_TILE) its neighbours run into the poll limit, the launch drains at once, the queued work behind
+    it drains too, and the next synchronising call returns RTDD_ERR_TIMEOUT.  Afterwards the context works again."""
+    import time
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=5)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 64, 0.0, 0); ctx.synchronize()             # warm up, and: no error without the knob
+    info = ctx.last_solve_info()
+    assert info.kernel == 2 and info.persistent == 1 and info.iterations == 64, info.describe()
+    ctx.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); ctx.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 100 + 1)
+    try:
+        d2 = up(p["depth"])
+        t0 = time.perf_counter()
+        for _ in range(3):                                  # the failed launch and two more queued behind it
+            ctx.GPUMatrixFreeSolver(d2, m, g, rows, cols, 0.4, 400, 0.0, 0)
+        with pytest.raises(rt.RtddError) as e:
+            ctx.synchronize()
+        elapsed = time.perf_counter() - t0
+        assert e.value.status == rt.RTDD_ERR_TIMEOUT, e.value
+        assert elapsed < 0.5, f"a timed-out launch must drain quickly, took {elapsed:.2f} s"
+        # the same through a residual-stopped solve (it synchronises itself) ...
+        with pytest.raises(rt.RtddError) as e:
+            ctx.solve_ex(d2, m, g, rows, cols, 0, method=rt.METHOD_CHEBYSHEV_JACOBI, maxIterations=400, tolerance=1e-3, checkEvery=200)
+        assert e.value.status == rt.RTDD_ERR_TIMEOUT
+        # ... and through the red-black kernel's persistent mode
+        ctx.solve_ex(d2, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=64, tolerance=0.0)
+        with pytest.raises(rt.RtddError) as e:
+            ctx.synchronize()
+        assert e.value.status == rt.RTDD_ERR_TIMEOUT
+    finally:
+        ctx.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 0); ctx.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 0)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 64, 0, 0, lut, 1, threads=oracle.max_threads())
+    d3 = up(p["depth"])
+    ctx.GPUMatrixFreeSolver(d3, m, g, rows, cols, 0.4, 64, 0.0, 0); ctx.synchronize()
+    assert_bit_equal(down(d3), want, "solve after a timed-out one")
+
+
+def test_solve_info_names_the_path_that_ran(ctx):
+    """rtdd_solve_info / rtdd_last_solve_info: kernel, tile, depth, persistence and contraction of the solve that just ran."""
+    p = make_problem(270, 480, seed=2)
+    rows, cols = 270, 480
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    ctx.set_option(rt.OPT_SWEEP_KERNEL, 1)
+    ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 10, 0.0, 0)
+    i = ctx.last_solve_info()
+    assert (i.kernel, i.iterations, i.launches, i.persistent, i.fp_contract) == (1, 10, 10, 0, 1), i.describe()
+    ctx.set_option(rt.OPT_SWEEP_KERNEL, 2); ctx.set_option(rt.OPT_TILE, 9); ctx.set_option(rt.OPT_TEMPORAL_DEPTH, 4); ctx.set_option(rt.OPT_PERSISTENT, 0)
+    ctx.set_option(rt.OPT_FP_CONTRACT, 0)
+    ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 10, 0.0, 0)
+    i = ctx.last_solve_info()
+    assert (i.kernel, i.tile, i.iterations, i.launches, i.persistent, i.fp_contract) == (2, 9, 10, 3, 0, 0), i.describe()
+    ctx.set_option(rt.OPT_SWEEP_KERNEL, 0); ctx.set_option(rt.OPT_TILE, 0); ctx.set_option(rt.OPT_TEMPORAL_DEPTH, 0); ctx.set_option(rt.OPT_PERSISTENT, 1)
+    ctx.set_option(rt.OPT_FP_CONTRACT, 1)
+    its, _ = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=12, tolerance=0.0)
+    i = ctx.last_solve_info()
+    assert (i.kernel, i.iterations, i.fp_contract) == (4, 12, 1), i.describe()
+    ctx.synchronize()
