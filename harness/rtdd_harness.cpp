@@ -155,17 +155,26 @@ struct Job {
 
 // One GPU: context + stream + device staging, runs `count` estimates; keeps the last result on the host.
 static int run_device(int device, const Job &job, int count, bool live, std::vector<unsigned char> *depth_u8, std::vector<unsigned char> *art, double *ms_per_estimate) {
-    rtdd_ctx *ctx = nullptr;
-    int rc = rtdd_ctx_create(device, &ctx);
+    // everything this function owns, released on EVERY return path (the CK() early returns included)
+    struct Owned {
+        rtdd_ctx *ctx = nullptr; hipStream_t stream = nullptr; unsigned char *d_bgr = nullptr, *d_ann = nullptr;
+        ~Owned() {
+            if (d_bgr) (void)hipFree(d_bgr);
+            if (d_ann) (void)hipFree(d_ann);
+            if (ctx) rtdd_ctx_destroy(ctx);           // synchronises the stream first
+            if (stream) (void)hipStreamDestroy(stream);
+        }
+    } own;
+    int rc = rtdd_ctx_create(device, &own.ctx);
     if (rc != RTDD_OK) { std::printf("rtdd_ctx_create(%d): %s\n", device, rtdd_status_string(rc)); return rc; }
-    hipStream_t stream = nullptr;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&stream) != hipSuccess) { std::printf("device %d: cannot create a stream\n", device); return RTDD_ERR_HIP; }
-    rtdd_ctx_set_stream(ctx, stream);
+    rtdd_ctx *ctx = own.ctx;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&own.stream) != hipSuccess) { std::printf("device %d: cannot create a stream\n", device); return RTDD_ERR_HIP; }
+    rtdd_ctx_set_stream(ctx, own.stream);
     const int rows = job.bgr.h, cols = job.bgr.w;
     CK(rtdd_load_weights(ctx, 0.4f));                                   // main.cpp:152-155
     CK(rtdd_pyramid_create(ctx, rows, cols));                           // main.cpp:92-149
-    unsigned char *d_bgr = nullptr, *d_ann = nullptr;
-    if (hipMalloc((void **)&d_bgr, (size_t)rows * cols * 3) != hipSuccess || hipMalloc((void **)&d_ann, (size_t)rows * cols) != hipSuccess) { std::printf("device %d: out of memory\n", device); return RTDD_ERR_NOMEM; }
+    if (hipMalloc((void **)&own.d_bgr, (size_t)rows * cols * 3) != hipSuccess || hipMalloc((void **)&own.d_ann, (size_t)rows * cols) != hipSuccess) { std::printf("device %d: out of memory\n", device); return RTDD_ERR_NOMEM; }
+    unsigned char *d_bgr = own.d_bgr, *d_ann = own.d_ann;
     void *p_scr, *p_ed, *p_orig, *p_gray, *p_depth, *p_art, *p_u8;
     size_t pi_scr, pi_ed, pi_orig, pi_gray, pi_depth, pi_art, pi_u8;
     CK(rtdd_pyramid_image(ctx, RTDD_IMG_SCRIBBLE, 0, &p_scr, &pi_scr, nullptr, nullptr));
@@ -178,7 +187,8 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
 
     auto t0 = std::chrono::steady_clock::now();
     for (int n = 0; n < count; n++) {
-        if (n == 0 || !live) {                                          // a new image: upload + (re)build the pyramid inputs
+        if (n == 0 || !live) {                                          // a new image (--batch: every image is independent -- rtdd_pyramid_set_image
+                                                                        // also resets the warm-start state): upload + (re)build the pyramid inputs
             CK(rtdd_upload(ctx, d_bgr, (size_t)cols * 3, job.bgr.px.data(), (size_t)cols * 3, (size_t)cols * 3, rows));
             CK(rtdd_pyramid_set_image(ctx, d_bgr, (size_t)cols * 3));
             if (job.has_ann) {
@@ -206,9 +216,7 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
         if (!job.effect.empty()) { art->resize((size_t)rows * cols * 3); CK(rtdd_download(ctx, art->data(), (size_t)cols * 3, p_art, pi_art, (size_t)cols * 3, rows)); }
     }
     *ms_per_estimate = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (count > 0 ? count : 1);
-    (void)hipFree(d_bgr); (void)hipFree(d_ann);
-    rtdd_ctx_destroy(ctx);
-    (void)hipStreamDestroy(stream);
+    CK(rtdd_ctx_synchronize(ctx));                                      // also reports a persistent launch that gave up (RTDD_ERR_TIMEOUT)
     return RTDD_OK;
 }
 

@@ -227,11 +227,13 @@ def pyrdown_u8(src):
     return d
 
 
-def pyrup_f32(src, drows, dcols, rows=None, cols=None):
+def pyrup_f32(src, drows, dcols, rows=None, cols=None, contract=1):
+    """f32 pyrUp as src/main.cpp:272-279 calls it: cv::cuda::pyrUp when (drows, dcols) is exactly twice the source, else
+    the host's cv::pyrUp with the explicit size (rtdd_cascade_oracle.c).  `contract`: nvcc's fmad in the CUDA branch."""
     r = src.shape[0] if rows is None else rows
     c = src.shape[1] if cols is None else cols
     d = np.empty((drows, dcols), np.float32)
-    lib().orc_pyrup_f32(_p(src), _pitch(src), C.c_int(r), C.c_int(c), _p(d), _pitch(d), C.c_int(drows), C.c_int(dcols))
+    lib().orc_pyrup_f32(_p(src), _pitch(src), C.c_int(r), C.c_int(c), _p(d), _pitch(d), C.c_int(drows), C.c_int(dcols), C.c_int(contract))
     return d
 
 

@@ -47,9 +47,44 @@ __global__ __launch_bounds__(256) void k_pyrdown_u8(const uint8_t *__restrict__ 
     dst[(size_t)y * dp + x] = (uint8_t)((s + 128) >> 8);
 }
 
-// cv::pyrUp (32f) to an explicit destination size -- src/main.cpp:273,277 -- with the Dirichlet
-// re-injection of GPUConvertToFloat (src/main.cpp:281-283, src/GPUImageProcessing.cu:19) fused in.
-// Accumulation order: rows outer, columns inner, ascending (the same as the CPU restatement it is tested against).
+// f32 pyrUp as src/main.cpp:272-279 calls it, with the Dirichlet re-injection of GPUConvertToFloat (src/main.cpp:281-283,
+// src/GPUImageProcessing.cu:19) fused in.  The reference uses TWO OpenCV routines: cv::cuda::pyrUp when the destination is exactly
+// twice the source (main.cpp:273), the host's cv::pyrUp with the explicit size otherwise (main.cpp:277).  Both mirror at the
+// top/left border and REPLICATE at the bottom/right; they differ in the border arithmetic and in that the CUDA one accumulates
+// sum = sum + w * s, which nvcc contracts (CONTRACT, as for the solver).  Formulas and what is unknowable about them:
+// oracle/rtdd_cascade_oracle.c (third-party code, unpinned).
+__device__ __forceinline__ int clamp_abs(int i, int n) { if (i < 0) i = -i; return i < n - 1 ? i : n - 1; }
+
+template <bool CONTRACT>
+__device__ __forceinline__ float pyrup_cuda_h(const float *s, int n, int k) {
+    const int c = k >> 1;
+    float sum = 0.0f;
+    if ((k & 1) == 0) {
+        const float a = s[clamp_abs(c - 1, n)], b = s[clamp_abs(c, n)], d = s[clamp_abs(c + 1, n)];
+        if (CONTRACT) { sum = __builtin_fmaf(0.0625f, a, sum); sum = __builtin_fmaf(0.375f, b, sum); sum = __builtin_fmaf(0.0625f, d, sum); }
+        else { sum = sum + 0.0625f * a; sum = sum + 0.375f * b; sum = sum + 0.0625f * d; }
+    } else {
+        const float a = s[clamp_abs(c, n)], b = s[clamp_abs(c + 1, n)];
+        if (CONTRACT) { sum = __builtin_fmaf(0.25f, a, sum); sum = __builtin_fmaf(0.25f, b, sum); }
+        else { sum = sum + 0.25f * a; sum = sum + 0.25f * b; }
+    }
+    return sum;
+}
+
+__device__ __forceinline__ float pyrup_host_h(const float *s, int n, int k) {
+    if (n == 1) return s[0] * 8;
+    if (k >= 2 * n) k = 2 * n - 1;
+    const int c = k >> 1;
+    if ((k & 1) == 0) {
+        if (c == 0) return s[0] * 6 + s[1] * 2;
+        if (c == n - 1) return s[n - 2] + s[n - 1] * 7;
+        return s[c - 1] + s[c] * 6 + s[c + 1];
+    }
+    if (c == n - 1) return s[n - 1] * 8;
+    return (s[c] + s[c + 1]) * 4;
+}
+
+template <bool CONTRACT>
 __global__ __launch_bounds__(256) void k_pyrup_inject(const float *__restrict__ src, size_t sp, int rows, int cols,
                                                       float *__restrict__ dst, size_t dp, int drows, int dcols,
                                                       const uint8_t *__restrict__ edited, size_t ep,
@@ -58,19 +93,30 @@ __global__ __launch_bounds__(256) void k_pyrup_inject(const float *__restrict__ 
     if (x >= dcols || y >= drows) return;
     float *out = (float *)((char *)dst + (size_t)y * dp) + x;
     if (mask && mask[(size_t)y * mp + x] == 255) { *out = (float)edited[(size_t)y * ep + 3 * x]; return; }
-    int cy[3], cxx[3]; float wy[3], wx[3]; int ny, nx;
-    if ((y & 1) == 0) { ny = 3; cy[0] = y / 2 - 1; cy[1] = y / 2; cy[2] = y / 2 + 1; wy[0] = 0.125f; wy[1] = 0.75f; wy[2] = 0.125f; }
-    else { ny = 2; cy[0] = y / 2; cy[1] = y / 2 + 1; cy[2] = 0; wy[0] = 0.5f; wy[1] = 0.5f; wy[2] = 0.0f; }
-    if ((x & 1) == 0) { nx = 3; cxx[0] = x / 2 - 1; cxx[1] = x / 2; cxx[2] = x / 2 + 1; wx[0] = 0.125f; wx[1] = 0.75f; wx[2] = 0.125f; }
-    else { nx = 2; cxx[0] = x / 2; cxx[1] = x / 2 + 1; cxx[2] = 0; wx[0] = 0.5f; wx[1] = 0.5f; wx[2] = 0.0f; }
-    float acc = 0.0f;
-    for (int j = 0; j < ny; j++) {
-        const float *srow = (const float *)((const char *)src + (size_t)reflect101(cy[j], rows) * sp);
-        float h = 0.0f;
-        for (int i = 0; i < nx; i++) h = h + wx[i] * srow[reflect101(cxx[i], cols)];
-        acc = acc + wy[j] * h;
+#define SROW(r) ((const float *)((const char *)src + (size_t)(r) * sp))
+    if (drows == 2 * rows && dcols == 2 * cols) {                                  // cv::cuda::pyrUp
+        const int cy = y >> 1;
+        float sum = 0.0f;
+        if ((y & 1) == 0) {
+            const float h0 = pyrup_cuda_h<CONTRACT>(SROW(clamp_abs(cy - 1, rows)), cols, x), h1 = pyrup_cuda_h<CONTRACT>(SROW(clamp_abs(cy, rows)), cols, x),
+                        h2 = pyrup_cuda_h<CONTRACT>(SROW(clamp_abs(cy + 1, rows)), cols, x);
+            if (CONTRACT) { sum = __builtin_fmaf(0.0625f, h0, sum); sum = __builtin_fmaf(0.375f, h1, sum); sum = __builtin_fmaf(0.0625f, h2, sum); }
+            else { sum = sum + 0.0625f * h0; sum = sum + 0.375f * h1; sum = sum + 0.0625f * h2; }
+        } else {
+            const float h1 = pyrup_cuda_h<CONTRACT>(SROW(clamp_abs(cy, rows)), cols, x), h2 = pyrup_cuda_h<CONTRACT>(SROW(clamp_abs(cy + 1, rows)), cols, x);
+            if (CONTRACT) { sum = __builtin_fmaf(0.25f, h1, sum); sum = __builtin_fmaf(0.25f, h2, sum); }
+            else { sum = sum + 0.25f * h1; sum = sum + 0.25f * h2; }
+        }
+        *out = 4.0f * sum;
+    } else {                                                                       // cv::pyrUp with the explicit size
+        const int yy = y >= 2 * rows ? 2 * rows - 2 : y;
+        const int cy = yy >> 1;
+        const int r0 = cy - 1 < 0 ? (rows > 1 ? 1 : 0) : cy - 1, r2 = cy + 1 >= rows ? rows - 1 : cy + 1;
+        const float v1 = pyrup_host_h(SROW(cy), cols, x), v2 = pyrup_host_h(SROW(r2), cols, x);
+        if ((yy & 1) == 0) { const float v0 = pyrup_host_h(SROW(r0), cols, x); *out = (v0 + v1 * 6 + v2) * 0.015625f; }
+        else *out = ((v1 + v2) * 4) * 0.015625f;
     }
-    *out = acc;
+#undef SROW
 }
 
 // GpuMat::convertTo(CV_8UC1): saturate(round-half-even) -- src/main.cpp:290
@@ -116,7 +162,8 @@ int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, in
 }
 int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
                         const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp) {
-    hipLaunchKernelGGL(k_pyrup_inject, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp);
+    if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject<true>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp);
+    else hipLaunchKernelGGL(k_pyrup_inject<false>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp);
     RTDD_LAUNCH_CHECK(ctx, "k_pyrup_inject");
     return RTDD_OK;
 }

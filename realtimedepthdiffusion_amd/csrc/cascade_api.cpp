@@ -103,7 +103,17 @@ int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch) {
     DeviceGuard g(ctx->device);
     RTDD_HIP(ctx, hipMemcpy2DAsync(p->original.ptr, p->original.pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
     RTDD_HIP(ctx, hipMemcpy2DAsync(p->edited[0].ptr, p->edited[0].pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));   // :158
-    RTDD_HIP(ctx, hipMemsetAsync(p->scribble[0].ptr, 0, p->scribble[0].pitch * p->rows, ctx->stream));
+    // A new image is a new problem (the reference loads one image per process, src/main.cpp:93): everything an estimate carries
+    // over to the next one -- the depth pyramid it warm-starts from (:136) and the coarse annotation levels, which
+    // GPUPyrDownAnnotation only ever adds to -- goes back to its initial state.
+    for (int l = 0; l < p->levels; l++) {
+        if (p->scribble[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->scribble[l].ptr, 0, p->scribble[l].pitch * p->scribble[l].rows, ctx->stream));
+        if (l > 0 && p->edited[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->edited[l].ptr, 0, p->edited[l].pitch * p->edited[l].rows, ctx->stream));
+        if (p->depth[l].rows > 0 && p->depth[l].cols > 0) {
+            const int rc_ = launch_fill_f32(ctx, (float *)p->depth[l].ptr, p->depth[l].pitch, p->depth[l].rows, p->depth[l].cols, 255.0f);
+            if (rc_ != RTDD_OK) return rc_;
+        }
+    }
     int rc = launch_bgr2gray(ctx, (const uint8_t *)p->original.ptr, p->original.pitch, (uint8_t *)p->gray[0].ptr, p->gray[0].pitch, p->rows, p->cols);
     // the gray pyramid depends on the image only: built once here instead of once per estimate (:241-247)
     for (int l = 1; l < p->levels && rc == RTDD_OK; l++)

@@ -15,6 +15,8 @@
 //
 // Every point is computed with a fixed evaluation order and no atomics (the smoothers recompute halo points rather than
 // exchange them): oracle/rtdd_mg_oracle.c restates the same arithmetic and the parity tests compare bit for bit.
+#include <new>
+
 #include "rtdd_internal.hpp"
 
 namespace rtdd {
@@ -449,18 +451,23 @@ void mg_release(rtdd_ctx *ctx) {
 static int mg_allocate(rtdd_ctx *ctx, int rows, int cols) {
     if (ctx->mg && ctx->mg->rows == rows && ctx->mg->cols == cols) return RTDD_OK;
     mg_release(ctx);
-    ctx->mg = new MgState();
-    ctx->mg->rows = rows; ctx->mg->cols = cols;
+    ctx->mg = new (std::nothrow) MgState();
+    if (!ctx->mg) return fail(ctx, RTDD_ERR_NOMEM, "multigrid state");
     int r = rows, c = cols;
     for (int l = 0; l < 16; l++) {
         MgLevel L;
         L.rows = r; L.cols = c; L.pitch = (c + 63) / 64 * 64;
         L.plane = (size_t)L.pitch * r;
-        RTDD_HIP(ctx, hipMalloc((void **)&L.buf, 12 * L.plane * sizeof(float)));
+        const hipError_t e = hipMalloc((void **)&L.buf, 12 * L.plane * sizeof(float));      // 1.6 GB for level 0 at 8K
+        if (e != hipSuccess) {           // leave NO half-built hierarchy behind: the next solve of this size must not find one
+            mg_release(ctx);
+            return fail(ctx, e == hipErrorOutOfMemory ? RTDD_ERR_NOMEM : RTDD_ERR_HIP, "hipMalloc(multigrid level)", e);
+        }
         ctx->mg->lv.push_back(L);
         if ((size_t)r * c <= 256 || (r == 1 && c == 1)) break;
         r = (r + 1) / 2; c = (c + 1) / 2;
     }
+    ctx->mg->rows = rows; ctx->mg->cols = cols;      // only a complete hierarchy is ever matched by the early-out above
     return RTDD_OK;
 }
 

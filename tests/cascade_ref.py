@@ -40,7 +40,7 @@ class Cascade:
             if r > 0 and c > 0:
                 o.solve(self.depth[l], self.scribble[l], self.gray[l], iters, l, P - 1, self.lut, self.contract, threads=self.threads, rows=r, cols=c)
             if l > 0:
-                self.depth[l - 1] = o.pyrup_f32(self.depth[l], *self.size[l - 1])          # :272-279
+                self.depth[l - 1] = o.pyrup_f32(self.depth[l], *self.size[l - 1], contract=self.contract)          # :272-279
                 o.convert_to_float(self.edited[l - 1], self.depth[l - 1], self.scribble[l - 1])   # :281
         self.depth_u8 = o.depth_to_u8(self.depth[0])                     # :290
         return self.depth[0]

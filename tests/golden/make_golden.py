@@ -87,7 +87,7 @@ def cascade(gray0, mask0, edited0, lut, contract):
         oracle.solve(depth[lvl], mask[lvl], gray[lvl], ITERS[lvl], lvl, LEVELS - 1, lut, contract, threads=4)
         after[lvl] = depth[lvl].copy()
         if lvl > 0:
-            depth[lvl - 1] = oracle.pyrup_f32(depth[lvl], SIZE >> (lvl - 1), SIZE >> (lvl - 1))
+            depth[lvl - 1] = oracle.pyrup_f32(depth[lvl], SIZE >> (lvl - 1), SIZE >> (lvl - 1), contract=contract)
             oracle.convert_to_float(edited[lvl - 1], depth[lvl - 1], mask[lvl - 1])
     return gray, mask, edited, before, after, index_sha
 

@@ -53,7 +53,7 @@ def test_per_level_solve_reproduces_golden(oracle, name, lvl):
     got = oracle.solve(before.copy(), g[f"mask{lvl}"], g[f"gray{lvl}"], int(g["iters"][lvl]), lvl, LEVELS - 1, lut, 1, threads=4)
     assert np.array_equal(got.view(np.uint32), g[f"depth_after_c1_L{lvl}"].view(np.uint32))
     if lvl > 0:                                # pyrUp + injection link the levels
-        up = oracle.pyrup_f32(got, before.shape[0] * 2, before.shape[1] * 2)
+        up = oracle.pyrup_f32(got, before.shape[0] * 2, before.shape[1] * 2, contract=1)
         oracle.convert_to_float(edited_from_ch0(g[f"edited_ch0_{lvl - 1}"]), up, g[f"mask{lvl - 1}"])
         assert np.array_equal(up, g[f"depth_before_c1_L{lvl - 1}"])
 
@@ -73,7 +73,7 @@ def test_uncontracted_cascade_reproduces_hashes_and_spread(oracle, name):
         spread = np.abs(depth - g[f"depth_after_c1_L{lvl}"]).max()
         assert spread == g[f"spread_c0_c1_L{lvl}"]
         if lvl > 0:
-            depth = oracle.pyrup_f32(depth, depth.shape[0] * 2, depth.shape[1] * 2)
+            depth = oracle.pyrup_f32(depth, depth.shape[0] * 2, depth.shape[1] * 2, contract=0)
             oracle.convert_to_float(edited_from_ch0(g[f"edited_ch0_{lvl - 1}"]), depth, g[f"mask{lvl - 1}"])
     # at the coarsest level the two variants agree to ~1e-3; the depth gate ((uchar)depth thresholds,
     # src/GPUSolver.cu:199-218) then amplifies that into O(1) differences at level 0

@@ -21,7 +21,7 @@ def _bgr(rows, cols, seed):
     return bgr, ann
 
 
-@pytest.mark.parametrize("shape", [(6, 8), (67, 120), (135, 241), (853, 1280)])
+@pytest.mark.parametrize("shape", [(6, 8), (67, 120), (135, 241), (853, 1280), (1, 7), (7, 1), (2, 2)])
 def test_third_party_pieces_match_the_restatement(oracle, shape):
     rows, cols = shape
     bgr, _ = _bgr(rows, cols, 3)
@@ -34,10 +34,13 @@ def test_third_party_pieces_match_the_restatement(oracle, shape):
         c.pyrdown_gray(g, rows, cols, d)
         assert np.array_equal(down(d), oracle.pyrdown_u8(gray))
         src = np.random.default_rng(1).uniform(-10, 300, (rows, cols)).astype(np.float32)
-        for drows, dcols in ((2 * rows, 2 * cols), (2 * rows + 1, 2 * cols + 1), (2 * rows + 1, 2 * cols)):
-            dst = up(np.zeros((drows, dcols), np.float32))
-            c.pyrup_depth(up(src), rows, cols, dst, drows, dcols)
-            assert_bit_equal(down(dst), oracle.pyrup_f32(src, drows, dcols), f"pyrUp {shape}->{drows}x{dcols}")
+        for contract in (1, 0):                                         # the exact-doubling branch is cv::cuda::pyrUp: contraction matters there
+            c.set_option(rt.OPT_FP_CONTRACT, contract)
+            for drows, dcols in ((2 * rows, 2 * cols), (2 * rows + 1, 2 * cols + 1), (2 * rows + 1, 2 * cols), (2 * rows, 2 * cols + 1)):
+                dst = up(np.zeros((drows, dcols), np.float32))
+                c.pyrup_depth(up(src), rows, cols, dst, drows, dcols)
+                assert_bit_equal(down(dst), oracle.pyrup_f32(src, drows, dcols, contract=contract), f"pyrUp {shape}->{drows}x{dcols} contract {contract}")
+        c.set_option(rt.OPT_FP_CONTRACT, 1)
         u = up(np.zeros((rows, cols), np.uint8))
         vals = src.copy(); vals[0, :6] = [0.5, 1.5, 2.5, 254.5, 255.5, -0.5][:min(6, cols)] if cols >= 6 else vals[0, :6]
         c.depth_to_u8(up(vals), u, rows, cols)

@@ -52,15 +52,52 @@ def test_harness_png_in_png_out(tmp_path):
     assert np.array_equal(np.array(Image.open(tmp_path / "ArtisticEffect.png")), g["defocus"][..., ::-1])
 
 
-def test_harness_batch_and_paint(tmp_path):
+def _oracle_cascade(g, paints=(), annotation=True, estimates=1, iters=1000):
+    """The harness's call sequence restated over the oracle (tests/cascade_ref.py): decode, brush samples, `estimates` estimates."""
+    import oracle
+    from cascade_ref import Cascade
+    lut = oracle.load_weights(0.4)
+    c = Cascade(oracle, g["bgr"], g["annotation"] if annotation else None, lut, 1, threads=4)
+    for x, y, label, radius in paints:                                 # GPUPaintImage, src/GPUImageProcessing.cu:51-70 (main.cpp:55-57)
+        oracle.paint_image(x, y, label, radius, c.edited[0], c.scribble[0])
+    for _ in range(estimates):
+        c.estimate(iters)
+    return c
+
+
+def test_harness_live_mode_is_the_warm_started_estimate(tmp_path):
+    """--live N (src/main.cpp:232 `live`): N estimates of one image, each warm-started from the one before (the depth
+    pyramid and the coarse annotation levels persist); the written map is the N-th estimate of the restated cascade,
+    and differs from the single cold estimate."""
     g = load(NAMES[0])
     _write_pnm(tmp_path / "img.ppm", g["bgr"][..., ::-1])
-    # no annotation file: two brush samples instead (mouse drag, main.cpp:46-62); batch of 3 on 1 device
-    out = subprocess.check_output([BIN, "-i", str(tmp_path / "img.ppm"), "-o", str(tmp_path) + "/", "--paint", "40,40,0,9", "--paint", "200,180,254,9",
-                                   "--batch", "3", "--devices", "1", "--iters", "200"], text=True)
+    _write_pnm(tmp_path / "ann.pgm", g["annotation"])
+    out = subprocess.check_output([BIN, "-i", str(tmp_path / "img.ppm"), "-a", str(tmp_path / "ann.pgm"), "-o", str(tmp_path) + "/", "--live", "3", "--iters", "300"], text=True)
     assert "3 estimate(s) on 1 device(s)" in out
     d = _read_pnm(tmp_path / "DepthMap.pgm")
-    assert d[40, 40] == 0 and d[180, 200] == 254 and 0 < d[110, 120] < 254      # labels held, interior interpolated
+    third = _oracle_cascade(g, estimates=3, iters=300)
+    assert np.array_equal(d, third.depth_u8)
+    first = _oracle_cascade(g, estimates=1, iters=300)
+    assert not np.array_equal(first.depth[0], third.depth[0])          # the warm start really changes something at 300 sweeps
+
+
+def test_harness_batch_and_paint(tmp_path):
+    """--paint (the mouse-drag brush, main.cpp:46-62) against GPUPaintImage's restatement + the restated cascade, every pixel;
+    --batch B treats every image as independent: B = 3 on one device writes the same map as B = 1 (no warm start leaks in)."""
+    g = load(NAMES[0])
+    _write_pnm(tmp_path / "img.ppm", g["bgr"][..., ::-1])
+    paints = [(40, 40, 0, 9), (200, 180, 254, 9), (128, 10, 128, 5)]
+    args = [BIN, "-i", str(tmp_path / "img.ppm"), "-o", str(tmp_path) + "/", "--iters", "200"]
+    for p in paints:
+        args += ["--paint", "%d,%d,%d,%d" % p]
+    out = subprocess.check_output(args + ["--batch", "3", "--devices", "1"], text=True)
+    assert "3 estimate(s) on 1 device(s)" in out
+    d3 = _read_pnm(tmp_path / "DepthMap.pgm")
+    want = _oracle_cascade(g, paints=paints, annotation=False, estimates=1, iters=200)
+    assert np.array_equal(d3, want.depth_u8)
+    assert d3[40, 40] == 0 and d3[180, 200] == 254
+    subprocess.check_output(args + ["--batch", "1"], text=True)
+    assert np.array_equal(_read_pnm(tmp_path / "DepthMap.pgm"), d3)
 
 
 @pytest.mark.parametrize("how,unit", [("sor", "sweeps"), ("mg", "cycles")])

@@ -235,6 +235,18 @@ def test_cascade_helpers(oracle):
     assert d.shape == (4, 5) and np.all(d == 77)
     up = oracle.pyrup_f32(np.full((4, 5), 3.5, np.float32), 7, 9)
     assert up.shape == (7, 9) and np.all(up == 3.5)
+    # cv::pyrUp with an explicit odd size (imgproc pyramids.cpp, pyrUp_), worked by hand on [[1,2,4],[8,16,32]] -> 5x7: row buffers
+    # 10,12,17,24,30,32,32 and 80,96,136,192,240,256,256 (x=0: 6 s0 + 2 s1; x=n-1: s[n-2] + 7 s[n-1], then 8 s[n-1]; the 7th
+    # column repeats the 6th); rows: mirror above (r1 r0 r1), replicate below (r0 r1 r1), the 5th row repeats the 3rd
+    s = np.array([[1, 2, 4], [8, 16, 32]], np.float32)
+    b0 = np.array([10, 12, 17, 24, 30, 32, 32], np.float32); b1 = np.array([80, 96, 136, 192, 240, 256, 256], np.float32)
+    want = np.stack([(b1 + 6 * b0 + b1) / 64, (b0 + b1) * 4 / 64, (b0 + 6 * b1 + b1) / 64, (b1 + b1) * 4 / 64, (b0 + 6 * b1 + b1) / 64])
+    assert np.array_equal(oracle.pyrup_f32(s, 5, 7), want)
+    # cv::cuda::pyrUp for exact doubling: the same numbers (mirror top/left, replicate bottom/right), here without contraction
+    assert np.array_equal(oracle.pyrup_f32(s, 4, 6, contract=0), want[:4, :6])
+    assert oracle.pyrup_f32(s, 4, 6, contract=0)[0, 0] == 3.4375 and oracle.pyrup_f32(s, 4, 6, contract=0)[3, 5] == 32.0   # not reflect-101: that gives 24.25 at [3,5]
+    one = oracle.pyrup_f32(np.array([[3.0]], np.float32), 3, 3)
+    assert np.all(one == 3.0)
     ramp = np.tile(np.arange(6, dtype=np.float32), (4, 1))
     up = oracle.pyrup_f32(ramp, 8, 12)
     assert np.allclose(up[3, 2:10], np.arange(2, 10) / 2.0)          # linear ramps are reproduced in the interior
