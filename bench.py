@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- solver-sweep throughput of the hot path on MI355X.
 
-A *step* is one GPUMatrixFreeSolver call (edge-weight pass + K sweeps + copy-back) on one
-synthetic image already resident in HBM.  Default workload = BASELINE.json configs[1]:
-a single 1920x1080 image, one pyramid level, exactly 1000 Chebyshev-Jacobi sweeps.
-Workloads *_rbsor_1e-4 / *_multigrid_1e-4 (BASELINE configs 3 and 5, extensions) solve to a residual instead.
-With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank solves its own
-image of the same size (independent images shard with no collective; the only communication
-is the timing barrier and a MAX-reduce of the elapsed time), so scaling is weak.
+A *step* is one pass of the hot path over one batch of synthetic input already resident in HBM: for the default workload
+(BASELINE.json configs[1]) one GPUMatrixFreeSolver call -- edge-weight pass + 1000 Chebyshev-Jacobi sweeps + copy-back -- on a
+single 1920x1080 image, one pyramid level.  Other workloads: --workload 4k_jacobi1000 (the north star's 4K sweep),
+*_rbsor_1e-4 / *_multigrid_1e-4 (BASELINE configs 3 and 5, extensions: solve to a residual), batch64_1080p (config 4: 64
+independent 1080p images, image i on rank i % N, one stream per GPU).
 
-Prints ONE JSON line on rank 0; see the task contract for the fields.
+--gpus N: one process per GPU.  Launched by `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this
+process is one rank; launched plainly (`python3 bench.py --gpus N`) it starts the N ranks itself, before anything touches the
+GPU, and relays rank 0's line.  Images are independent, so there is NO collective on the data path: the process group only
+carries the timing barrier and a MAX / SUM of two scalars.  Default workload: every rank solves its own image of the same
+size ("weak"); batch64_1080p splits a fixed batch ("strong").
+
+Prints ONE JSON line on rank 0; see the task contract for the fields.  `roofline` is on the resource that binds -- VALU issue:
+the tile lives in registers for all sweeps, HBM is idle -- with the 17 B/pixel-sweep HBM-equivalent
+rate beside it.  Outside the timed region, on rank 0 at N = 1, the line also carries `estimate` (ms to a depth map: the whole
+1080p cascade), `sweep_4k` (the 4K sweep rate) and `effects` (the per-pixel passes), and `cpu_baseline` (the oracle on the host).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,20 +37,50 @@ WORKLOADS = {
     "480x270_jacobi250": dict(rows=270, cols=480, iters=250),
     "240x135_jacobi500": dict(rows=135, cols=240, iters=500),
     "960x540_jacobi125": dict(rows=540, cols=960, iters=125),
+    # BASELINE config 4: a fixed batch of 64 independent 1080p images (distinct seeds), image i on rank i % N
+    "batch64_1080p": dict(rows=1080, cols=1920, iters=1000, batch=64),
     # extensions (BASELINE configs 3 and 5): solve from the cold start to a residual max|J(x)-x| <= 1e-4; `iters` is the cap
     "4k_rbsor_1e-4": dict(rows=2160, cols=3840, iters=400000, method="sor_cycles", tolerance=1e-4),
     "1080p_rbsor_1e-4": dict(rows=1080, cols=1920, iters=400000, method="sor_cycles", tolerance=1e-4),
     "8k_multigrid_1e-4": dict(rows=4320, cols=7680, iters=200, method="multigrid", tolerance=1e-4),
     "1080p_multigrid_1e-4": dict(rows=1080, cols=1920, iters=200, method="multigrid", tolerance=1e-4),
 }
-# Chebyshev-Jacobi x_k 4 + x_{k-1} 4 + x_{k+1} 4 + 4 weight indices 4 + mask 1 = 17 B per pixel-sweep;
-# red-black sweep (no x_{k-1}) 13 B.  A V(2,2) cycle (no SURVEY figure: an extension) per image pixel: level 0 = 4 red-black
-# sweeps 52 + residual 13 (x 4, indices 4, mask 1, r 4) + restriction 20 (r 4, weights 16) + prolongation 24 (weights 16,
-# x read+write 8) = 109 B; the coarse levels hold 1/3 as many points, each 4 sweeps x 48 (9 coefficients 36, e 8, b 4) +
+# Algorithmic HBM bytes per pixel-sweep: Chebyshev-Jacobi 17 (x_k 4 + x_{k-1} 4 + x_{k+1} 4 + 4 weight indices 4 + mask 1);
+# red-black 13 (no x_{k-1}).  A V(2,2) cycle is counted as its 4 level-0 red-black sweeps for `value`; its algorithmic traffic per image
+# pixel is: level 0 -- 4 sweeps 52 + residual 13 (x 4, indices 4, mask 1, r 4) + restriction 20 (r 4, weights 16) + prolongation 24
+# (weights 16, x read+write 8) = 109 B; the coarse levels hold 1/3 as many points, each 4 sweeps x 48 (9 coefficients 36, e 8, b 4) +
 # residual 48 + restriction 20 + prolongation 24 = 284 B -> 95 B per image pixel; 204 B per cycle = 51 B per counted sweep.
 ALGO_BYTES = {"jacobi": 17.0, "rbgs": 13.0, "sor_cycles": 13.0, "multigrid": 51.0}
 MG_SWEEPS_PER_CYCLE = 4
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# VALU roof: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md chip table) = 78.6 T lane-operations/s (= 157.3 TFLOP/s / 2).
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# Algorithmic VALU operations per pixel-sweep, counted in the ISA of the sweep body (k_sweep_blocked<32,1024,3,true,true>, fast
+# path: 392 VALU instructions per 2 sweeps x 12 pixels; 4 fma for the sum, 3 for the divide, 1.5 for the tiny-numerator test, 6
+# for clamp + update + Dirichlet select, 0.5 DPP, ~1.3 bookkeeping).  Halo redundancy is NOT counted: `achieved` is useful work.
+VALU_OPS = {"jacobi": 16.3, "rbgs": 15.0, "sor_cycles": 15.0}
+
+
+def free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and relay rank 0's JSON line.
+    Nothing in this process has touched the GPU (no torch import yet)."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def cpu_baseline(rows, cols, method="jacobi", seconds_target=12.0):
@@ -94,11 +132,89 @@ def estimate_ms(rt, ctx, p, rows, cols, dev, n=20):
     t = time.perf_counter()
     for _ in range(n):
         ctx.estimate_depth(1000)
-    torch.cuda.synchronize()
+    ctx.synchronize()
     ms = (time.perf_counter() - t) / n * 1e3
     pxit = sum((rows >> l) * (cols >> l) * int(1000 / 2 ** (P - 1 - l)) for l in range(P))
+    ctx.pyramid_destroy()
     return {"what": f"{cols}x{rows} {P}-level cascade, {pxit / 1e6:.1f} Mpixel-iterations, device-resident", "ms": ms,
             "Mpixel_iterations_per_s": pxit / ms / 1e3}
+
+
+def valu_roofline(px_sweeps_per_s, method):
+    ops = VALU_OPS.get(method)
+    if ops is None:
+        return None
+    achieved = ops * px_sweeps_per_s / 1e12
+    return {"achieved": achieved, "peak": VALU_PEAK_TOPS, "frac": achieved / VALU_PEAK_TOPS, "ops_per_pixel_sweep": ops}
+
+
+def sweep_4k(rt, dev, steps=5):
+    """The north star's 4K sweep (3840x2160 x 1000 Chebyshev-Jacobi sweeps), timed like the headline, outside its timed region."""
+    import torch
+    from realtimedepthdiffusion_amd.synth import make_problem
+    rows, cols, iters = 2160, 3840, 1000
+    p = make_problem(rows, cols, seed=1234)
+    ctx = rt.Context(int(dev.split(":")[1]))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1); ctx.GPULoadWeights(0.4)
+    m = rt.device_image(p["mask"], dev); g = rt.device_image(p["gray"], dev)
+    ds = [rt.device_image(p["depth"], dev) for _ in range(steps + 1)]
+    ctx.GPUMatrixFreeSolver(ds[0], m, g, rows, cols, 0.4, iters, 1e-5, 0)
+    ctx.profile_enable(True)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for i in range(steps):
+        ctx.GPUMatrixFreeSolver(ds[1 + i], m, g, rows, cols, 0.4, iters, 1e-5, 0)
+    ctx.synchronize()
+    el = (time.perf_counter() - t) / steps
+    pr = ctx.profile()
+    info = ctx.last_solve_info()
+    ctx.close()
+    rate = rows * cols * iters / el
+    launch_us = pr.sweep_ms * 1e3 / max(pr.launches, 1)
+    sweeps_per_launch = pr.sweeps / max(pr.launches, 1)
+    hbm_eq = 17.0 * rows * cols * sweeps_per_launch / (launch_us * 1e-6) / 1e9
+    return {"workload": "4k_jacobi1000: one 3840x2160 image, 1 level, 1000 Chebyshev-Jacobi sweeps", "value": rate / 1e6, "unit": "Mpixel-iterations/s",
+            "ms_per_step": el * 1e3, "kernel": f"k_sweep_blocked tile {info.tile}, {sweeps_per_launch:g} sweeps per launch, {launch_us:.1f} us per launch",
+            "valu": valu_roofline(rows * cols * sweeps_per_launch / (launch_us * 1e-6), "jacobi"),
+            "hbm_equivalent": {"achieved": hbm_eq, "peak": HBM_PEAK_GBS, "frac": hbm_eq / HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_pixel_sweep": 17.0}}
+
+
+def effects(rt, dev):
+    """The per-pixel passes of the path (GPUDepthEffect.cu, and the solver's staging passes) against their algorithmic bytes."""
+    import numpy as np
+    import torch
+    from realtimedepthdiffusion_amd.synth import make_problem
+    out = {}
+    for name, rows, cols in (("1080p", 1080, 1920), ("4k", 2160, 3840)):
+        p = make_problem(rows, cols, seed=1)
+        rng = np.random.default_rng(0)
+        orig = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+        depth = (p["depth"] * rng.uniform(0, 1, (rows, cols))).astype(np.float32)
+        c = rt.Context(int(dev.split(":")[1]))
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.GPULoadWeights(0.4); c.GPUAllocateDeviceMemory(rows, cols, 1)
+        o, g, d, m = (rt.device_image(x, dev) for x in (orig, p["gray"], depth, p["mask"]))
+        art = rt.device_image(np.zeros_like(orig), dev)
+        px = rows * cols
+
+        def timeit(f, n=20):
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(n):
+                f()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        res = {}
+        for what, bpp, f in (("desaturation", 11, lambda: c.GPUSimulateDesaturation(o, g, d, art, rows, cols)),
+                             ("haze", 10, lambda: c.GPUSimulateHaze(o, d, art, rows, cols)),
+                             ("defocus", 10, lambda: c.GPUSimulateDefocus(o, d, art, rows, cols)),
+                             ("prepare_and_finish", 17, lambda: c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 0, 0, 0))):
+            t = timeit(f)
+            res[what] = {"us": t * 1e6, "algorithmic_GBs": px * bpp / t / 1e9, "bytes_per_pixel": bpp, "frac_of_hbm_peak": px * bpp / t / 1e9 / HBM_PEAK_GBS}
+        out[name] = res
+        c.close()
+    return out
 
 
 def main():
@@ -108,7 +224,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="1080p_jacobi1000", help="one of %s, or ROWSxCOLSxITERS" % ", ".join(sorted(WORKLOADS)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-estimate", action="store_true", help="skip the whole-cascade timing leg (profiling runs)")
+    ap.add_argument("--no-estimate", action="store_true", help="skip the legs outside the timed region (whole-cascade estimate, 4K sweep, effects): profiling runs")
     ap.add_argument("--sweep-kernel", type=int, default=0)
     ap.add_argument("--temporal-depth", type=int, default=0)
     ap.add_argument("--rows-per-wave", type=int, default=0)
@@ -116,35 +232,48 @@ def main():
     ap.add_argument("--persistent", type=int, default=-1)
     ap.add_argument("--method", default=None, choices=["jacobi", "rbgs", "sor_cycles", "multigrid"],
                     help="override the workload's method; everything but jacobi is an EXTENSION (not the headline)")
+    ap.add_argument("--dry-run", action="store_true", help="everything but the GPU work (launcher, rendezvous, sharding, aggregation): the N > 1 path on a CPU-only box")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import realtimedepthdiffusion_amd as rt
-    from realtimedepthdiffusion_amd.synth import make_problem
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:        # plain `python3 bench.py --gpus N`: be the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    if os.environ.get("RTDD_BENCH_SHARE_GPU"):     # rehearsal on a 1-GPU box: every rank on device 0 (use --persistent 0)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or plainly without WORLD_SIZE set")
+
+    import numpy as np
+    import torch
+    from realtimedepthdiffusion_amd import shard
+    from realtimedepthdiffusion_amd.synth import make_problem
+
+    share_gpu = bool(os.environ.get("RTDD_BENCH_SHARE_GPU"))       # rehearsal on a 1-GPU box: every rank on device 0
+    if share_gpu:
         local = 0
-    torch.cuda.set_device(local)
+    dry = args.dry_run
+    if not dry:
+        import realtimedepthdiffusion_amd as rt
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback (--dry-run rehearses the multi-rank plumbing only)")
+        torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         # The data path has NO collective (independent images); the process group only serves the timing barrier and
         # the MAX/SUM of two scalars.  RCCL ("nccl") is used when it comes up, gloo otherwise -- the result is the same.
-        try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            dist.barrier()
-        except Exception as e:                                  # noqa: BLE001
-            print(f"[bench] rank {rank}: nccl unavailable ({e!r}); using gloo for the timing barrier", file=sys.stderr)
-            if dist.is_initialized():
-                dist.destroy_process_group()
+        if dry or share_gpu:
             dist.init_process_group("gloo")
+        else:
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                dist.barrier()
+            except Exception as e:                                  # noqa: BLE001
+                print(f"[bench] rank {rank}: nccl unavailable ({e!r}); using gloo for the timing barrier", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
 
     if args.workload not in WORKLOADS:
         r_, c_, i_ = (int(v) for v in args.workload.split("x"))
@@ -153,98 +282,132 @@ def main():
     rows, cols, iters = w["rows"], w["cols"], w["iters"]
     method = args.method or w.get("method", "jacobi")
     tolerance = w.get("tolerance", 1e-4 if method in ("sor_cycles", "multigrid") else 0.0)
-    p = make_problem(rows, cols, seed=1234 + rank)
+    batch = w.get("batch", 0)
+    # which images this rank owns: a fixed batch is dealt round-robin (strong scaling); otherwise one image per rank (weak)
+    my_images = shard.images_for_rank(batch, world, rank) if batch else [rank]
     dev = f"cuda:{local}"
-    ctx = rt.Context(local)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
-    ctx.GPULoadWeights(0.4)
-    if args.sweep_kernel: ctx.set_option(rt.OPT_SWEEP_KERNEL, args.sweep_kernel)
-    if args.temporal_depth: ctx.set_option(rt.OPT_TEMPORAL_DEPTH, args.temporal_depth)
-    if args.rows_per_wave: ctx.set_option(rt.OPT_ROWS_PER_WAVE, args.rows_per_wave)
-    if args.tile: ctx.set_option(rt.OPT_TILE, args.tile)
-    if args.persistent >= 0: ctx.set_option(rt.OPT_PERSISTENT, args.persistent)
-    mask = rt.device_image(p["mask"], dev); gray = rt.device_image(p["gray"], dev)
-    # one pristine initial-depth image per step, uploaded before the clock starts
-    depths = [rt.device_image(p["depth"], dev) for _ in range(args.steps + args.warmup)]
-
     executed = []                           # iterations actually run per step (residual-stopped methods), and the residual reached
 
-    def step(i):
-        if method == "rbgs":
-            ctx.solve_ex(depths[i], mask, gray, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=iters, tolerance=0.0)
-        elif method == "sor_cycles":
-            executed.append(ctx.solve_ex(depths[i], mask, gray, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=iters, tolerance=tolerance,
-                                         relaxation=rt.RELAXATION_AUTO))
-        elif method == "multigrid":
-            executed.append(ctx.solve_ex(depths[i], mask, gray, rows, cols, 0, method=rt.METHOD_MULTIGRID, maxIterations=iters, tolerance=tolerance))
-        else:
-            ctx.GPUMatrixFreeSolver(depths[i], mask, gray, rows, cols, 0.4, iters, 1e-5, 0)
+    if dry:
+        def step(i):
+            time.sleep(0.001 * len(my_images))
 
-    from realtimedepthdiffusion_amd import shard
+        def fence():
+            shard.fence(dist, None)
+        ctx = None
+    else:
+        problems = [make_problem(rows, cols, seed=1234 + i) for i in my_images]
+        ctx = rt.Context(local)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+        ctx.GPULoadWeights(0.4)
+        if args.sweep_kernel: ctx.set_option(rt.OPT_SWEEP_KERNEL, args.sweep_kernel)
+        if args.temporal_depth: ctx.set_option(rt.OPT_TEMPORAL_DEPTH, args.temporal_depth)
+        if args.rows_per_wave: ctx.set_option(rt.OPT_ROWS_PER_WAVE, args.rows_per_wave)
+        if args.tile: ctx.set_option(rt.OPT_TILE, args.tile)
+        if args.persistent >= 0: ctx.set_option(rt.OPT_PERSISTENT, args.persistent)
+        elif share_gpu and world > 1: ctx.set_option(rt.OPT_PERSISTENT, 0)      # ranks sharing one GPU are not co-resident: no persistent launches
+        masks = [rt.device_image(p["mask"], dev) for p in problems]; grays = [rt.device_image(p["gray"], dev) for p in problems]
+        # one pristine initial-depth image per image and step, uploaded before the clock starts
+        depths = [[rt.device_image(p["depth"], dev) for p in problems] for _ in range(args.steps + args.warmup)]
 
-    def fence():
-        shard.fence(dist, torch.cuda.synchronize)
+        def step(i):
+            for k in range(len(problems)):
+                d, m, g = depths[i][k], masks[k], grays[k]
+                if method == "rbgs":
+                    ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=iters, tolerance=0.0)
+                elif method == "sor_cycles":
+                    executed.append(ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=iters, tolerance=tolerance, relaxation=rt.RELAXATION_AUTO))
+                elif method == "multigrid":
+                    executed.append(ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_MULTIGRID, maxIterations=iters, tolerance=tolerance))
+                else:
+                    ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, iters, 1e-5, 0)
+
+        def fence():
+            shard.fence(dist, torch.cuda.synchronize)
 
     for i in range(args.warmup):
         step(i)
     executed.clear()
-    ctx.profile_enable(True)               # HIP events around the sweep launches, on the launch stream
-    sweep_ms = 0.0; launches = 0; sweeps = 0
+    if ctx: ctx.profile_enable(True)        # HIP events around the sweep launches, on the launch stream
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)                  # asynchronous: nothing in the timed loop waits for the GPU
     fence()
     elapsed = time.perf_counter() - t0
-    pr = ctx.profile(); sweep_ms = pr.sweep_ms; launches = pr.launches; sweeps = pr.sweeps   # events recorded inside the timed region
+    if ctx: ctx.synchronize()                  # also surfaces RTDD_ERR_TIMEOUT of a persistent launch: a number from a failed run is no number
+    sweep_ms = 0.0; launches = 0; sweeps = 0; info = None
+    if ctx:
+        pr = ctx.profile(); sweep_ms = pr.sweep_ms; launches = pr.launches; sweeps = pr.sweeps   # events recorded inside the timed region (last <= 64 solves)
+        info = ctx.last_solve_info()
     if executed:                              # residual-stopped: count what actually ran (a V-cycle = its level-0 sweeps)
         per = MG_SWEEPS_PER_CYCLE if method == "multigrid" else 1
-        px_iter_per_step = rows * cols * per * sum(e[0] for e in executed) / len(executed)
+        px_iter_per_image = rows * cols * per * sum(e[0] for e in executed) / len(executed)
     else:
-        px_iter_per_step = rows * cols * iters
+        px_iter_per_image = rows * cols * iters
     algo_bytes = ALGO_BYTES[method]
-    agg_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
-    units, elapsed, thr = shard.aggregate(args.steps * px_iter_per_step, elapsed, dist, agg_dev)   # SUM of units, MAX of time
+    agg_dev = "cpu" if (dry or dist is None or dist.get_backend() != "nccl") else dev
+    units, elapsed, thr = shard.aggregate(args.steps * len(my_images) * px_iter_per_image, elapsed, dist, agg_dev)   # SUM of units, MAX of time
+    n_images = batch if batch else world
     value = thr / 1e6
     launch_us = sweep_ms * 1e3 / max(launches, 1)
     if method == "multigrid": sweeps *= MG_SWEEPS_PER_CYCLE
     sweeps_per_launch = sweeps / max(launches, 1)
-    achieved = algo_bytes * rows * cols * sweeps_per_launch / (launch_us * 1e-6) / 1e9
+    kernel_px_sweeps_per_s = rows * cols * sweeps_per_launch / (launch_us * 1e-6) if launch_us > 0 else 0.0
+    hbm_eq = algo_bytes * kernel_px_sweeps_per_s / 1e9
+    default_line = args.workload == "1080p_jacobi1000" and method == "jacobi"
     out = {
         "metric": "Mpixel-iterations/s (solver sweep)", "value": value, "unit": "Mpixel-iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps "
-                               f"(BASELINE configs[1])" if args.workload == "1080p_jacobi1000" and method == "jacobi" else f"{args.workload} ({method})",
-                   "images_per_step": world, "sweep_kernel": ctx.get_option(rt.OPT_SWEEP_KERNEL), "tile": ctx.get_option(rt.OPT_TILE), "temporal_depth": ctx.get_option(rt.OPT_TEMPORAL_DEPTH), "persistent": ctx.get_option(rt.OPT_PERSISTENT),
-                   "sweeps_per_launch": sweeps_per_launch},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": {"jacobi": "k_sweep_blocked", "rbgs": "k_rbgs_blocked", "sor_cycles": "k_rbgs_blocked (+ residual checks)",
-                                                 "multigrid": "whole V(2,2) cycle, all levels: 204 B per image pixel and cycle"}[method], "launch_us": launch_us,
-                     "algorithmic_bytes_per_launch": algo_bytes * rows * cols * sweeps_per_launch},
+        "higher_is_better": True, "scaling": "strong" if batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not dry else "none (--dry-run: no GPU work)",
+        "config": {"workload": (f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps (BASELINE configs[1])" if default_line else
+                                f"{args.workload}: {batch} independent {cols}x{rows} images x {iters} Chebyshev-Jacobi sweeps, image i on rank i % {world}, one stream per GPU (BASELINE configs[3])" if batch else
+                                f"{args.workload} ({method})"),
+                   "images_per_step": n_images, "images_this_rank": len(my_images), "sweeps_per_launch": sweeps_per_launch},
     }
+    if info is not None:
+        out["config"].update({"kernel": info.kernel, "tile": info.tile, "temporal_depth": info.temporal_depth, "persistent": info.persistent, "fp_contract": info.fp_contract})
+        kname = {"jacobi": "k_sweep_blocked", "rbgs": "k_rbgs_blocked", "sor_cycles": "k_rbgs_blocked (+ residual checks)",
+                 "multigrid": "whole V(2,2) cycle, all levels: 204 B per image pixel and cycle"}[method]
+        hbm_equivalent = {"achieved": hbm_eq, "peak": HBM_PEAK_GBS, "frac": hbm_eq / HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_pixel_sweep": algo_bytes,
+                          "algorithmic_bytes_per_launch": algo_bytes * rows * cols * sweeps_per_launch,
+                          "note": "what the sweeps would move through HBM one launch per sweep; with temporal blocking the tile stays in registers, so this can exceed 1 and is NOT the binding roof"}
+        v = valu_roofline(kernel_px_sweeps_per_s, method)
+        if v is not None:
+            out["roofline"] = {"bound": "valu", "achieved": v["achieved"], "peak": v["peak"], "unit": "Tlane-op/s", "frac": v["frac"], "traffic": None,
+                               "kernel": kname, "launch_us": launch_us, "ops_per_pixel_sweep": v["ops_per_pixel_sweep"],
+                               "definition": "useful pixel-sweeps/s of the kernel x VALU operations per pixel-sweep (static ISA count) / (256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz); halo redundancy not credited",
+                               "hbm_equivalent": hbm_equivalent}
+        else:                                   # the V-cycle is a chain of streaming kernels: HBM is its roof
+            out["roofline"] = {"bound": "hbm", "achieved": hbm_eq, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_eq / HBM_PEAK_GBS, "traffic": None, "kernel": kname, "launch_us": launch_us,
+                               "algorithmic_bytes_per_launch": algo_bytes * rows * cols * sweeps_per_launch}
+        # Counter evidence of the same command, from separate rocprofv3 --pmc passes (scripts/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE per
+        # MI355X_MICROARCH.md section HBM; SQ_INSTS_VALU), committed under profiles/: HBM-side traffic per launch and the counted VALU issue rate.
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "counters_latest.json")))
+            k = prof.get(args.workload if not (args.sweep_kernel or args.tile or args.temporal_depth or args.persistent >= 0 or args.method) else "", {})
+            if k:
+                out["roofline"]["traffic"] = k.get("hbm_bytes_per_launch_corrected")
+                if k.get("hbm_bytes_per_launch_corrected") and launch_us > 0:
+                    out["roofline"]["hbm_counter_frac"] = k["hbm_bytes_per_launch_corrected"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                if k.get("valu_issue_frac_counted") is not None:
+                    out["roofline"]["valu_issue_frac_counted"] = k["valu_issue_frac_counted"]      # SQ_INSTS_VALU x 2 cycles / (duration x 1024 SIMDs x 2.4 GHz): includes halo redundancy
+                out["roofline"]["counters_source"] = k.get("source")
+        except (OSError, ValueError, KeyError):
+            pass
     if executed:
         out["config"]["converged"] = {"tolerance": tolerance, "iterations": [e[0] for e in executed], "unit": "cycles" if method == "multigrid" else "sweeps",
                                       "residual": max(e[1] for e in executed), "start": "cold (depth 255 + labels)"}
-    # HBM-side traffic of the sweep kernel comes from a separate rocprofv3 --pmc pass of this same command
-    # (scripts/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), committed under profiles/.
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))) + [os.path.join(ROOT, "profiles", "traffic_latest.json")]:
-        try:
-            prof = json.load(open(path))
-            if prof.get("workload") == args.workload and method == "jacobi" and not (args.sweep_kernel or args.tile or args.temporal_depth or args.persistent >= 0):
-                sweeps_k = [k for name, k in prof["kernels"].items() if "k_sweep" in name]
-                if sweeps_k:                            # the dominant kernel of that profile; a later file (traffic_latest last) overrides an earlier one
-                    out["roofline"]["traffic"] = max(k["hbm_bytes_per_launch_corrected"] for k in sweeps_k)
-                    out["roofline"]["traffic_source"] = prof.get("source", os.path.relpath(path, ROOT))
-        except (OSError, ValueError, KeyError):
-            pass
-    if rank == 0 and args.workload == "1080p_jacobi1000" and method == "jacobi" and not args.no_estimate:
-        out["estimate"] = estimate_ms(rt, ctx, p, rows, cols, dev)      # second half of BASELINE's metric; outside the timed region
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if ctx: ctx.close()
+    if not dry and rank == 0 and world == 1 and default_line and not args.no_estimate:      # outside the timed region
+        c2 = rt.Context(local); c2.set_stream(torch.cuda.current_stream().cuda_stream); c2.GPULoadWeights(0.4)
+        out["estimate"] = estimate_ms(rt, c2, problems[0], rows, cols, dev)      # second half of BASELINE's metric
+        c2.close()
+        out["sweep_4k"] = sweep_4k(rt, dev)                                      # the north star's 4K stencil sweep
+        out["effects"] = effects(rt, dev)
+    if not dry and rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rows, cols, method)
-    ctx.close()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -1,0 +1,85 @@
+"""Turn the rocprofv3 outputs of scripts/profile_round.sh (gpurun_out/prof_<round>_<workload>/) into the committed summaries under
+profiles/:  <round>_<workload>_kernel_stats.csv (the clean --kernel-trace --stats pass at --steps 20 --warmup 5),
+<round>_<workload>_counters.json (per kernel: launches, mean duration, HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, KB ->
+bytes, per MI355X_MICROARCH.md section HBM; SQ counters per launch; VALU issue fraction), and the entry bench.py reads,
+profiles/counters_latest.json[workload] for the workload's dominant kernel.
+usage: make_counters_json.py ROUND WORKLOAD"""
+import collections, csv, json, os, sys
+
+rnd, wl = sys.argv[1], sys.argv[2]
+d = f"gpurun_out/prof_{rnd}_{wl}"
+SIMDS, CLOCK = 256 * 4, 2.4e9
+
+
+def per_kernel(prefix):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
+    f = f"{d}/{prefix}_counter_collection.csv"
+    if not os.path.exists(f):
+        return {}
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "rtdd::" not in k:
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
+    return {k: {c: v / len(disp[(k, c)]) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+def durations(prefix):
+    out = collections.defaultdict(list)
+    f = f"{d}/{prefix}_kernel_trace.csv"
+    if os.path.exists(f):
+        for r in csv.DictReader(open(f)):
+            out[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+    return out
+
+
+clean = durations("trace")
+kernels = {}
+fetch, write, sq1, sq2 = per_kernel("fetch"), per_kernel("write"), per_kernel("sq1"), per_kernel("sq2")
+dur_sq1 = durations("sq1")
+for k, ds in clean.items():
+    if "rtdd::" not in k:
+        continue
+    e = {"launches_in_clean_trace": len(ds), "mean_duration_us": sum(ds) / len(ds) * 1e6, "total_ms": sum(ds) * 1e3}
+    fs, ws = fetch.get(k, {}).get("FETCH_SIZE"), write.get(k, {}).get("WRITE_SIZE")
+    if fs is not None and ws is not None:
+        e["FETCH_SIZE_KB_per_launch"] = fs; e["WRITE_SIZE_KB_per_launch"] = ws
+        e["hbm_bytes_per_launch_corrected"] = (2 * fs + ws) * 1024
+    sq = dict(sq1.get(k, {})); sq.update(sq2.get(k, {}))
+    if sq:
+        e["sq_per_launch"] = {c: round(v, 1) for c, v in sorted(sq.items())}
+        dd = dur_sq1.get(k)
+        if dd and "SQ_INSTS_VALU" in sq:
+            e["mean_duration_us_under_sq_pass"] = sum(dd) / len(dd) * 1e6
+            e["valu_issue_frac_counted"] = sq["SQ_INSTS_VALU"] * 2 / (sum(dd) / len(dd) * SIMDS * CLOCK)
+        if sq.get("SQ_WAVE_CYCLES"):
+            for c in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"):
+                if c in sq:
+                    e[c + "/SQ_WAVE_CYCLES"] = sq[c] / sq["SQ_WAVE_CYCLES"]
+    kernels[k] = e
+bench = {}
+for name in ("bench_unprofiled.json", "trace.json"):
+    try:
+        bench[name] = json.loads([l for l in open(f"{d}/{name}").read().splitlines() if l.startswith("{")][-1])
+    except (OSError, IndexError, ValueError):
+        pass
+summary = {"workload": wl, "round": rnd,
+           "commands": {"clean trace": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-estimate --workload {wl}",
+                        "counters": "rocprofv3 --kernel-trace --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE | SQ group 1 | SQ group 2> -- python3 bench.py --steps 3 --warmup 1 ... (scripts/profile_round.sh)"},
+           "corrections": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE x1, KB -> bytes x1024; VALU issue fraction = SQ_INSTS_VALU x 2 cycles / (duration x 1024 SIMD-32 x 2.4 GHz)",
+           "bench_line_unprofiled": {k: bench.get("bench_unprofiled.json", {}).get(k) for k in ("value", "ms_per_step", "roofline")},
+           "ms_per_step_under_kernel_trace": bench.get("trace.json", {}).get("ms_per_step"),
+           "kernels": kernels}
+os.makedirs("profiles", exist_ok=True)
+json.dump(summary, open(f"profiles/{rnd}_{wl}_counters.json", "w"), indent=1)
+stats = open(f"{d}/trace_kernel_stats.csv").read().splitlines()
+open(f"profiles/{rnd}_{wl}_kernel_stats.csv", "w").write("\n".join(l[:420] for l in stats[:16]) + "\n")
+# the dominant kernel of this workload -> the entry bench.py attaches to its roofline record
+dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+latest_path = "profiles/counters_latest.json"
+latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
+latest[wl] = {"kernel": dom, "source": f"profiles/{rnd}_{wl}_counters.json", "mean_duration_us": kernels[dom]["mean_duration_us"],
+              "hbm_bytes_per_launch_corrected": kernels[dom].get("hbm_bytes_per_launch_corrected"), "valu_issue_frac_counted": kernels[dom].get("valu_issue_frac_counted")}
+json.dump(latest, open(latest_path, "w"), indent=1)
+print(dom, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in kernels[dom].items() if k != "sq_per_launch"})
+print("\n".join(l[:160] for l in stats[:5]))

@@ -1,0 +1,54 @@
+"""bench.py's N > 1 path: `python3 bench.py --gpus N` started plainly is its own launcher (one process per rank, 127.0.0.1
+rendezvous, gloo or RCCL for the timing barrier only), deals a fixed batch round-robin, and rank 0 prints ONE JSON line.
+On a CPU-only box --dry-run runs all of that except the GPU work; with a GPU two ranks share device 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_plain_launch_two_ranks_dry_run_batch():
+    d = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--workload", "batch64_1080p"])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["images_per_step"] == 64 and d["config"]["images_this_rank"] == 32
+    assert "configs[3]" in d["config"]["workload"] and d["unit"] == "Mpixel-iterations/s"
+    # SUM of the units of both ranks / MAX of their times: 3 steps x 64 images x 1080p x 1000 sweeps
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * 3 - 3 * 64 * 1080 * 1920 * 1000) < 1e-3 * 3 * 64 * 1080 * 1920 * 1000
+
+
+def test_plain_launch_default_workload_is_weak():
+    d = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["images_per_step"] == 2 and d["config"]["images_this_rank"] == 1
+    d1 = _run(["--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert d1["n_gpus"] == 1 and d1["config"]["images_per_step"] == 1
+
+
+def test_gpus_flag_must_match_world_size():
+    e = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run"], env=e, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_for_real():
+    """The product through the launcher: two ranks on device 0 (RTDD_BENCH_SHARE_GPU), a small image each."""
+    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", "270x480x100"], env={"RTDD_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["config"]["images_per_step"] == 2 and d["value"] > 0
+    assert d["config"]["persistent"] == 0                      # ranks sharing a GPU never launch persistently
+    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1
