@@ -153,6 +153,15 @@ def defocus(orig, depth, threads=1):
     return art
 
 
+def defocus_at(orig, depth, ys, xs):
+    """The literal gather of orc_defocus for the listed pixels only; returns [n, 3]."""
+    rows, cols = depth.shape
+    ys = np.ascontiguousarray(ys, np.int32); xs = np.ascontiguousarray(xs, np.int32)
+    out = np.zeros((len(ys), 3), np.uint8)
+    lib().orc_defocus_at(_p(orig), _pitch(orig), _p(depth), _pitch(depth), C.c_int(rows), C.c_int(cols), _p(ys), _p(xs), C.c_int(len(ys)), _p(out))
+    return out
+
+
 def haze(orig, depth, contract):
     rows, cols = depth.shape
     art = np.zeros_like(orig)

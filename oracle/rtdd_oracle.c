@@ -313,6 +313,29 @@ ORC_API void orc_defocus(const uint8_t *orig, size_t origPitch, const float *dep
     }
 }
 
+/* The same gather for a list of pixels only (full-size tests: the whole image would take minutes at 4K/8K). */
+ORC_API void orc_defocus_at(const uint8_t *orig, size_t origPitch, const float *depth, size_t depthPitch,
+                            int rows, int cols, const int32_t *ys, const int32_t *xs, int n, uint8_t *out /*[n*3]*/) {
+    int kernelSize = 0.025 * sqrtf(rows * rows + cols * cols);           /* :42 */
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; i++) {
+        const int y = ys[i], x = xs[i];
+        const float dv = ((const float *)((const char *)depth + (size_t)y * depthPitch))[x];
+        int k = kernelSize * dv / 255.0;                                 /* :43 */
+        float sum[3] = {0, 0, 0};
+        int count = 0;
+        for (int py = y - k / 2; py < y + k / 2; py++)
+            for (int px = x - k / 2; px < x + k / 2; px++)
+                if (px >= 0 && py >= 0 && px < cols && py < rows) {
+                    const uint8_t *o = orig + (size_t)py * origPitch + px * 3;
+                    sum[0] += o[0]; sum[1] += o[1]; sum[2] += o[2];
+                    count++;
+                }
+        const uint8_t *o = orig + (size_t)y * origPitch + x * 3;
+        for (int c = 0; c < 3; c++) out[3 * i + c] = count == 0 ? o[c] : sat_u8(sum[c] / count);
+    }
+}
+
 /* =====================================================================================
  * a12  GPUSimulateHaze (K10) -- src/GPUDepthEffect.cu:74-93
  * expf here is host libm; the CUDA device expf (<= 2 ulp) is not reproducible anywhere.

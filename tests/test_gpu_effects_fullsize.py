@@ -1,0 +1,62 @@
+"""The three depth effects (src/GPUDepthEffect.cu) at the sizes BASELINE names, on the GPU (-m gpu).
+
+Desaturation and haze are O(N): the oracle does whole 4K images.  Defocus is an O(K^2) gather per pixel in the reference
+(K = 110 at 4K, 220 at 8K): the oracle's literal gather is run on a sample of pixels, and EVERY pixel is checked against an
+independent O(N) restatement here -- a 64-bit summed-area table in numpy with the reference's window and rounding rules
+(src/GPUDepthEffect.cu:42-70).  At 8K the kernel's 32-bit table wraps (255 x 33 M pixels > 2^32): window sums are
+differences mod 2^32 of wrapped entries, exact because every window sum is < 2^24.
+"""
+import numpy as np
+import pytest
+
+import realtimedepthdiffusion_amd as rt
+from effects_ref import defocus_by_summed_area_table, effect_inputs as _inputs
+from gpu_util import down, up
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rt.Context(0)
+    c.GPULoadWeights(0.4)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("rows,cols,name", [(2160, 3840, "4K"), (4320, 7680, "8K")])
+def test_defocus_full_size_every_pixel(ctx, oracle, rows, cols, name):
+    orig, depth = _inputs(rows, cols, 11)
+    if name == "8K":
+        orig[: rows * 3 // 4] = 255                                 # make the 32-bit table wrap: 255 x 24.9 M pixels = 6.3e9 > 2^32
+        assert 255 * (rows * 3 // 4) * cols > 2 ** 32
+    art = up(np.zeros_like(orig))
+    ctx.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+    got = down(art)
+    want = defocus_by_summed_area_table(orig, depth)
+    assert np.array_equal(got, want), f"{name}: {int((got != want).sum())} of {got.size} values differ"
+    # and the literal gather of the oracle on a few hundred pixels spread over every depth regime (incl. the largest windows)
+    rng = np.random.default_rng(5)
+    ys = rng.integers(0, rows, 300); xs = rng.integers(0, cols, 300)
+    ys[:40] = rng.integers(0, rows // 4, 40)                        # depth 255: the full K x K window
+    lit = oracle.defocus_at(orig, depth, ys, xs)
+    assert np.array_equal(got[ys, xs], lit)
+
+
+def test_desaturation_and_haze_4k(ctx, oracle):
+    rows, cols = 2160, 3840
+    orig, depth = _inputs(rows, cols, 7)
+    gray = np.random.default_rng(9).integers(0, 256, (rows, cols), dtype=np.uint8)
+    o, d = up(orig), up(depth)
+    for contract in (1, 0):
+        ctx.set_option(rt.OPT_FP_CONTRACT, contract)
+        art = up(np.zeros_like(orig))
+        ctx.GPUSimulateDesaturation(o, up(gray), d, art, rows, cols)
+        assert np.array_equal(down(art), oracle.desaturate(orig, gray, depth, contract)), f"desaturation contract {contract}"
+        art = up(np.zeros_like(orig))
+        ctx.GPUSimulateHaze(o, d, art, rows, cols)
+        got = down(art).astype(np.int16); want = oracle.haze(orig, depth, contract).astype(np.int16)
+        diff = np.abs(got - want)
+        # device exp (f64, rounded once) vs host libm expf: <= 1 grey level on <= 1e-4 of the values
+        assert diff.max() <= 1 and (diff > 0).mean() <= 1e-4, (int(diff.max()), float((diff > 0).mean()))
+    ctx.set_option(rt.OPT_FP_CONTRACT, 1)

@@ -251,3 +251,14 @@ def test_cascade_helpers(oracle):
     up = oracle.pyrup_f32(ramp, 8, 12)
     assert np.allclose(up[3, 2:10], np.arange(2, 10) / 2.0)          # linear ramps are reproduced in the interior
     assert oracle.depth_to_u8(np.array([[0.5, 1.5, 2.5, -3, 300, 254.5]], np.float32)).tolist() == [[0, 2, 2, 0, 255, 254]]
+
+
+def test_summed_area_restatement_of_defocus_agrees_with_the_literal_gather(oracle):
+    """tests/effects_ref.py (used for the 4K / 8K defocus tests on the GPU) against orc_defocus, every pixel, and orc_defocus_at
+    (the literal gather for listed pixels) against orc_defocus."""
+    from effects_ref import defocus_by_summed_area_table, effect_inputs
+    orig, depth = effect_inputs(300, 420, 3)
+    lit = oracle.defocus(orig, depth, threads=4)
+    assert np.array_equal(defocus_by_summed_area_table(orig, depth), lit)
+    ys = np.array([0, 10, 299, 150, 77]); xs = np.array([0, 400, 419, 200, 5])
+    assert np.array_equal(oracle.defocus_at(orig, depth, ys, xs), lit[ys, xs])
