@@ -19,11 +19,11 @@
 namespace rtdd {
 namespace {
 
-__device__ __forceinline__ float from_prev_lane(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+__device__ __forceinline__ float from_prev_lane(float v) {          // (bound_ctrl: the lane without a source reads 0, never used -- sweep_blocked.hip)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float from_next_lane(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float div3(float n, float d, float y) {     // see sweep_blocked.hip: == RN(n/d) for normal d, n = 0 or |n| >= 2^-100
     const float q0 = n * y;
@@ -42,26 +42,6 @@ __device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     const f4v t = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
-}
-
-template <bool CONTRACT, bool FAST, bool SOR>
-__device__ __forceinline__ float gs_value(float x, float omega, float xl, float xr, float xu, float xd, float wl, float wr, float wu, float wd, float cnt, float rcp) {
-    float sum = 0.0f;
-    sum = CONTRACT ? __builtin_fmaf(wl, xl, sum) : sum + wl * xl;
-    sum = CONTRACT ? __builtin_fmaf(wr, xr, sum) : sum + wr * xr;
-    sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
-    sum = CONTRACT ? __builtin_fmaf(wd, xd, sum) : sum + wd * xd;
-    float r;
-    if (FAST) {
-        r = div3(sum, cnt, rcp);
-        const bool tiny = __builtin_fabsf(sum) < 0x1p-100f && sum != 0.0f;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny) != 0, 0)) r = tiny ? sum / cnt : r;
-    } else {
-        r = sum / cnt;
-    }
-    r = __builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
-    if (SOR) { r = CONTRACT ? __builtin_fmaf(omega, r - x, x) : x + omega * (r - x); r = __builtin_amdgcn_fmed3f(r, 0.0f, 255.0f); }
-    return r;
 }
 
 }  // namespace
@@ -151,61 +131,115 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
         }
     const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
 
-    auto half = [&](int colour, int h, auto fast) {                // h = running half-sweep index
-        constexpr bool FAST = decltype(fast)::value;
-        const int buf = h & 1;
-        float4 up4 = make_float4(0, 0, 0, 0), dn4 = up4;
+    // One half-sweep, written like sweep_blocked.hip's sweep body (see the comments there): the pixels of the colour in two GROUPS
+    // of rows -- the thread's first and last row, whose new values the neighbouring thread rows need, then the interior rows --,
+    // each group as independent chains (sums, 3-op quotients, ONE branch-free test for numerators too small for the 3-op divide,
+    // then clamp / SOR step / Dirichlet select); the edge rows are PUBLISHED before the interior rows are computed; the wait reads
+    // both neighbouring waves' counters in one LDS access.  In-place update is safe inside a group: every operand of a pixel of
+    // one colour is of the other colour.
+    constexpr uint32_t kTinyT = 2u * 0x0D800000u - 1u;          // 2 * bits(2^-100) - 1
+    const int wv = tid >> 6, nwv = (int)blockDim.x >> 6;
+    const int flag_idx = (tid & 63) == 0 ? (wv > 0 ? wv - 1 : wv) : (wv < nwv - 1 ? wv + 1 : wv);
+    auto publish = [&](int h, int buf) {                           // the rows half-sweep h of the neighbours reads
         *(f4r *)&edge[buf][tr][0][lx] = a[0];
         *(f4r *)&edge[buf][tr][1][lx] = a[G - 1];
-        {
-            const int wv = tid >> 6, nwv = (int)blockDim.x >> 6;
-            __hip_atomic_store(&published[wv], h + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (wv > 0)
-                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < h + 1) __builtin_amdgcn_s_sleep(1);
-            if (wv < nwv - 1)
-                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < h + 1) __builtin_amdgcn_s_sleep(1);
+        __hip_atomic_store(&published[wv], h + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto half = [&](int h, auto fast, auto col, bool last_of_block) {      // h = running half-sweep index; colour = h & 1 = buffer
+        constexpr bool FAST = decltype(fast)::value;
+        constexpr int C = decltype(col)::value;
+        for (;;) {
+            const int f = __hip_atomic_load(&published[flag_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int f0 = __builtin_amdgcn_readlane(f, 0), f1 = __builtin_amdgcn_readlane(f, 1);
+            if ((f0 < f1 ? f0 : f1) >= h + 1) break;
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (tr > 0) up4 = edge[buf][tr - 1][1][lx];
-        if (tr < ntr - 1) dn4 = edge[buf][tr + 1][0][lx];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the first / last thread row reads its OWN published row instead of a row above / below (finite, and either weighted 0 or discarded halo)
+        const float4 up4 = edge[C][tr > 0 ? tr - 1 : 0][tr > 0 ? 1 : 0][lx];
+        const float4 dn4 = edge[C][tr < ntr - 1 ? tr + 1 : tr][tr < ntr - 1 ? 0 : 1][lx];
         const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
         float xl0[G], xr3[G];
+        auto wsum = [&](int g, int i) {
+            const float xl = i == 0 ? xl0[g] : a[g][i - 1];
+            const float xr = i == 3 ? xr3[g] : a[g][i + 1];
+            const float xu = g == 0 ? up[i] : a[g - 1][i];
+            const float xd = g == G - 1 ? dn[i] : a[g + 1][i];
+            const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
+            const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
+            float sum = 0.0f;
+            sum = CONTRACT ? __builtin_fmaf(wl, xl, sum) : sum + wl * xl;
+            sum = CONTRACT ? __builtin_fmaf(wr[g][i], xr, sum) : sum + wr[g][i] * xr;
+            sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
+            sum = CONTRACT ? __builtin_fmaf(wd[g][i], xd, sum) : sum + wd[g][i] * xd;
+            return sum;
+        };
+        auto group = [&](auto pick) {
+            float q[G][4];
+            uint32_t tmin = 0xFFFFFFFFu;
 #pragma unroll
-        for (int g = 0; g < G; g++) { xl0[g] = from_prev_lane(a[g][3]); xr3[g] = from_next_lane(a[g][0]); }   // all fetched BEFORE any in-place update
-        // colour is wave-uniform at run time but the PIXELS of a colour are a compile-time pattern: two instantiations
-        auto run = [&](auto col) {
-            constexpr int C = decltype(col)::value;
-#pragma unroll
-            for (int g = 0; g < G; g++)
+            for (int g = 0; g < G; g++) {
+                if (!pick(g)) continue;
+                // a pixel of colour C in column 0 / 3 needs the neighbouring lane's value (of the other colour: not touched by this half-sweep)
+                if (((g + 0) & 1) == C) xl0[g] = from_prev_lane(a[g][3]);
+                if (((g + 3) & 1) == C) xr3[g] = from_next_lane(a[g][0]);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     if (((g + i) & 1) != C) continue;
-                    const float xl = i == 0 ? xl0[g] : a[g][i - 1];
-                    const float xr = i == 3 ? xr3[g] : a[g][i + 1];
-                    const float xu = g == 0 ? up[i] : a[g - 1][i];
-                    const float xd = g == G - 1 ? dn[i] : a[g + 1][i];
-                    const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
-                    const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
-                    const float v = gs_value<CONTRACT, FAST, SOR>(a[g][i], omega, xl, xr, xu, xd, wl, wr[g][i], wu, wd[g][i], cnt[g][i], rcp[g][i]);
-                    a[g][i] = (dirichlet >> (g * 4 + i)) & 1u ? a[g][i] : v;
+                    const float sum = wsum(g, i);
+                    if (FAST) { q[g][i] = div3(sum, cnt[g][i], rcp[g][i]); tmin = min(tmin, (__float_as_uint(sum) << 1) + 0xFFFFFFFFu); }
+                    else q[g][i] = sum / cnt[g][i];
                 }
+            }
+            if (FAST && __builtin_expect(__builtin_amdgcn_ballot_w64(tmin < kTinyT) != 0, 0)) {      // wave-uniform, rare: full IEEE divide
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    if (!pick(g)) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) if (((g + i) & 1) == C) q[g][i] = wsum(g, i) / cnt[g][i];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (!pick(g)) continue;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (((g + i) & 1) != C) continue;
+                    const float x = a[g][i];
+                    float r = __builtin_amdgcn_fmed3f(q[g][i], 0.0f, 255.0f);
+                    if (SOR) { r = CONTRACT ? __builtin_fmaf(omega, r - x, x) : x + omega * (r - x); r = __builtin_amdgcn_fmed3f(r, 0.0f, 255.0f); }
+                    a[g][i] = (dirichlet >> (g * 4 + i)) & 1u ? x : r;
+                }
+            }
         };
-        if (colour == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+        group([](int g) { return g == 0 || g == G - 1; });
+        if (!last_of_block) publish(h + 1, C ^ 1);
+        group([](int g) { return g != 0 && g != G - 1; });
     };
 
     // colour 0 of the oracle = (x + y) even.  Pixel (g, i) sits at (x0 + i, y0 + g) with x0 % 4 == 0 and y0 even, so its
     // image colour is (g + i) & 1.  (y0 = by*TH - hy + tr*G: every term even.)
-    const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
     const int tile_id = by * gx + bx;
     int h = 0, s = 0, blk = 0;
     for (;; blk++) {
         const int s_end = min(s + block_sweeps, nsweeps);
+        publish(h, 0);                                             // block prologue: the rows the first half-sweep reads (h is even)
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
         for (; s < s_end; s++) {
-            if (!wave_unsafe) { half(0, h, std::true_type{}); half(1, h + 1, std::true_type{}); }
-            else { half(0, h, std::false_type{}); half(1, h + 1, std::false_type{}); }
+            if (!wave_unsafe) { half(h, std::true_type{}, C0{}, false); half(h + 1, std::true_type{}, C1{}, s + 1 >= s_end); }
+            else { half(h, std::false_type{}, C0{}, false); half(h + 1, std::false_type{}, C1{}, s + 1 >= s_end); }
             h += 2;
         }
         if (!PERSIST || s >= nsweeps) break;
         float *Ex = (blk & 1) ? X : Y;
+        // (addresses and predicates recomputed from a laundered thread index: hoisted out of the block loop they would stay live
+        // across the sweeps and push the sweep loop's operands into scratch -- as in sweep_blocked.hip)
+        int tid_x = tid;
+        asm volatile("" : "+v"(tid_x));
+        const int lx = tid_x % LX, tr = tid_x / LX;
+        const int x0 = bx * TW - hx + 4 * lx, y0 = by * TH - hy + tr * G;
+        const bool colok = x0 >= 0 && x0 < cols;
+        const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int y = y0 + g, ty = tr * G + g;
@@ -230,10 +264,15 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
     }
     if (PERSIST && (blk & 1)) Y = X;                                     // the last block's parity names the result buffer
 
+    int tid_w = tid;
+    asm volatile("" : "+v"(tid_w));
+    const int lx_w = tid_w % LX, tr_w = tid_w / LX;
+    const int x0_w = bx * TW - hx + 4 * lx_w, y0_w = by * TH - hy + tr_w * G;
+    const bool xin_w = x0_w >= 0 && x0_w < cols && 4 * lx_w >= hx && 4 * lx_w < EW - hx;
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        const int y = y0 + g, ty = tr * G + g;
-        if (xin && ty >= hy && ty < eh - hy && y < rows) *(f4r *)(Y + (size_t)y * ip + x0) = a[g];
+        const int y = y0_w + g, ty = tr_w * G + g;
+        if (xin_w && ty >= hy && ty < eh - hy && y < rows) *(f4r *)(Y + (size_t)y * ip + x0_w) = a[g];
     }
 }
 
