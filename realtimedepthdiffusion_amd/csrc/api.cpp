@@ -114,8 +114,8 @@ int rtdd_ctx_create(int device, rtdd_ctx **out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     bool ok = hipMalloc((void **)&ctx->lut_dev, 257 * sizeof(float)) == hipSuccess &&
               hipMalloc((void **)&ctx->residual_dev, 64) == hipSuccess &&
-              hipMalloc((void **)&ctx->sync_words, (kSyncFlags + kSyncMaxTiles) * sizeof(int)) == hipSuccess &&
-              hipMemset(ctx->sync_words, 0, (kSyncFlags + kSyncMaxTiles) * sizeof(int)) == hipSuccess;
+              hipMalloc((void **)&ctx->sync_words, kSyncWords * sizeof(int)) == hipSuccess &&
+              hipMemset(ctx->sync_words, 0, kSyncWords * sizeof(int)) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) { rtdd_ctx_destroy(ctx); return RTDD_ERR_HIP; }
     *out = ctx;

@@ -19,6 +19,7 @@
 namespace rtdd {
 
 constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncFlags = 16, kSyncMaxTiles = 1024;
+constexpr int kSyncWords = kSyncFlags + kSyncMaxTiles;              // size of sync_words in ints
 constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: legitimate waits are microseconds
 
 #ifdef __HIPCC__
@@ -62,6 +63,7 @@ __device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, in
     __syncthreads();
     return __hip_atomic_load(dead_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
 }
+
 #endif
 
 }  // namespace rtdd

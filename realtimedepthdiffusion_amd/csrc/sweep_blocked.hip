@@ -133,6 +133,13 @@ __device__ unsigned long long g_stamps[4096][4];
 #else
 #define RTDD_STAMP(k) do {} while (0)
 #endif
+#ifdef RTDD_TIMELINE   // diagnostic build only (scripts/ubench/sweep_timeline.hip): per-wave, per-sweep s_memtime stamps of ONE workgroup
+__device__ unsigned long long g_tl[16][64][4];      // [wave][sweep][0 top of sweep, 1 neighbours' rows in hand, 2 own edge rows published, 3 end]
+__device__ int g_tl_tile = 100;
+#define RTDD_TL(k, sw) do { if (tile_id_tl == g_tl_tile && (threadIdx.x & 63) == 0 && (sw) < 64) g_tl[threadIdx.x >> 6][(sw)][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RTDD_TL(k, sw) do {} while (0)
+#endif
 #ifdef RTDD_STAMPS
 __device__ unsigned long long g_xphase[4096][6];
 #define RTDD_XT(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); g_xphase[blockIdx.y * gridDim.x + blockIdx.x][k] += t_ - xt_; xt_ = t_; } } while (0)
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     //     >= s+1, which they set after consuming (reading and waiting for) my sweep-(s-1) rows from that buffer.
     constexpr uint32_t kTinyT = 2u * 0x0D800000u - 1u;          // bits(2^-100) = 27 << 23
     const int wv = tid >> 6, nwv = (int)blockDim.x >> 6;
+    const int tile_id_tl = by * gx + bx; (void)tile_id_tl;
     auto publish = [&](const f4r &top, const f4r &bottom, int sweep_no, int buf) {      // rows that sweep `sweep_no` of the neighbours reads
         // (buf = sweep_no & 1, passed separately so that it is a compile-time constant in the unrolled sweep pair: every block
         // starts at an even sweep)
@@ -346,8 +354,12 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
         if (tr < ntr - 1) pre_dn = *(const f4r *)&edge[buf][tr + 1][0][lx];
     };
 #endif
+    unsigned lds_spins = 0;
+    bool gone = false;                       // the launch is dead (dead_s is set): this wave stops waiting for its neighbours; the whole
+                                             // workgroup leaves together at the next exchange (exchange_wait returns true for everyone)
     auto await = [&](int sweep_no) {
 #if RTDD_F_ONEPOLL
+        if (gone) return;
         // both neighbours' counters in one LDS access: lane 0 reads the wave above, every other lane the wave below
 #if RTDD_F_PRIO2
         const int idx = (tid & 63) == 0 ? (wv > 0 ? wv - 1 : wv) : (tid & 63) == 2 ? NT / 64 : (wv < nwv - 1 ? wv + 1 : wv);      // lane 2: the maximum
@@ -380,6 +392,14 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
+            if ((++lds_spins & 1023u) == 0) {                        // a neighbouring wave that has LEFT (dead launch) never publishes again
+                if (__hip_atomic_load(&dead_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { gone = true; break; }
+                if (lds_spins > (1u << 22)) {                        // seconds: every wave of a workgroup is resident, so this is a bug -- say so, never hang
+                    __hip_atomic_store(&sync_words[kSyncStatus], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&dead_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    gone = true; break;
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #else
@@ -409,6 +429,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 #if !RTDD_F_EARLY
         publish(cur[0], cur[G - 1], s, buf);
 #endif
+        RTDD_TL(0, s);
         await(s);
         // The first / last thread row of the tile has no row above / below in LDS: it reads its OWN published row instead (any
         // finite value will do -- the weight towards it is 0 at the image border, and elsewhere that row is discarded halo), which
@@ -416,6 +437,10 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
         const float4 up4 = edge[buf][tr > 0 ? tr - 1 : 0][tr > 0 ? 1 : 0][lx];
         const float4 dn4 = edge[buf][tr < ntr - 1 ? tr + 1 : tr][tr < ntr - 1 ? 0 : 1][lx];
         const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
+#ifdef RTDD_TIMELINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RTDD_TL(1, s);
+#endif
 #endif
         const float omega = omegas[s];
         float xl0[G], xr3[G];                    // filled per group (each costs a register until its row is done)
@@ -494,12 +519,14 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
             prefetch(buf ^ 1);
 #endif
         }
+        RTDD_TL(2, s);
 #if RTDD_F_ROWGROUP
 #pragma unroll
         for (int gi = 1; gi < G - 1; gi++) group([gi](int g) { return g == gi; });
 #else
         if (G > 2) group([](int g) { return g != 0 && g != G - 1; });
 #endif
+        RTDD_TL(3, s);
 #else
         (void)last_of_block;
         group([](int) { return true; });

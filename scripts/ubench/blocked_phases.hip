@@ -8,7 +8,7 @@
 namespace rtdd {
 int fail(rtdd_ctx *, int s, const char *, hipError_t) { return s; }
 int prepare_persistent_launch(rtdd_ctx *ctx) {
-    if (!ctx->sync_words) { hipMalloc((void **)&ctx->sync_words, (kSyncFlags + kSyncMaxTiles) * sizeof(int)); hipMemset(ctx->sync_words, 0, (kSyncFlags + kSyncMaxTiles) * sizeof(int)); }
+    if (!ctx->sync_words) { hipMalloc((void **)&ctx->sync_words, kSyncWords * sizeof(int)); hipMemset(ctx->sync_words, 0, kSyncWords * sizeof(int)); }
     hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, kSyncMaxTiles * sizeof(int), ctx->stream);
     return 0;
 }
