@@ -49,18 +49,6 @@ __device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
 #ifndef RTDD_STORE_MODE
 #define RTDD_STORE_MODE 0
 #endif
-// Sweep body variants (diagnostic knob for A/B builds, scripts/build_variant.sh): 0 = the round-1 body; otherwise features:
-#ifndef RTDD_SWEEP_V
-#define RTDD_SWEEP_V 9
-#endif
-#define RTDD_F_EARLY    (RTDD_SWEEP_V >= 2)                        /* edge rows first, published before the interior rows */
-#define RTDD_F_ONEPOLL  (RTDD_SWEEP_V >= 3)                        /* both neighbours' counters in one LDS access */
-#define RTDD_F_SPEC     (RTDD_SWEEP_V == 4 || RTDD_SWEEP_V == 5)   /* no-wait publish + speculative row fetch (slower: see DESIGN.md) */
-#define RTDD_F_ROWGROUP (RTDD_SWEEP_V == 5 || RTDD_SWEEP_V == 7 || RTDD_SWEEP_V >= 9)   /* one row per group */
-#define RTDD_F_PRIO     (RTDD_SWEEP_V >= 6 && RTDD_SWEEP_V <= 8)   /* waves whose neighbours are both ahead raise their issue priority (no gain) */
-#define RTDD_F_PRIO2    (RTDD_SWEEP_V >= 10)                       /* issue priority = distance behind the workgroup's leading wave */
-#define RTDD_F_NOWAIT   (RTDD_F_SPEC || RTDD_SWEEP_V == 8)         /* no s_waitcnt between the row stores and the counter store */
-
 __device__ __forceinline__ void store_result(float4 *p, float4 v) {
 #if RTDD_STORE_MODE == 1
     __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
@@ -260,51 +248,6 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 
     RTDD_STAMP(1);
     // ---- n sweeps in registers -------------------------------------------------------------------
-#if RTDD_SWEEP_V == 0
-    auto sweep = [&](f4r (&cur)[G], f4r (&oth)[G], int s, auto fast) {
-        constexpr bool FAST = decltype(fast)::value;
-        const int buf = s & 1;
-        // Vertical halo exchange.  A workgroup barrier here costs as much as the sweep's arithmetic (measured
-        // 0.7 of 1.4 us per sweep for 16 waves: every wave of a SIMD drains and refills together), but a wave
-        // only needs the edge rows of the two ADJACENT waves.  So: publish own edge rows, release-store a per-wave
-        // counter, acquire-spin on the two neighbours' counters.  Waves drift apart by up to one sweep and the
-        // SIMDs stay busy.  Buffer reuse is safe without a second handshake: a neighbour publishes sweep s+1 only
-        // after it has consumed my sweep-s rows, and I overwrite that buffer (sweep s+2) only after waiting for
-        // its sweep-s+1 rows.  All waves of a workgroup are co-resident, so the spin cannot deadlock.
-        float4 up4 = make_float4(0, 0, 0, 0), dn4 = up4;
-        *(f4r *)&edge[buf][tr][0][lx] = cur[0];
-        *(f4r *)&edge[buf][tr][1][lx] = cur[G - 1];
-        {
-            const int wv = tid >> 6, nwv = (int)blockDim.x >> 6;
-            __hip_atomic_store(&published[wv], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (wv > 0)
-                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < s + 1) __builtin_amdgcn_s_sleep(1);
-            if (wv < nwv - 1)
-                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < s + 1) __builtin_amdgcn_s_sleep(1);
-        }
-        if (tr > 0) up4 = edge[buf][tr - 1][1][lx];
-        if (tr < ntr - 1) dn4 = edge[buf][tr + 1][0][lx];
-        const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
-        const float omega = omegas[s];
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const float xl0 = lane_from_prev(cur[g][3]);
-            const float xr3 = lane_from_next(cur[g][0]);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float xl = i == 0 ? xl0 : cur[g][i - 1];
-                const float xr = i == 3 ? xr3 : cur[g][i + 1];
-                const float xu = g == 0 ? up[i] : cur[g - 1][i];
-                const float xd = g == G - 1 ? dn[i] : cur[g + 1][i];
-                const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
-                const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
-                const float v = relax<CONTRACT, FAST>(xl, xr, xu, xd, wl, wr[g][i], wu, wd[g][i], cnt[g][i], rcp[g][i], cur[g][i], oth[g][i], omega, gamma);
-                oth[g][i] = (dirichlet >> (g * 4 + i)) & 1u ? cur[g][i] : v;      // x_{k+1} replaces x_{k-1}
-            }
-        }
-    };
-
-#else
     // One sweep, written for instruction-level parallelism: the weighted sums and quotients of a GROUP of rows first (12 independent
     // 7-deep chains the scheduler can interleave -- a wave alone on its SIMD issues a dependent VALU instruction only every ~6.6 cycles,
     // an independent one every 4), ONE wave-uniform test for numerators too small for the 3-op divide (below), then the updates.
@@ -313,10 +256,15 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     //     compare: 1.5 VALU ops per pixel and no branch, instead of two compares, two SALU ops and a branch per pixel.  A wave that
     //     does see such a numerator (values decaying through 1e-31, pixels whose four weights are all ~1e-38) recomputes the group
     //     with the full IEEE divide; x_{k-1} is still intact then because the updates come after the test.
-    //   * RTDD_SWEEP_V >= 2: the rows the neighbours need (a thread's first and last) form the first group and are PUBLISHED as soon
-    //     as they are updated, before the interior rows are computed; the wait for the neighbours' rows at the top of the next sweep
-    //     then finds them already there.  Buffer reuse: I write buffer (s+1)&1 in sweep s after my wait for the neighbours' flags
-    //     >= s+1, which they set after consuming (reading and waiting for) my sweep-(s-1) rows from that buffer.
+    //   * the rows the neighbouring thread rows need (a thread's first and last) are computed first and PUBLISHED as soon as they
+    //     are updated, before the interior rows; the wait for the neighbours' rows at the top of the next sweep then usually finds
+    //     them there.  Buffer reuse: I write buffer (s+1)&1 in sweep s after my wait for the neighbours' counters >= s+1, which they
+    //     set after consuming (reading and waiting for) my sweep-(s-1) rows from that buffer.
+    //   * one row per group: 4 chains cover the VALU latency, and only 4 quotients + 4 sums are live at a time (the 1024-thread tiles
+    //     have 128 registers; two rows per group spilled inside the loop).
+    // Measured and dropped: publishing without draining lgkmcnt, fetching the neighbours' rows speculatively
+    // before their counter is known, fetching counter and rows in one go, s_setprio feedback for lagging waves, a half-sweep
+    // stagger between groups of four waves, and a wave-level (barrier-free) hand-off between workgroups.
     constexpr uint32_t kTinyT = 2u * 0x0D800000u - 1u;          // bits(2^-100) = 27 << 23
     const int wv = tid >> 6, nwv = (int)blockDim.x >> 6;
     const int tile_id_tl = by * gx + bx; (void)tile_id_tl;
@@ -325,72 +273,19 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
         // starts at an even sweep)
         *(f4r *)&edge[buf][tr][0][lx] = top;
         *(f4r *)&edge[buf][tr][1][lx] = bottom;
-#if RTDD_F_NOWAIT
-        // The LDS executes one wave's instructions in issue order, so the counter store below cannot overtake the two row stores:
-        // no s_waitcnt between them (a workgroup-scope release would drain lgkmcnt here, ~100 cycles per sweep with the wave parked).
-        // The wavefront-scope fences only pin the order in the compiler.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __hip_atomic_store(&published[wv], sweep_no + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#else
         __hip_atomic_store(&published[wv], sweep_no + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-#if RTDD_F_PRIO2
-        __hip_atomic_fetch_max(&published[NT / 64], sweep_no + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
     };
-#if RTDD_F_SPEC
-    // Speculative fetch of the rows sweep `sweep_no` needs: counters first, rows behind them, nothing waited for.  Issued right
-    // after the own rows are published and consumed one group of rows later; if the counters (read BEFORE the rows, in order)
-    // already showed the neighbours' rows as published the rows are valid, otherwise fetch again.
-    const int flag_idx = (tid & 63) == 0 ? (wv > 0 ? wv - 1 : wv) : (wv < nwv - 1 ? wv + 1 : wv);
-    int pre_flag = 0;
-    bool broken = false;
-    f4r pre_up = {0, 0, 0, 0}, pre_dn = {0, 0, 0, 0};
-    auto prefetch = [&](int buf) {
-        pre_flag = __hip_atomic_load(&published[flag_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (tr > 0) pre_up = *(const f4r *)&edge[buf][tr - 1][1][lx];
-        if (tr < ntr - 1) pre_dn = *(const f4r *)&edge[buf][tr + 1][0][lx];
-    };
-#endif
     unsigned lds_spins = 0;
     bool gone = false;                       // the launch is dead (dead_s is set): this wave stops waiting for its neighbours; the whole
                                              // workgroup leaves together at the next exchange (exchange_wait returns true for everyone)
     auto await = [&](int sweep_no) {
-#if RTDD_F_ONEPOLL
         if (gone) return;
         // both neighbours' counters in one LDS access: lane 0 reads the wave above, every other lane the wave below
-#if RTDD_F_PRIO2
-        const int idx = (tid & 63) == 0 ? (wv > 0 ? wv - 1 : wv) : (tid & 63) == 2 ? NT / 64 : (wv < nwv - 1 ? wv + 1 : wv);      // lane 2: the maximum
-#else
         const int idx = (tid & 63) == 0 ? (wv > 0 ? wv - 1 : wv) : (wv < nwv - 1 ? wv + 1 : wv);
-#endif
         for (;;) {
             const int f = __hip_atomic_load(&published[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int f0 = __builtin_amdgcn_readlane(f, 0), f1 = __builtin_amdgcn_readlane(f, 1);
-            const int fmin = f0 < f1 ? f0 : f1;
-            if (fmin >= sweep_no + 1) {
-#if RTDD_F_PRIO2
-                // The SIMD arbitrates by priority, then AGE: left alone, the oldest waves of a SIMD take the issue slots until they block
-                // on a neighbour and the workgroup advances as a staircase, one sweep per wave (wave 0 finishes a block of 8 sweeps in
-                // half the time of the last wave): a 16-stage pipeline that fills and drains once per block.  So: the further a wave
-                // is behind the workgroup's leading wave, the higher its priority.
-                const int behind = __builtin_amdgcn_readlane(f, 2) - (sweep_no + 1);
-                if (behind <= 0) __builtin_amdgcn_s_setprio(0);
-                else if (behind == 1) __builtin_amdgcn_s_setprio(1);
-                else if (behind == 2) __builtin_amdgcn_s_setprio(2);
-                else __builtin_amdgcn_s_setprio(3);
-#endif
-#if RTDD_F_PRIO
-                // The SIMD arbitrates by priority, then AGE: left alone, the oldest two waves of a SIMD take every issue slot until
-                // they block on a neighbour, the youngest starve, and the workgroup advances as a staircase (wave 0 finishes a block
-                // of 8 sweeps in half the time of wave 15) with its SIMDs half idle.  So a wave whose neighbours are already a sweep
-                // ahead -- it is what they will wait for next -- raises its priority, and one that is level or ahead drops it.
-                if (fmin >= sweep_no + 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
-                break;
-            }
+            if ((f0 < f1 ? f0 : f1) >= sweep_no + 1) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++lds_spins & 1023u) == 0) {                        // a neighbouring wave that has LEFT (dead launch) never publishes again
                 if (__hip_atomic_load(&dead_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { gone = true; break; }
@@ -402,33 +297,10 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#else
-        if (wv > 0)
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < sweep_no + 1) __builtin_amdgcn_s_sleep(1);
-        if (wv < nwv - 1)
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&published[wv + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < sweep_no + 1) __builtin_amdgcn_s_sleep(1);
-#endif
     };
     auto sweep = [&](f4r (&cur)[G], f4r (&oth)[G], int s, auto fast, bool last_of_block, auto parity) {
         constexpr bool FAST = decltype(fast)::value;
         constexpr int buf = decltype(parity)::value;         // = s & 1
-#if RTDD_F_SPEC
-        (void)buf;
-        for (unsigned spins = 0;;) {
-            const int f0 = __builtin_amdgcn_readlane(pre_flag, 0), f1 = __builtin_amdgcn_readlane(pre_flag, 1);
-            if ((f0 < f1 ? f0 : f1) >= s + 1 || broken) break;
-            __builtin_amdgcn_s_sleep(1);
-            prefetch(buf);
-            if (++spins > (1u << 20)) {          // ~0.1 s: every wave of a workgroup is resident, so this is a protocol bug -- never hang, say so
-                __hip_atomic_store(&sync_words[kSyncStatus], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                broken = true;
-            }
-        }
-        const float up[4] = {pre_up[0], pre_up[1], pre_up[2], pre_up[3]}, dn[4] = {pre_dn[0], pre_dn[1], pre_dn[2], pre_dn[3]};
-#else
-#if !RTDD_F_EARLY
-        publish(cur[0], cur[G - 1], s, buf);
-#endif
         RTDD_TL(0, s);
         await(s);
         // The first / last thread row of the tile has no row above / below in LDS: it reads its OWN published row instead (any
@@ -440,7 +312,6 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 #ifdef RTDD_TIMELINE
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RTDD_TL(1, s);
-#endif
 #endif
         const float omega = omegas[s];
         float xl0[G], xr3[G];                    // filled per group (each costs a register until its row is done)
@@ -505,35 +376,14 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
                 }
             }
         };
-#if RTDD_F_EARLY
-#if RTDD_F_ROWGROUP
-        // one row per group: 4 chains are enough to cover the VALU latency, and only 4 quotients + 4 sums are live at a time
         group([](int g) { return g == 0; });
         if (G > 1) group([](int g) { return g == G - 1; });
-#else
-        group([](int g) { return g == 0 || g == G - 1; });
-#endif
-        if (!last_of_block) {
-            publish(oth[0], oth[G - 1], s + 1, buf ^ 1);
-#if RTDD_F_SPEC
-            prefetch(buf ^ 1);
-#endif
-        }
+        if (!last_of_block) publish(oth[0], oth[G - 1], s + 1, buf ^ 1);
         RTDD_TL(2, s);
-#if RTDD_F_ROWGROUP
 #pragma unroll
         for (int gi = 1; gi < G - 1; gi++) group([gi](int g) { return g == gi; });
-#else
-        if (G > 2) group([](int g) { return g != 0 && g != G - 1; });
-#endif
         RTDD_TL(3, s);
-#else
-        (void)last_of_block;
-        group([](int) { return true; });
-#endif
     };
-#define RTDD_SWEEP_NEW 1
-#endif
 
     // (the divide variant is chosen per wave; the neighbour handshake above does not care which one a wave runs)
     const int tile_id = by * gx + bx, ntiles = gx * gy;
@@ -542,27 +392,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     RTDD_XT_BEGIN;
     for (;; blk++) {
         const int s_end = min(s + block_sweeps, nsweeps);
-#if RTDD_SWEEP_V == 0
-        if (!wave_unsafe) {
-            for (; s + 1 < s_end; s += 2) {
-                sweep(a, b, s, std::true_type{});
-                sweep(b, a, s + 1, std::true_type{});
-            }
-            if (s < s_end) { sweep(a, b, s, std::true_type{}); s++; odd = true; }
-        } else {
-            for (; s + 1 < s_end; s += 2) {
-                sweep(a, b, s, std::false_type{});
-                sweep(b, a, s + 1, std::false_type{});
-            }
-            if (s < s_end) { sweep(a, b, s, std::false_type{}); s++; odd = true; }
-        }
-#else
-#if RTDD_F_EARLY
         publish(a[0], a[G - 1], s, 0);               // block prologue: the rows the first sweep of this block reads (a = newest here; s is even)
-#endif
-#if RTDD_F_SPEC
-        prefetch(0);
-#endif
         using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
         if (!wave_unsafe) {
             for (; s + 1 < s_end; s += 2) {
@@ -577,7 +407,6 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
             }
             if (s < s_end) { sweep(a, b, s, std::false_type{}, true, P0{}); s++; odd = true; }
         }
-#endif
         if (!PERSIST || s >= nsweeps) break;
         RTDD_XT(0);
 

@@ -17,7 +17,8 @@ using namespace rtdd;
 int main(int argc, char **argv) {
     int rows = argc > 1 ? atoi(argv[1]) : 1080, cols = argc > 2 ? atoi(argv[2]) : 1920, tile = argc > 3 ? atoi(argv[3]) : 4, T = argc > 4 ? atoi(argv[4]) : 8;
     int nsweeps = argc > 5 ? atoi(argv[5]) : 32;
-    rtdd_ctx ctx; ctx.opt.tile = tile; ctx.opt.temporal_depth = T; ctx.opt.persistent = 1; ctx.num_cus = 256;
+    rtdd_ctx ctx; ctx.opt.tile = tile; ctx.opt.temporal_depth = T; ctx.opt.persistent = argc > 6 ? atoi(argv[6]) : 1; ctx.num_cus = 256;
+    { int t = argc > 7 ? atoi(argv[7]) : 100; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_tile), &t, sizeof(t)); }
     rtdd::prepare_persistent_launch(&ctx);
     Level L; size_t ip = plane_pitch(cols); L.elems = plane_elems(rows, cols);
     std::vector<float> h(L.elems); for (auto &v : h) v = (float)(rand() % 25500) / 100.0f;
