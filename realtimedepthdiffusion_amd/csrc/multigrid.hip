@@ -346,56 +346,107 @@ __global__ __launch_bounds__(1024) void k_mg_gs_lds(Stencil s, float *e, const f
 // into LDS and runs ALL the colour steps of the smoothing step on it; what a missing outer neighbour spoils moves inwards one
 // point per colour step and stops short of the tile, so the tile's own points end up exactly as a level-wide sweep leaves
 // them.  One launch instead of 4 per sweep.  Tiles read each other's points, so the result goes to a second plane.
-constexpr int kTileX = 64, kTileY = 32;
-__global__ __launch_bounds__(1024) void k_mg_gs_tile(Stencil s, const float *e, float *out, const float *b, int nsweeps, int reverse) {
-    constexpr int PPT = 4;
-    extern __shared__ float le[];
-    const int H = 4 * nsweeps, EW = kTileX + 2 * H, EH = kTileY + 2 * H, LP = EW + 2, tid = threadIdx.x;
+//
+// Data movement (round 2): a thread owns two groups of 4 consecutive points and fetches E, S, SE, SW, D, b and e of a group as
+// one 16-byte load each -- 7 coalesced loads per group instead of 11 bounds-checked scalar gathers per POINT.  The other four
+// couplings of a point are its neighbours' own (W = the left point's E, N = the upper point's S, NW = the upper-left point's SE,
+// NE = the upper-right point's SW): the threads trade them through two LDS staging planes (E and S, then SE and SW).  A
+// neighbour outside the extended tile reads as coupling 0, which only touches the outermost ring -- spoilt from the first step
+// anyway.  512 threads and ~100 registers: two workgroups per CU, so one loads while the other relaxes.
+constexpr int kTileX = 64, kTileY = 32, kTileThreads = 512;
+__global__ __launch_bounds__(kTileThreads, 4) void k_mg_gs_tile(Stencil s, const float *e, float *out, const float *b, int nsweeps, int reverse) {
+    constexpr int GPT = 2;                               // groups of 4 points per thread
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ float lds[];
+    const int H = 4 * nsweeps, EW = kTileX + 2 * H, EH = kTileY + 2 * H, LP = EW + 2, GW = EW / 4, tid = threadIdx.x;
+    const int plane = (EH + 2) * LP;
+    float *le = lds, *st0 = lds + plane, *st1 = lds + 2 * plane;
     const int ox = blockIdx.x * kTileX - H, oy = blockIdx.y * kTileY - H;
-    for (int i = tid; i < (EH + 2) * LP; i += 1024) le[i] = 0.0f;
+    for (int i = tid; i < 3 * plane; i += kTileThreads) lds[i] = 0.0f;
     __syncthreads();
-    float cw[PPT][8], dg[PPT], rb[PPT];
-    int at_[PPT], col[PPT];
+    float cw[GPT][4][8], dg[GPT][4], rb[GPT][4];         // dg == 0 marks a point that is never updated (inactive, or outside the level)
+    int at_[GPT];                                        // LDS index of the group's first point
 #pragma unroll
-    for (int k = 0; k < PPT; k++) {
-        const int i = tid + k * 1024;
-        const int ly = i / EW, lx = i % EW, y = oy + ly, x = ox + lx;
-        const bool in = i < EW * EH && y >= 0 && y < s.rows && x >= 0 && x < s.cols;
-        at_[k] = in ? (ly + 1) * LP + lx + 1 : 0;
-        col[k] = in ? (y & 1) * 2 + (x & 1) : -1;
-        dg[k] = in ? s.D[(size_t)y * s.pitch + x] : 0.0f;
-        rb[k] = in ? b[(size_t)y * s.pitch + x] : 0.0f;
-        if (in) le[at_[k]] = e[(size_t)y * s.pitch + x];
-        cw[k][0] = coupling(s, y, x, 0, -1); cw[k][1] = coupling(s, y, x, 0, 1); cw[k][2] = coupling(s, y, x, -1, 0); cw[k][3] = coupling(s, y, x, 1, 0);
-        cw[k][4] = coupling(s, y, x, -1, -1); cw[k][5] = coupling(s, y, x, -1, 1); cw[k][6] = coupling(s, y, x, 1, -1); cw[k][7] = coupling(s, y, x, 1, 1);
-        if (!(dg[k] > 0.0f)) col[k] = -1;
+    for (int k = 0; k < GPT; k++) {
+        const int gi = tid + k * kTileThreads;
+        const int ly = gi / GW, lx = 4 * (gi % GW), y = oy + ly, x0 = ox + lx;
+        const bool row = gi < GW * EH && y >= 0 && y < s.rows && x0 >= 0 && x0 < s.cols;     // x0 and the pitch are multiples of 4: the 16-byte loads stay inside the row
+        at_[k] = gi < GW * EH ? (ly + 1) * LP + lx + 1 : LP + 1;
+        const f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        f4 vd = z, vb = z, ve = z, pe = z, ps = z, pse = z, psw = z;
+        if (row) {
+            const size_t q = (size_t)y * s.pitch + x0;
+            pe = *(const f4 *)(s.E + q); ps = *(const f4 *)(s.S + q); pse = *(const f4 *)(s.SE + q); psw = *(const f4 *)(s.SW + q);
+            vd = *(const f4 *)(s.D + q); vb = *(const f4 *)(b + q); ve = *(const f4 *)(e + q);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool in = row && x0 + j < s.cols;
+            dg[k][j] = in ? vd[j] : 0.0f;
+            rb[k][j] = in ? vb[j] : 0.0f;
+            if (in) le[at_[k] + j] = ve[j];
+            cw[k][j][1] = in ? pe[j] : 0.0f; cw[k][j][3] = in ? ps[j] : 0.0f;                 // the point's own couplings: E, S, ...
+            cw[k][j][7] = in ? pse[j] : 0.0f; cw[k][j][6] = in ? psw[j] : 0.0f;               // ... SE, SW
+        }
+        if (gi < GW * EH) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { st0[at_[k] + j] = cw[k][j][1]; st1[at_[k] + j] = cw[k][j][3]; }
+        }
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GPT; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cw[k][j][0] = st0[at_[k] + j - 1]; cw[k][j][2] = st1[at_[k] + j - LP]; }        // W = left point's E, N = upper point's S
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GPT; k++)
+        if (tid + k * kTileThreads < GW * EH) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { st0[at_[k] + j] = cw[k][j][7]; st1[at_[k] + j] = cw[k][j][6]; }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GPT; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cw[k][j][4] = st0[at_[k] + j - LP - 1]; cw[k][j][5] = st1[at_[k] + j - LP + 1]; }   // NW = upper-left point's SE, NE = upper-right point's SW
+    // (le was complete before the first barrier above; no thread writes it before the loop below)
     for (int sw = 0; sw < nsweeps; sw++)
         for (int c = 0; c < 4; c++) {
             const int colour = reverse ? 3 - c : c;
 #pragma unroll
-            for (int k = 0; k < PPT; k++)
-                if (col[k] == colour) {
-                    const int a = at_[k];
-                    float v = rb[k];
-                    v += cw[k][0] * le[a - 1];
-                    v += cw[k][1] * le[a + 1];
-                    v += cw[k][2] * le[a - LP];
-                    v += cw[k][3] * le[a + LP];
-                    v += cw[k][4] * le[a - LP - 1];
-                    v += cw[k][5] * le[a - LP + 1];
-                    v += cw[k][6] * le[a + LP - 1];
-                    v += cw[k][7] * le[a + LP + 1];
-                    le[a] = v / dg[k];
+            for (int k = 0; k < GPT; k++) {
+                const int gi = tid + k * kTileThreads;
+                const int ly = gi / GW, y = oy + ly;
+                if ((y & 1) != (colour >> 1)) continue;                       // this row has no point of the colour
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    // x0 is a multiple of 4, so point j of a group has x parity j & 1
+                    if ((j & 1) != (colour & 1) || !(dg[k][j] > 0.0f)) continue;
+                    const int a = at_[k] + j;
+                    float v = rb[k][j];
+                    v += cw[k][j][0] * le[a - 1];
+                    v += cw[k][j][1] * le[a + 1];
+                    v += cw[k][j][2] * le[a - LP];
+                    v += cw[k][j][3] * le[a + LP];
+                    v += cw[k][j][4] * le[a - LP - 1];
+                    v += cw[k][j][5] * le[a - LP + 1];
+                    v += cw[k][j][6] * le[a + LP - 1];
+                    v += cw[k][j][7] * le[a + LP + 1];
+                    le[a] = v / dg[k][j];
                 }
+            }
             __syncthreads();
         }
 #pragma unroll
-    for (int k = 0; k < PPT; k++) {
-        const int i = tid + k * 1024;
-        const int ly = i / EW, lx = i % EW, y = oy + ly, x = ox + lx;
-        if (i < EW * EH && ly >= H && ly < H + kTileY && lx >= H && lx < H + kTileX && y < s.rows && x < s.cols) out[(size_t)y * s.pitch + x] = le[at_[k]];
+    for (int k = 0; k < GPT; k++) {
+        const int gi = tid + k * kTileThreads;
+        const int ly = gi / GW, lx = 4 * (gi % GW), y = oy + ly, x0 = ox + lx;
+        if (gi < GW * EH && ly >= H && ly < H + kTileY && lx >= H && lx < H + kTileX && y < s.rows) {
+            float *o = out + (size_t)y * s.pitch + x0;
+            if (x0 + 3 < s.cols) { const f4 v = {le[at_[k]], le[at_[k] + 1], le[at_[k] + 2], le[at_[k] + 3]}; *(f4 *)o = v; }
+            else for (int j = 0; j < 4; j++) if (x0 + j < s.cols) o[j] = le[at_[k] + j];
+        }
     }
 }
 
@@ -504,11 +555,11 @@ static void mg_smooth(rtdd_ctx *ctx, MgLevel &l, int nsweeps, bool reverse, int 
         (*launches)++;
         return;
     }
-    if (nsweeps <= 2) {                                   // (64 + 16) x (32 + 16) extended points = 4 per thread
+    if (nsweeps <= 2) {                                   // (64 + 16) x (32 + 16) extended points = 960 groups of 4: two per thread
         const int H = 4 * nsweeps;
-        const size_t lds = (size_t)(kTileX + 2 * H + 2) * (kTileY + 2 * H + 2) * sizeof(float);
+        const size_t lds = 3 * (size_t)(kTileX + 2 * H + 2) * (kTileY + 2 * H + 2) * sizeof(float);       // the iterate + two staging planes
         const dim3 g((l.cols + kTileX - 1) / kTileX, (l.rows + kTileY - 1) / kTileY);
-        hipLaunchKernelGGL(k_mg_gs_tile, g, dim3(1024), lds, ctx->stream, view(l), l.e(), l.r(), l.b(), nsweeps, reverse ? 1 : 0);
+        hipLaunchKernelGGL(k_mg_gs_tile, g, dim3(kTileThreads), lds, ctx->stream, view(l), l.e(), l.r(), l.b(), nsweeps, reverse ? 1 : 0);
         const int t = l.ei; l.ei = l.ri; l.ri = t;        // the result is in what was r's plane
         (*launches)++;
         return;
