@@ -302,10 +302,10 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
         constexpr bool FAST = decltype(fast)::value;
         constexpr int buf = decltype(parity)::value;         // = s & 1
         RTDD_TL(0, s);
-        await(s);
         // The first / last thread row of the tile has no row above / below in LDS: it reads its OWN published row instead (any
         // finite value will do -- the weight towards it is 0 at the image border, and elsewhere that row is discarded halo), which
         // keeps the two loads unconditional: no lane masks, no zero-filling moves.
+        await(s);
         const float4 up4 = edge[buf][tr > 0 ? tr - 1 : 0][tr > 0 ? 1 : 0][lx];
         const float4 dn4 = edge[buf][tr < ntr - 1 ? tr + 1 : tr][tr < ntr - 1 ? 0 : 1][lx];
         const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
