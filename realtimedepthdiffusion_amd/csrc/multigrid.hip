@@ -450,19 +450,40 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_mg_gs_tile(Stencil s, const
     }
 }
 
-// b_c = P^T r, and the coarse correction starts from zero
-__global__ __launch_bounds__(256) void k_mg_restrict(const float *R, Interp ip, int frows, int fcols, int fpitch, float *bc, float *ec, int crows, int ccols, int cpitch) {
-    const int J = blockIdx.x * 64 + (threadIdx.x & 63), I = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (J >= ccols || I >= crows) return;
-    float acc = 0.0f;
-    for (int py = -1; py <= 1; py++)
-        for (int px = -1; px <= 1; px++) {
-            const int y = 2 * I + py, x = 2 * J + px;
-            const float wp = pweight(ip, fpitch, frows, fcols, y, x, I, J);
-            if (wp != 0.0f) acc += wp * R[(size_t)y * fpitch + x];
-        }
-    bc[(size_t)I * cpitch + J] = acc;
-    ec[(size_t)I * cpitch + J] = 0.0f;
+// b_c = P^T r, and the coarse correction starts from zero.  TWO coarse points (I, J0), (I, J0 + 1), J0 even, per thread: their
+// 3 x 5 fine points start at the 16-byte aligned column 2 J0, so every fine row is one 16-byte load plus the scalar to its left
+// for r and for each weight plane it needs -- 15 mostly 16-byte loads for two points instead of 36 strided scalar ones.
+// Which plane holds the weight of fine point (y, x) towards (I, J) (pweight): rows 2I and 2I+1 lie in coarse row I (planes P0/P1),
+// row 2I-1 in coarse row I-1 (P2/P3); columns 2J and 2J+1 in coarse column J (even planes), column 2J-1 in column J-1 (odd planes).
+// Terms are added in the order of the plain loops (py, then px), a zero weight adds nothing -- as the restatement does.
+__global__ __launch_bounds__(256) void k_mg_restrict(const float *__restrict__ R, Interp ip, int frows, int fcols, int fpitch, float *bc, float *ec, int crows, int ccols, int cpitch) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int J0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), I = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (J0 >= ccols || I >= crows) return;
+    const int x0 = 2 * J0;                                         // < fcols, a multiple of 4: the 16-byte loads stay inside the row
+    float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+    for (int py = -1; py <= 1; py++) {
+        const int y = 2 * I + py;
+        if (y < 0 || y >= frows) continue;
+        const size_t q = (size_t)y * fpitch + x0;
+        const f4 r4 = *(const f4 *)(R + q);
+        const f4 we = *(const f4 *)((py < 0 ? ip.P2 : ip.P0) + q);      // towards the coarse column of an even fine column
+        const f4 wo = *(const f4 *)((py < 0 ? ip.P3 : ip.P1) + q);      // ... of the odd fine column to its right: only [1] (column x0+1 -> J0+1) is used
+        const bool left = x0 > 0;
+        const float rl = left ? R[q - 1] : 0.0f, wl = left ? (py < 0 ? ip.P3 : ip.P1)[q - 1] : 0.0f;      // column x0-1 -> J0
+        // coarse point J0: fine columns x0-1, x0, x0+1
+        if (wl != 0.0f) acc0 += wl * rl;
+        if (we[0] != 0.0f) acc0 += we[0] * r4[0];
+        if (x0 + 1 < fcols && we[1] != 0.0f) acc0 += we[1] * r4[1];
+        // coarse point J0+1: fine columns x0+1, x0+2, x0+3
+        if (x0 + 1 < fcols && wo[1] != 0.0f) acc1 += wo[1] * r4[1];
+        if (x0 + 2 < fcols && we[2] != 0.0f) acc1 += we[2] * r4[2];
+        if (x0 + 3 < fcols && we[3] != 0.0f) acc1 += we[3] * r4[3];
+    }
+    const size_t o = (size_t)I * cpitch + J0;
+    bc[o] = acc0; ec[o] = 0.0f;
+    if (J0 + 1 < ccols) { bc[o + 1] = acc1; ec[o + 1] = 0.0f; }
 }
 
 // target += P e_c
@@ -592,7 +613,7 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     (*launches)++;
     for (int l = 0; l < last; l++) {                    // down
         MgLevel &f = lv[l], &c = lv[l + 1];
-        hipLaunchKernelGGL(k_mg_restrict, grid_for(c.rows, c.cols), dim3(256), 0, ctx->stream, f.r(), interp(f), f.rows, f.cols, f.pitch, c.b(), c.e(), c.rows, c.cols, c.pitch);
+        hipLaunchKernelGGL(k_mg_restrict, grid_for(c.rows, (c.cols + 1) / 2), dim3(256), 0, ctx->stream, f.r(), interp(f), f.rows, f.cols, f.pitch, c.b(), c.e(), c.rows, c.cols, c.pitch);
         (*launches)++;
         if (l + 1 == last) { mg_smooth(ctx, c, kCoarsestSweeps, false, launches); break; }
         mg_smooth(ctx, c, kNu, false, launches);
