@@ -486,17 +486,30 @@ __global__ __launch_bounds__(256) void k_mg_restrict(const float *__restrict__ R
     if (J0 + 1 < ccols) { bc[o + 1] = acc1; ec[o + 1] = 0.0f; }
 }
 
-// target += P e_c
-__global__ __launch_bounds__(256) void k_mg_prolong(const float *ec, int crows, int ccols, int cpitch, Interp ip, int frows, int fcols, int fpitch, float *T, int tpitch) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= fcols || y >= frows) return;
-    const size_t q = (size_t)y * fpitch + x;
-    const int I = y >> 1, J = x >> 1;
-    float v = ip.P0[q] * at(ec, cpitch, crows, ccols, I, J);
-    v += ip.P1[q] * at(ec, cpitch, crows, ccols, I, J + 1);
-    v += ip.P2[q] * at(ec, cpitch, crows, ccols, I + 1, J);
-    v += ip.P3[q] * at(ec, cpitch, crows, ccols, I + 1, J + 1);
-    T[(size_t)y * tpitch + x] += v;
+// target += P e_c; four fine points per thread (16-byte loads of the four weight planes and of the target row)
+__global__ __launch_bounds__(256) void k_mg_prolong(const float *__restrict__ ec, int crows, int ccols, int cpitch, Interp ip, int frows, int fcols, int fpitch, float *T, int tpitch) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= fcols || y >= frows) return;
+    const size_t q = (size_t)y * fpitch + x0;
+    const f4 p0 = *(const f4 *)(ip.P0 + q), p1 = *(const f4 *)(ip.P1 + q), p2 = *(const f4 *)(ip.P2 + q), p3 = *(const f4 *)(ip.P3 + q);
+    const int I = y >> 1, J = x0 >> 1;
+    float c0[3], c1[3];                                            // e_c at (I, J..J+2) and (I+1, J..J+2)
+#pragma unroll
+    for (int k = 0; k < 3; k++) { c0[k] = at(ec, cpitch, crows, ccols, I, J + k); c1[k] = at(ec, cpitch, crows, ccols, I + 1, J + k); }
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int k = j >> 1;                                      // fine column x0 + j lies in coarse column J + k
+        float t = p0[j] * c0[k];
+        t += p1[j] * c0[k + 1];
+        t += p2[j] * c1[k];
+        t += p3[j] * c1[k + 1];
+        v[j] = t;
+    }
+    float *o = T + (size_t)y * tpitch + x0;
+    if (x0 + 3 < fcols) { f4 t4 = *(f4 *)o; t4[0] += v[0]; t4[1] += v[1]; t4[2] += v[2]; t4[3] += v[3]; *(f4 *)o = t4; }
+    else for (int j = 0; j < 4; j++) if (x0 + j < fcols) o[j] += v[j];
 }
 
 // x <- clamp(x + alpha (x - x_prev)): removes an error component that shrinks by lambda = alpha / (1 + alpha) per cycle
@@ -622,11 +635,11 @@ static int mg_vcycle(rtdd_ctx *ctx, const Level &L0, size_t ip, int rows, int co
     }
     for (int l = last - 1; l >= 1; l--) {                // up
         MgLevel &f = lv[l], &c = lv[l + 1];
-        hipLaunchKernelGGL(k_mg_prolong, grid_for(f.rows, f.cols), dim3(256), 0, ctx->stream, c.e(), c.rows, c.cols, c.pitch, interp(f), f.rows, f.cols, f.pitch, f.e(), f.pitch);
+        hipLaunchKernelGGL(k_mg_prolong, grid_for(f.rows, (f.cols + 3) / 4), dim3(256), 0, ctx->stream, c.e(), c.rows, c.cols, c.pitch, interp(f), f.rows, f.cols, f.pitch, f.e(), f.pitch);
         (*launches)++;
         mg_smooth(ctx, f, kNu, true, launches);
     }
-    hipLaunchKernelGGL(k_mg_prolong, grid_for(rows, cols), dim3(256), 0, ctx->stream, lv[1].e(), lv[1].rows, lv[1].cols, lv[1].pitch, interp(lv[0]), rows, cols, lv[0].pitch,
+    hipLaunchKernelGGL(k_mg_prolong, grid_for(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, lv[1].e(), lv[1].rows, lv[1].cols, lv[1].pitch, interp(lv[0]), rows, cols, lv[0].pitch,
                        L0.P(*plane, ip), (int)ip);
     (*launches)++;
     RTDD_LAUNCH_CHECK(ctx, "multigrid cycle");
