@@ -66,6 +66,71 @@ __global__ __launch_bounds__(256) void k_prepare(const float *__restrict__ depth
     M[p] = (uint32_t)right | ((uint32_t)down << 8) | (dirichlet ? kMetaDirichlet : 0u);
 }
 
+// The same pass, four pixels per thread, for callers whose rows are 16-byte (depth) / 4-byte (gray, scribble) aligned -- what
+// cudaMallocPitch-style allocations give: one 16-byte load per depth row, one 4-byte load per u8 row, 16-byte stores of the three
+// planes.  A group that would run past the end of a row falls back to the scalar form above, pixel by pixel.
+__global__ __launch_bounds__(256) void k_prepare4(const float *__restrict__ depth, size_t depthPitch,
+                                                  const uint8_t *__restrict__ scribble, size_t scribblePitch,
+                                                  const uint8_t *__restrict__ gray, size_t grayPitch,
+                                                  float *__restrict__ X0, float *__restrict__ X1,
+                                                  uint32_t *__restrict__ M, int ip, int rows, int cols, int gated, int thr) {
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= cols || y >= rows) return;
+    const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
+    const uint8_t *grow = gray + (size_t)y * grayPitch, *srow = scribble + (size_t)y * scribblePitch;
+    const bool down_ok = y + 1 < rows;
+    float d[5], dd[4];
+    int g[5], gd[4];
+    uint32_t sc;
+    if (x0 + 3 < cols) {
+        const float4 d4 = *(const float4 *)(drow + x0);
+        d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
+        const uint32_t g4 = *(const uint32_t *)(grow + x0);
+        g[0] = g4 & 255; g[1] = (g4 >> 8) & 255; g[2] = (g4 >> 16) & 255; g[3] = g4 >> 24;
+        sc = *(const uint32_t *)(srow + x0);
+        if (down_ok) {
+            const uint32_t h4 = *(const uint32_t *)(grow + grayPitch + x0);
+            gd[0] = h4 & 255; gd[1] = (h4 >> 8) & 255; gd[2] = (h4 >> 16) & 255; gd[3] = h4 >> 24;
+            if (gated) { const float4 e4 = *(const float4 *)((const float *)((const char *)depth + (size_t)(y + 1) * depthPitch) + x0); dd[0] = e4.x; dd[1] = e4.y; dd[2] = e4.z; dd[3] = e4.w; }
+        }
+    } else {                                       // ragged end of the row
+        sc = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool in = x0 + i < cols;
+            d[i] = in ? drow[x0 + i] : 0.0f; g[i] = in ? grow[x0 + i] : 0;
+            sc |= (uint32_t)(in ? srow[x0 + i] : 0) << (8 * i);
+            gd[i] = in && down_ok ? grow[x0 + i + grayPitch] : 0;
+            dd[i] = in && down_ok && gated ? ((const float *)((const char *)depth + (size_t)(y + 1) * depthPitch))[x0 + i] : 0.0f;
+        }
+    }
+    const bool right_ok = x0 + 4 < cols;
+    d[4] = right_ok ? drow[x0 + 4] : 0.0f; g[4] = right_ok ? grow[x0 + 4] : 0;
+    float x0v[4], x1v[4];
+    uint32_t mv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool dirichlet = ((sc >> (8 * i)) & 255) == 255;
+        int right = 0, down = 0;
+        if (x0 + i + 1 < cols) {
+            right = iabs(g[i] - g[i + 1]);
+            if (gated && !(iabs(sat_u8_dev(d[i]) - sat_u8_dev(d[i + 1])) > thr)) right = 0;
+        }
+        if (down_ok) {
+            down = iabs(g[i] - gd[i]);
+            if (gated && !(iabs(sat_u8_dev(d[i]) - sat_u8_dev(dd[i])) > thr)) down = 0;
+        }
+        x0v[i] = d[i];
+        x1v[i] = dirichlet ? d[i] : 0.0f;
+        mv[i] = (uint32_t)right | ((uint32_t)down << 8) | (dirichlet ? kMetaDirichlet : 0u);
+    }
+    const size_t p = (size_t)y * ip + x0;          // the planes' rows are 256-byte aligned and padded: whole 16-byte stores always fit; columns >= cols are never read as pixels
+    *(float4 *)(X0 + p) = make_float4(x0v[0], x0v[1], x0v[2], x0v[3]);
+    *(float4 *)(X1 + p) = make_float4(x1v[0], x1v[1], x1v[2], x1v[3]);
+    *(uint4 *)(M + p) = make_uint4(mv[0], mv[1], mv[2], mv[3]);
+}
+
 // The reference's own index format, for parity tests of the weight pass (src/GPUSolver.cu:136-224).
 __global__ __launch_bounds__(256) void k_index_to_weight(const uint8_t *__restrict__ gray, size_t grayPitch,
                                                          const float *__restrict__ depth, size_t depthPitch,
@@ -205,6 +270,18 @@ __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int
     ((float *)((char *)depth + (size_t)y * depthPitch))[x] = X[(size_t)y * ip + x];
 }
 
+// four pixels per thread when the caller's rows are 16-byte aligned (a group past the end of the row: pixel by pixel)
+__global__ __launch_bounds__(256) void k_finish4(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
+                                                 int rows, int cols) {
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= cols || y >= rows) return;
+    const float4 v = *(const float4 *)(X + (size_t)y * ip + x0);
+    float *o = (float *)((char *)depth + (size_t)y * depthPitch) + x0;
+    if (x0 + 3 < cols) *(float4 *)o = v;
+    else { const float t[4] = {v.x, v.y, v.z, v.w}; for (int i = 0; i < 4; i++) if (x0 + i < cols) o[i] = t[i]; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Extensions (no reference behaviour): residual max|J(x)-x| and red-black Gauss-Seidel.
 // ------------------------------------------------------------------------------------------------
@@ -295,8 +372,14 @@ int launch_prepare(rtdd_ctx *ctx, const Level &L, size_t ip, const float *depth,
                    int rows, int cols, int level) {
     const int gated = level != ctx->maxLevel;
     const int thr = level == 0 ? 0 : 4;
-    hipLaunchKernelGGL(k_prepare, grid64x4(rows, cols), dim3(256), 0, ctx->stream, depth, depthPitch, scribble, scribblePitch,
-                       gray, grayPitch, L.P(0, ip), L.P(1, ip), L.M(ip), (int)ip, rows, cols, gated, thr);
+    const bool aligned = ((uintptr_t)depth % 16 == 0) && depthPitch % 16 == 0 && ((uintptr_t)gray % 4 == 0) && grayPitch % 4 == 0 &&
+                         ((uintptr_t)scribble % 4 == 0) && scribblePitch % 4 == 0;
+    if (aligned)
+        hipLaunchKernelGGL(k_prepare4, grid64x4(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, depth, depthPitch, scribble, scribblePitch,
+                           gray, grayPitch, L.P(0, ip), L.P(1, ip), L.M(ip), (int)ip, rows, cols, gated, thr);
+    else
+        hipLaunchKernelGGL(k_prepare, grid64x4(rows, cols), dim3(256), 0, ctx->stream, depth, depthPitch, scribble, scribblePitch,
+                           gray, grayPitch, L.P(0, ip), L.P(1, ip), L.M(ip), (int)ip, rows, cols, gated, thr);
     RTDD_LAUNCH_CHECK(ctx, "k_prepare");
     return RTDD_OK;
 }
@@ -346,7 +429,10 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
 }
 
 int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols) {
-    hipLaunchKernelGGL(k_finish, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols);
+    if ((uintptr_t)depth % 16 == 0 && depthPitch % 16 == 0)
+        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols);
+    else
+        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols);
     RTDD_LAUNCH_CHECK(ctx, "k_finish");
     return RTDD_OK;
 }
