@@ -11,13 +11,17 @@ d = f"gpurun_out/prof_{rnd}_{wl}"
 SIMDS, CLOCK = 256 * 4, 2.4e9
 
 
+def kname(full):
+    return full.replace("(anonymous namespace)::", "").split("(")[0]
+
+
 def per_kernel(prefix):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
     f = f"{d}/{prefix}_counter_collection.csv"
     if not os.path.exists(f):
         return {}
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = kname(r["Kernel_Name"])
         if "rtdd::" not in k:
             continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
@@ -29,7 +33,7 @@ def durations(prefix):
     f = f"{d}/{prefix}_kernel_trace.csv"
     if os.path.exists(f):
         for r in csv.DictReader(open(f)):
-            out[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+            out[kname(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
     return out
 
 

@@ -14,7 +14,7 @@ for p1 in sorted(glob.glob(os.path.join(d, "*_p1_counter_collection.csv"))):
         if not os.path.exists(f):
             continue
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             if "rtdd::" not in k:
                 continue
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -23,7 +23,7 @@ for p1 in sorted(glob.glob(os.path.join(d, "*_p1_counter_collection.csv"))):
     kt = p1.replace("_counter_collection", "_kernel_trace")
     if os.path.exists(kt):
         for r in csv.DictReader(open(kt)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
     run = {}
     for k, v in acc.items():
