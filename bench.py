@@ -388,9 +388,15 @@ def main():
             prof = json.load(open(os.path.join(ROOT, "profiles", "counters_latest.json")))
             k = prof.get(args.workload if not (args.sweep_kernel or args.tile or args.temporal_depth or args.persistent >= 0 or args.method) else "", {})
             if k:
-                out["roofline"]["traffic"] = k.get("hbm_bytes_per_launch_corrected")
-                if k.get("hbm_bytes_per_launch_corrected") and launch_us > 0:
-                    out["roofline"]["hbm_counter_frac"] = k["hbm_bytes_per_launch_corrected"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                if method == "multigrid":       # a chain of kernels: all of them together, per solve (setup + cycles + residual checks)
+                    out["roofline"]["traffic"] = k.get("hbm_bytes_per_solve_all_kernels_corrected")
+                    out["roofline"]["traffic_is"] = "HBM-side bytes of ALL kernels of one solve"
+                    if k.get("kernel_ms_per_solve_clean_trace"):
+                        out["roofline"]["hbm_counter_frac"] = k["hbm_bytes_per_solve_all_kernels_corrected"] / (k["kernel_ms_per_solve_clean_trace"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                else:
+                    out["roofline"]["traffic"] = k.get("hbm_bytes_per_launch_corrected")
+                    if k.get("hbm_bytes_per_launch_corrected") and launch_us > 0:
+                        out["roofline"]["hbm_counter_frac"] = k["hbm_bytes_per_launch_corrected"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS
                 if k.get("valu_issue_frac_counted") is not None:
                     out["roofline"]["valu_issue_frac_counted"] = k["valu_issue_frac_counted"]      # SQ_INSTS_VALU x 2 cycles / (duration x 1024 SIMDs x 2.4 GHz): includes halo redundancy
                 out["roofline"]["counters_source"] = k.get("source")

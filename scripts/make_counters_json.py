@@ -15,8 +15,12 @@ def kname(full):
     return full.replace("(anonymous namespace)::", "").split("(")[0]
 
 
+TOTALS = {}          # prefix -> counter -> sum over every rtdd kernel launch of the pass
+
+
 def per_kernel(prefix):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
+    TOTALS[prefix] = collections.defaultdict(float)
     f = f"{d}/{prefix}_counter_collection.csv"
     if not os.path.exists(f):
         return {}
@@ -25,6 +29,7 @@ def per_kernel(prefix):
         if "rtdd::" not in k:
             continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
+        TOTALS[prefix][r["Counter_Name"]] += float(r["Counter_Value"])
     return {k: {c: v / len(disp[(k, c)]) for c, v in cs.items()} for k, cs in acc.items()}
 
 
@@ -82,7 +87,12 @@ open(f"profiles/{rnd}_{wl}_kernel_stats.csv", "w").write("\n".join(l[:420] for l
 dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
 latest_path = "profiles/counters_latest.json"
 latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
-latest[wl] = {"kernel": dom, "source": f"profiles/{rnd}_{wl}_counters.json", "mean_duration_us": kernels[dom]["mean_duration_us"],
+SOLVES_IN_COUNTER_PASS = 4          # --steps 3 --warmup 1
+all_bytes = (2 * TOTALS.get("fetch", {}).get("FETCH_SIZE", 0.0) + TOTALS.get("write", {}).get("WRITE_SIZE", 0.0)) * 1024 / SOLVES_IN_COUNTER_PASS
+summary["hbm_bytes_per_solve_all_kernels_corrected"] = all_bytes
+summary["kernel_ms_per_solve_clean_trace"] = sum(k["total_ms"] for k in kernels.values()) / 25.0      # --steps 20 --warmup 5
+json.dump(summary, open(f"profiles/{rnd}_{wl}_counters.json", "w"), indent=1)
+latest[wl] = {"hbm_bytes_per_solve_all_kernels_corrected": all_bytes, "kernel_ms_per_solve_clean_trace": summary["kernel_ms_per_solve_clean_trace"], "kernel": dom, "source": f"profiles/{rnd}_{wl}_counters.json", "mean_duration_us": kernels[dom]["mean_duration_us"],
               "hbm_bytes_per_launch_corrected": kernels[dom].get("hbm_bytes_per_launch_corrected"), "valu_issue_frac_counted": kernels[dom].get("valu_issue_frac_counted")}
 json.dump(latest, open(latest_path, "w"), indent=1)
 print(dom, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in kernels[dom].items() if k != "sq_per_launch"})
