@@ -608,10 +608,14 @@ static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fi
         fprintf(stderr, "[rtdd] %dx%d n=%d -> tile %d depth %d persistent %d (model %.3f us/sweep)\n", cols, rows, n, *tile, *T, (int)*persist, best);
 }
 
+#ifdef RTDD_EXP_ONE_TILE   // (compile-time experiments: -DRTDD_EXP_ONE_TILE='RTDD_TILE_CASE(4, 32, 1024, 3)' builds one instantiation in seconds)
+#define RTDD_ALL_TILES RTDD_EXP_ONE_TILE
+#else
 #define RTDD_ALL_TILES \
     RTDD_TILE_CASE(1, 16, 256, 4) RTDD_TILE_CASE(2, 32, 512, 4) RTDD_TILE_CASE(3, 32, 1024, 4) RTDD_TILE_CASE(4, 32, 1024, 3) RTDD_TILE_CASE(5, 32, 512, 3) \
     RTDD_TILE_CASE(6, 16, 512, 3) RTDD_TILE_CASE(7, 16, 256, 3) RTDD_TILE_CASE(8, 32, 1024, 2) RTDD_TILE_CASE(9, 16, 1024, 1) RTDD_TILE_CASE(10, 16, 512, 2) \
     RTDD_TILE_CASE(11, 32, 1024, 1) RTDD_TILE_CASE(12, 32, 768, 4) RTDD_TILE_CASE(13, 32, 512, 6)
+#endif
 
 // Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
 // holding x_{k+n} / x_{k+n-1}.  omegas_dev[0..n) must already be on the device.
