@@ -194,6 +194,7 @@ def effects(rt, dev):
         c.set_stream(torch.cuda.current_stream().cuda_stream)
         c.GPULoadWeights(0.4); c.GPUAllocateDeviceMemory(rows, cols, 1)
         o, g, d, m = (rt.device_image(x, dev) for x in (orig, p["gray"], depth, p["mask"]))
+        d_smooth = rt.device_image(p["gray"].astype(np.float32), dev)      # a piecewise-smooth depth map (value noise + rectangles), like a solved one
         art = rt.device_image(np.zeros_like(orig), dev)
         px = rows * cols
 
@@ -208,7 +209,9 @@ def effects(rt, dev):
         res = {}
         for what, bpp, f in (("desaturation", 11, lambda: c.GPUSimulateDesaturation(o, g, d, art, rows, cols)),
                              ("haze", 10, lambda: c.GPUSimulateHaze(o, d, art, rows, cols)),
-                             ("defocus", 10, lambda: c.GPUSimulateDefocus(o, d, art, rows, cols)),
+                             ("defocus", 10, lambda: c.GPUSimulateDefocus(o, d_smooth, art, rows, cols)),
+                             # per-pixel random depth: every window size side by side, no coherence between neighbouring lookups (the worst case)
+                             ("defocus_random_depth", 10, lambda: c.GPUSimulateDefocus(o, d, art, rows, cols)),
                              ("prepare_and_finish", 17, lambda: c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 0, 0, 0))):
             t = timeit(f)
             res[what] = {"us": t * 1e6, "algorithmic_GBs": px * bpp / t / 1e9, "bytes_per_pixel": bpp, "frac_of_hbm_peak": px * bpp / t / 1e9 / HBM_PEAK_GBS}

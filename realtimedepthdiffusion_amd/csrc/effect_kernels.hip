@@ -119,44 +119,69 @@ struct u3 { uint32_t x, y, z; };                                    // 12-byte t
 __device__ __forceinline__ u3 ld3(const u3 *p) { return *p; }
 __device__ __forceinline__ void st3(u3 *p, uint32_t a, uint32_t b, uint32_t c) { u3 v; v.x = a; v.y = b; v.z = c; *p = v; }
 
+// inclusive prefix sum over the 64 lanes of a wave: the 7-step DPP scan (3 row shifts of the input, row_shr:4 / :8 under bank
+// masks, row_bcast:15 / :31 under row masks) -- VALU only, no LDS crossbar
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o); if ((int)(threadIdx.x & 63) >= o) v += t; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+#define RTDD_DPP(src, ctrl, rows, banks) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(src), ctrl, rows, banks, true)
+    uint32_t t = v + RTDD_DPP(v, 0x111, 0xF, 0xF);      // row_shr:1
+    t += RTDD_DPP(v, 0x112, 0xF, 0xF);                  // row_shr:2
+    t += RTDD_DPP(v, 0x113, 0xF, 0xF);                  // row_shr:3   -> v[i-3..i] within a row of 16
+    t += RTDD_DPP(t, 0x114, 0xF, 0xE);                  // row_shr:4, banks 1-3
+    t += RTDD_DPP(t, 0x118, 0xF, 0xC);                  // row_shr:8, banks 2-3  -> prefix within each row of 16
+    t += RTDD_DPP(t, 0x142, 0xA, 0xF);                  // row_bcast:15 into rows 1 and 3
+    t += RTDD_DPP(t, 0x143, 0xC, 0xF);                  // row_bcast:31 into rows 2 and 3
+#undef RTDD_DPP
+    return t;
 }
 
-// pass 1: row-wise inclusive prefix of image row y into L[y+1][1..].  Each of the 4 waves owns a contiguous
-// quarter of the row and walks it 64 pixels at a time with lane = pixel, so the 3-byte loads and the 12-byte
-// stores of a wave are contiguous; quarter totals go through LDS once.
-__global__ __launch_bounds__(256) void k_sat_rows(const uint8_t *__restrict__ orig, size_t op, u3 *__restrict__ L, int rows, int cols) {
-    __shared__ uint32_t qsum[4][3];
-    const int y = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int q = ((cols + 3) / 4 + 63) / 64 * 64;                  // quarter length, a multiple of 64
-    const int xa = min(w * q, cols), xb = min(xa + q, cols);
+// pass 1: row-wise inclusive prefix of image row y into L[y+1][1..].  One workgroup per row, one wave per 512-pixel segment (4 waves
+// at 1080p, 8 at 4K, 16 at 8K; wider rows loop).  A wave loads its whole segment at once -- 8 groups of 64 pixels, lane = pixel,
+// so the 3-byte loads and the 12-byte stores of a wave instruction are contiguous -- runs the 24 independent DPP scans, chains
+// the group totals in scalar registers, trades segment totals through LDS (one barrier) and stores.  One pass over the row, every
+// load in flight together.
+constexpr int kSatGroups = 8;                                       // 64-pixel groups per wave and pass
+__global__ __launch_bounds__(1024) void k_sat_rows(const uint8_t *__restrict__ orig, size_t op, u3 *__restrict__ L, int rows, int cols) {
+    __shared__ uint32_t seg[2][16][3];
+    const int y = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     const uint8_t *o = orig + (size_t)y * op;
-    uint32_t t0 = 0, t1 = 0, t2 = 0;
-    for (int x = xa + lane; x < xb; x += 64) { t0 += o[3 * x]; t1 += o[3 * x + 1]; t2 += o[3 * x + 2]; }
-    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
-    if (lane == 0) { qsum[w][0] = t0; qsum[w][1] = t1; qsum[w][2] = t2; }
-    __syncthreads();
-    uint32_t c0 = 0, c1 = 0, c2 = 0;                                // carry into this quarter
-    for (int k = 0; k < w; k++) { c0 += qsum[k][0]; c1 += qsum[k][1]; c2 += qsum[k][2]; }
     u3 *lrow = L + (size_t)(y + 1) * (cols + 1);
     if (threadIdx.x == 0) st3(lrow, 0, 0, 0);
-    for (int xs = xa; xs < xb; xs += 64) {
-        const int x = xs + lane;
-        uint32_t v0 = 0, v1 = 0, v2 = 0;
-        if (x < xb) { v0 = o[3 * x]; v1 = o[3 * x + 1]; v2 = o[3 * x + 2]; }
-        v0 = wave_incl_scan(v0) + c0; v1 = wave_incl_scan(v1) + c1; v2 = wave_incl_scan(v2) + c2;
-        if (x < xb) st3(lrow + x + 1, v0, v1, v2);
-        c0 = __shfl(v0, 63); c1 = __shfl(v1, 63); c2 = __shfl(v2, 63);
+    uint32_t carry[3] = {0, 0, 0};                                  // everything left of this pass (wave-uniform)
+    int buf = 0;
+    for (int x0 = 0; x0 < cols; x0 += nw * 64 * kSatGroups, buf ^= 1) {
+        const int xs = x0 + w * 64 * kSatGroups + lane;
+        uint32_t v[kSatGroups][3];
+#pragma unroll
+        for (int g = 0; g < kSatGroups; g++) {
+            const int x = xs + 64 * g;
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[g][c] = x < cols ? o[3 * (size_t)x + c] : 0u;
+        }
+        uint32_t run[3] = {0, 0, 0};                                // groups of this wave so far (wave-uniform)
+#pragma unroll
+        for (int g = 0; g < kSatGroups; g++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                v[g][c] = wave_incl_scan(v[g][c]) + run[c];
+                run[c] = (uint32_t)__builtin_amdgcn_readlane((int)v[g][c], 63);
+            }
+        if (lane == 0) { seg[buf][w][0] = run[0]; seg[buf][w][1] = run[1]; seg[buf][w][2] = run[2]; }
+        __syncthreads();                                            // (seg is double buffered: one barrier per pass)
+        uint32_t add[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            uint32_t before = 0, all = 0;
+            for (int k = 0; k < nw; k++) { const uint32_t t = seg[buf][k][c]; all += t; if (k < w) before += t; }
+            add[c] = carry[c] + before;
+            carry[c] += all;
+        }
+#pragma unroll
+        for (int g = 0; g < kSatGroups; g++) {
+            const int x = xs + 64 * g;
+            if (x < cols) st3(lrow + x + 1, v[g][0] + add[0], v[g][1] + add[1], v[g][2] + add[2]);
+        }
     }
-    if (y == 0) for (int i = threadIdx.x; i <= cols; i += 256) st3(L + i, 0, 0, 0);
+    if (y == 0) for (int i = threadIdx.x; i <= cols; i += (int)blockDim.x) st3(L + i, 0, 0, 0);
 }
 
 // pass 2: column prefix inside each band of kBand rows, in place; band totals -> tot[band][c]
@@ -270,7 +295,9 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
     }
     u3 *L = (u3 *)ctx->sat, *base = L + (size_t)(rows + 1) * width;
     const int kernelSize = 0.025 * sqrtf(rows * rows + cols * cols);    // :42, evaluated once on the host (sqrtf is correctly rounded on both)
-    hipLaunchKernelGGL(k_sat_rows, dim3(rows), dim3(256), 0, ctx->stream, orig, op, L, rows, cols);
+    int sat_waves = (cols + 64 * kSatGroups - 1) / (64 * kSatGroups);      // one wave per 512-pixel segment, at most 16
+    if (sat_waves > 16) sat_waves = 16;
+    hipLaunchKernelGGL(k_sat_rows, dim3(rows), dim3(64 * sat_waves), 0, ctx->stream, orig, op, L, rows, cols);
     RTDD_LAUNCH_CHECK(ctx, "k_sat_rows");
     hipLaunchKernelGGL(k_sat_bands, dim3((width + 255) / 256, nbands), dim3(256), 0, ctx->stream, L, base, rows, width);
     RTDD_LAUNCH_CHECK(ctx, "k_sat_bands");
