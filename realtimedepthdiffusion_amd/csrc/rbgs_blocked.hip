@@ -150,8 +150,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
         constexpr int C = decltype(col)::value;
         for (;;) {
             const int f = __hip_atomic_load(&published[flag_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int f0 = __builtin_amdgcn_readlane(f, 0), f1 = __builtin_amdgcn_readlane(f, 1);
-            if ((f0 < f1 ? f0 : f1) >= h + 1) break;
+            if (__builtin_amdgcn_ballot_w64(f < h + 1) == 0) break;      // (one compare and a branch on the lane mask: sweep_blocked.hip)
             __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
