@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
         // (buf = sweep_no & 1, passed separately so that it is a compile-time constant in the unrolled sweep pair: every block
         // starts at an even sweep)
         *(f4r *)&edge[buf][tr][0][lx] = top;
-        *(f4r *)&edge[buf][tr][1][lx] = bottom;
+        if (G > 1) *(f4r *)&edge[buf][tr][1][lx] = bottom;       // (G == 1: one row is both; the readers below take slot 0 -- half the LDS writes of the coarse levels' tile)
         if (!PERSIST) {
             // The LDS serves one wave's accesses in order, so the counter store needs no drained lgkmcnt in front of it: compiler
             // barriers only (+1 % at 4K, -1 % on the estimate).  The persistent instantiation keeps the release store: there the
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 #ifndef RTDD_DIAG_NOPOLL           // (diagnostic ablation, timing only: the LDS reads without the wait for the neighbours' counters)
         await(s);
 #endif
-        const float4 up4 = edge[buf][tr > 0 ? tr - 1 : 0][tr > 0 ? 1 : 0][lx];
-        const float4 dn4 = edge[buf][tr < ntr - 1 ? tr + 1 : tr][tr < ntr - 1 ? 0 : 1][lx];
+        const float4 up4 = edge[buf][tr > 0 ? tr - 1 : 0][G > 1 && tr > 0 ? 1 : 0][lx];
+        const float4 dn4 = edge[buf][tr < ntr - 1 ? tr + 1 : tr][G == 1 || tr < ntr - 1 ? 0 : 1][lx];
 #endif
         const float up[4] = {up4.x, up4.y, up4.z, up4.w}, dn[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
 #ifdef RTDD_TIMELINE
