@@ -564,7 +564,7 @@ static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int ti
     const int G = kTiles[tile].g;
     const int EW = 4 * kTiles[tile].lx, EH = kTiles[tile].nt / kTiles[tile].lx * G;
     const int hx = (T + 3) / 4 * 4, TW = EW - 2 * hx, TH = EH - 2 * T;
-    if (TW < 16 || TH < 8) return 1e30;
+    if (TW < 8 || TH < 8) return 1e30;
     const double nwg = (double)((cols + TW - 1) / TW) * ((rows + TH - 1) / TH);
     const double cus = ctx->num_cus, ext = (double)EW * EH;
     const double lat = 0.25 + 0.28 * G;
@@ -598,7 +598,7 @@ static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int ti
 
 static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fixed_tile, int fixed_T, int *tile, int *T, bool *persist) {
     static const int tiles[] = {4, 8, 9, 6, 5, 7, 12};
-    static const int depths[] = {4, 8, 12, 16, 24};
+    static const int depths[] = {4, 8, 12, 16, 24, 28};
     double best = 1e30;
     *tile = 9; *T = 8; *persist = false;
     for (int ti : tiles) {
@@ -649,7 +649,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
     const int EW = 4 * kTiles[tile].lx, EH = kTiles[tile].nt / kTiles[tile].lx * kTiles[tile].g;
     const bool single = cols <= EW && rows <= EH;
     if (T > 28) T = 28;
-    while (T > 1 && (EW - 2 * ((T + 3) / 4 * 4) < 16 || EH - 2 * T < 8)) T--;   // keep a non-degenerate written-back region
+    while (T > 1 && (EW - 2 * ((T + 3) / 4 * 4) < 8 || EH - 2 * T < 8)) T--;   // keep a non-degenerate written-back region
     int done = 0;
     *launches = 0;
     while (done < n) {
