@@ -492,7 +492,12 @@ __global__ __launch_bounds__(256) void k_mg_prolong(const float *__restrict__ ec
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x0 >= fcols || y >= frows) return;
     const size_t q = (size_t)y * fpitch + x0;
-    const f4 p0 = *(const f4 *)(ip.P0 + q), p1 = *(const f4 *)(ip.P1 + q), p2 = *(const f4 *)(ip.P2 + q), p3 = *(const f4 *)(ip.P3 + q);
+    // A fine point on an EVEN row lies on a coarse row: its weights towards the coarse row below (planes P2, P3) are +0 by
+    // construction (k_mg_build_p) -- those two loads are skipped and the same arithmetic runs on literal zeros.
+    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool odd_row = (y & 1) != 0;                              // (wave-uniform: a wave holds one row)
+    const f4 p0 = *(const f4 *)(ip.P0 + q), p1 = *(const f4 *)(ip.P1 + q);
+    const f4 p2 = odd_row ? *(const f4 *)(ip.P2 + q) : zero4, p3 = odd_row ? *(const f4 *)(ip.P3 + q) : zero4;
     const int I = y >> 1, J = x0 >> 1;
     float c0[3], c1[3];                                            // e_c at (I, J..J+2) and (I+1, J..J+2)
 #pragma unroll
