@@ -218,9 +218,12 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
             wd[g][i] = (in && y + 1 < rows) ? lut[(mv[i] >> 8) & 255] : 0.0f;
             if (in && (mv[i] & kMetaDirichlet)) dirichlet |= 1u << (g * 4 + i);
         }
-        // weight towards the pixel left of the block = the left lane's right-weight of its last pixel
-        const float w = lane_from_prev(wr[g][3]);
-        wl0[g] = (lx > 0 && x0 > 0) ? w : 0.0f;
+        // The right weight of a tile row's LAST pixel becomes 0 (at the image border it is 0 anyway, elsewhere that pixel is discarded
+        // halo): the weight towards the pixel left of a block is then the previous lane's wr[g][3] for EVERY lane (0 for lane 0 by
+        // bound_ctrl, 0 where the previous lane ends another tile row or lies outside the image), and the sweep takes the whole left
+        // term -- weight times value, formed in the previous lane -- through one DPP operand instead of keeping wl0[] in registers.
+        if (lx == LX - 1) wr[g][3] = 0.0f;
+        wl0[g] = lane_from_prev(wr[g][3]);           // (for the divisor below only; +1 % at 1080p: three registers fewer in the 128-register tile)
     }
     {   // weights towards the row above the block: the down-weights of row y0-1
         const int y = y0 - 1;
@@ -338,10 +341,9 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
             const float xr = i == 3 ? xr3[g] : cur[g][i + 1];
             const float xu = g == 0 ? up[i] : cur[g - 1][i];
             const float xd = g == G - 1 ? dn[i] : cur[g + 1][i];
-            const float wl = i == 0 ? wl0[g] : wr[g][i - 1];
             const float wu = g == 0 ? wu0[i] : wd[g - 1][i];
-            float sum = 0.0f;
-            sum = CONTRACT ? __builtin_fmaf(wl, xl, sum) : sum + wl * xl;
+            // xl0[g] holds the previous lane's wr[g][3] * cur[g][3]; RN(wl * xl) + 0 is what fma(wl, xl, 0) and 0 + wl * xl both give
+            float sum = i == 0 ? 0.0f + xl0[g] : (CONTRACT ? __builtin_fmaf(wr[g][i - 1], xl, 0.0f) : 0.0f + wr[g][i - 1] * xl);
             sum = CONTRACT ? __builtin_fmaf(wr[g][i], xr, sum) : sum + wr[g][i] * xr;
             sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
             sum = CONTRACT ? __builtin_fmaf(wd[g][i], xd, sum) : sum + wd[g][i] * xd;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 if (!pick(g)) continue;
-                xl0[g] = lane_from_prev(cur[g][3]); xr3[g] = lane_from_next(cur[g][0]);
+                xl0[g] = lane_from_prev(wr[g][3] * cur[g][3]); xr3[g] = lane_from_next(cur[g][0]);
                 uint32_t t[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
