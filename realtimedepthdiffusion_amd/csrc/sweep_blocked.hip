@@ -510,12 +510,165 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 #endif
 }
 
+// ---- the same sweeps in a COLUMN layout (tile 14): a thread owns 1 pixel x 4 rows --------------------------------------------
+// For the small pyramid levels every sweep is a chain -- counter poll, row reads, arithmetic, publish -- and with one row of 4
+// pixels per thread (tile 9) EVERY row is an edge row: all of a wave's arithmetic sits between its wait and its publish, and each
+// thread moves 16 B out and 32 B in through LDS per sweep.  Here a wave is 64 pixels wide and 4 rows tall: horizontal neighbours are
+// DPP lane shifts, vertical neighbours are the thread's own registers except above row 0 and below row 3, which are ONE float
+// each from LDS (8 B out, 8 B in per thread and sweep), and rows 1 and 2 are computed after the publish, off the neighbours'
+// critical path.  Same geometry as tile 9 (64 x 64 extended tile, up to 16 waves), same arithmetic per pixel, bit-identical.
+template <bool CONTRACT>
+__global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk, const float *__restrict__ Xm, float *__restrict__ Yk, float *__restrict__ Ym,
+                                                    const uint32_t *__restrict__ M, const float *__restrict__ lut_g, const float *__restrict__ omegas,
+                                                    int ip, int rows, int cols, int hx, int hy, int nsweeps, float gamma, int gx, int gy, int xcd_tiles) {
+    constexpr int R = 4;
+    __shared__ float lut[257];
+    __shared__ float2 edge[2][16][64];         // [buffer][wave][lane] = (its top row, its bottom row)
+    __shared__ int published[16];
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (xcd_tiles > 0) {
+        const int t = ((int)blockIdx.x & 7) * xcd_tiles + ((int)blockIdx.x >> 3);
+        if (t >= gx * gy) return;
+        bx = t % gx; by = t / gx;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = (int)blockDim.x >> 6;
+    for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
+    if (tid < 16) published[tid] = 0;
+    __syncthreads();
+    const int eh = R * nwv, TW = 64 - 2 * hx, TH = eh - 2 * hy;
+    const int x = bx * TW - hx + lane, y0 = by * TH - hy + R * wv;
+    const bool colok = x >= 0 && x < cols;
+    float a[R], b[R], wr[R], wd[R], wl[R], cnt[R], rcp[R], wu0;
+    bool dir[R], unsafe = false;
+#pragma unroll
+    for (int g = 0; g < R; g++) {
+        const int y = y0 + g;
+        const bool in = colok && y >= 0 && y < rows;
+        const size_t off = (size_t)(in ? y : 0) * ip + (in ? x : 0);
+        const uint32_t m = in ? M[off] : 0u;
+        a[g] = in ? Xk[off] : 0.0f;
+        b[g] = in ? Xm[off] : 0.0f;
+        wr[g] = (in && x + 1 < cols) ? lut[m & 255] : 0.0f;
+        wd[g] = (in && y + 1 < rows) ? lut[(m >> 8) & 255] : 0.0f;
+        dir[g] = in && (m & kMetaDirichlet);
+        wl[g] = lane_from_prev(wr[g]);           // 0 for lane 0 (bound_ctrl): the image border, or discarded halo
+    }
+    {
+        const int y = y0 - 1;
+        const bool ok = colok && y >= 0 && y + 1 < rows;
+        wu0 = ok ? lut[(M[(size_t)y * ip + x] >> 8) & 255] : 0.0f;
+    }
+#pragma unroll
+    for (int g = 0; g < R; g++) {
+        float c = 0.0f;                          // left, right, up, down (src/GPUSolver.cu:82,88,94,100)
+        c += wl[g]; c += wr[g]; c += g == 0 ? wu0 : wd[g - 1]; c += wd[g];
+        cnt[g] = c == 0.0f ? 1.0f : c;
+        rcp[g] = rcp_rn(cnt[g]);
+        unsafe |= cnt[g] < 0x1p-126f;
+    }
+    const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
+    constexpr uint32_t kTinyT = 2u * 0x0D800000u - 1u;
+    const int up_w = wv > 0 ? wv - 1 : wv, dn_w = wv < nwv - 1 ? wv + 1 : wv;
+    const int poll_idx = lane == 0 ? up_w : dn_w;
+
+    auto sweep = [&](float (&cur)[R], float (&oth)[R], int s, auto fast, bool last, auto parity) {
+        constexpr bool FAST = decltype(fast)::value;
+        constexpr int buf = decltype(parity)::value;
+        for (;;) {                               // both neighbouring waves' counters in one LDS access (lane 0: above, the others: below)
+            const int f = __hip_atomic_load(&published[poll_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_ballot_w64(f < s + 1) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // (the first / last wave reads its own row instead of a missing neighbour: weighted 0 at the image border, discarded halo elsewhere)
+        const float up = wv > 0 ? edge[buf][up_w][lane].y : edge[buf][wv][lane].x;
+        const float dn = wv < nwv - 1 ? edge[buf][dn_w][lane].x : edge[buf][wv][lane].y;
+        const float omega = omegas[s];
+        auto wsum = [&](int g) {
+            const float xl = lane_from_prev(cur[g]), xr = lane_from_next(cur[g]);
+            const float xu = g == 0 ? up : cur[g - 1], xd = g == R - 1 ? dn : cur[g + 1];
+            const float wu = g == 0 ? wu0 : wd[g - 1];
+            float sum = 0.0f;
+            sum = CONTRACT ? __builtin_fmaf(wl[g], xl, sum) : sum + wl[g] * xl;
+            sum = CONTRACT ? __builtin_fmaf(wr[g], xr, sum) : sum + wr[g] * xr;
+            sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
+            sum = CONTRACT ? __builtin_fmaf(wd[g], xd, sum) : sum + wd[g] * xd;
+            return sum;
+        };
+        auto pair = [&](int g0, int g1) {        // two rows: sums, quotients, ONE tiny test, updates (as in k_sweep_blocked)
+            const float s0 = wsum(g0), s1 = wsum(g1);
+            float q0, q1;
+            if (FAST) {
+                q0 = div_tail(s0, cnt[g0], rcp[g0]); q1 = div_tail(s1, cnt[g1], rcp[g1]);
+                const uint32_t t0 = (__float_as_uint(s0) << 1) + 0xFFFFFFFFu, t1 = (__float_as_uint(s1) << 1) + 0xFFFFFFFFu;
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64((t0 < t1 ? t0 : t1) < kTinyT) != 0, 0)) { q0 = s0 / cnt[g0]; q1 = s1 / cnt[g1]; }
+            } else { q0 = s0 / cnt[g0]; q1 = s1 / cnt[g1]; }
+            const int gs[2] = {g0, g1}; const float qs[2] = {q0, q1};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int g = gs[k];
+                const float r = __builtin_amdgcn_fmed3f(qs[k], 0.0f, 255.0f);
+                const float xc = cur[g], prev = oth[g];
+                const float v = CONTRACT ? __builtin_fmaf(omega, __builtin_fmaf(gamma, r - xc, xc) - prev, prev)      // src/GPUSolver.cu:259
+                                         : (omega * (gamma * (r - xc) + xc - prev)) + prev;
+                oth[g] = dir[g] ? xc : v;
+            }
+        };
+        pair(0, R - 1);
+        if (!last) {
+            edge[buf ^ 1][wv][lane] = make_float2(oth[0], oth[R - 1]);
+            __hip_atomic_store(&published[wv], s + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        pair(1, 2);
+    };
+
+    edge[0][wv][lane] = make_float2(a[0], a[R - 1]);
+    __hip_atomic_store(&published[wv], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+    // TRAPEZOID: what sweep s has to produce is the written-back region grown by the sweeps still to come, rows
+    // [hy - (n-1-s), eh - hy + (n-1-s)) -- it shrinks by a row per sweep from either side.  A wave none of whose four rows lie in it
+    // any more has nothing left to contribute (the region only shrinks): it sets its counter to "for ever" so that its neighbours
+    // never wait for it again, and leaves.  What its inner neighbour then reads from it is stale but finite, and the rows that
+    // value spoils move inwards one per sweep -- exactly as fast as the region's edge, so they are never rows anyone needs.
+    // At depth 28 on the 64-row tile 59 % of the wave-sweeps remain, and the last sweeps run on two waves instead of sixteen.
+    // (a tile that is the whole level has hy = 0: every wave stays to the end)
+    const int n = nsweeps;
+    const int a0 = n + 2 - hy + R * wv, a1 = n - 2 - R * wv + eh - hy;
+    const int active_until = min(n - 1, min(a0, a1));                // the last sweep this wave takes part in (wave-uniform)
+    int s = 0;
+    bool odd = false;
+    if (!wave_unsafe) {
+        for (; s + 1 < n && s + 1 <= active_until; s += 2) { sweep(a, b, s, std::true_type{}, false, P0{}); sweep(b, a, s + 1, std::true_type{}, s + 2 >= n, P1{}); }
+        if (s < n && s <= active_until) { sweep(a, b, s, std::true_type{}, s + 1 >= n, P0{}); odd = true; }
+    } else {
+        for (; s + 1 < n && s + 1 <= active_until; s += 2) { sweep(a, b, s, std::false_type{}, false, P0{}); sweep(b, a, s + 1, std::false_type{}, s + 2 >= n, P1{}); }
+        if (s < n && s <= active_until) { sweep(a, b, s, std::false_type{}, s + 1 >= n, P0{}); odd = true; }
+    }
+    if (active_until < n - 1) {                                      // left early: never hold a neighbour up, nothing of mine is written back
+        __hip_atomic_store(&published[wv], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    // write back the part that is still exact: newest iterate -> Yk, the one before -> Ym
+    const bool xin = colok && lane >= hx && lane < 64 - hx;
+#pragma unroll
+    for (int g = 0; g < R; g++) {
+        const int y = y0 + g, ty = R * wv + g;
+        if (xin && ty >= hy && ty < eh - hy && y < rows) {
+            const size_t off = (size_t)y * ip + x;
+            Yk[off] = odd ? b[g] : a[g];
+            Ym[off] = odd ? a[g] : b[g];
+        }
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 struct TileCfg { int lx, nt, g; };
 // id -> (lanes per tile row, threads, rows per thread); extended tile = 4*lx wide, nt/lx*g tall
 static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 1024, 4}, {32, 1024, 3}, {32, 512, 3}, {16, 512, 3}, {16, 256, 3}, {32, 1024, 2},
-                                 {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}, {32, 768, 4}, {32, 512, 6}};
-constexpr int kNumTiles = 13;
+                                 {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}, {32, 768, 4}, {32, 512, 6},
+                                 {16, 1024, 1} /* 14: tile 9's geometry in the column layout (k_sweep_col) */};
+constexpr int kNumTiles = 14;
 
 // Can every workgroup of a persistent launch be resident at once?  Asked of the runtime once per kernel (the answer depends on the
 // kernel's registers and LDS): at least one workgroup of `nthreads` threads per CU, and no more workgroups than CUs.  A launch that
@@ -560,7 +713,7 @@ static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, fl
 //   persistent                 T sweeps + ~8 us halo exchange (6 us for the small tiles); needs nWG <= #CUs, T even,
 //                              halo no wider than a neighbour's centre
 // It only has to rank candidates; it reproduces the measured launch times within ~15 %.
-static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1};
+static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1, 1};
 
 static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int tile, int T, bool persist) {
     const int G = kTiles[tile].g;
@@ -576,7 +729,7 @@ static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int ti
     const double bw = img_bytes > 2e8 ? 17600.0 : 22600.0;      // bytes/us per CU: 4.5 TB/s from HBM (8K), 5.8 TB/s from the Infinity Cache
     const double load1 = small * ext * 12.0 / bw, store1 = small * (double)TW * TH * 8.0 / bw;
     if (persist) {
-        if (nwg > cus || (T & 1) || hx > TW || T > TH || n <= T) return 1e30;
+        if (tile == 14 || nwg > cus || (T & 1) || hx > TW || T > TH || n <= T) return 1e30;
         return (T * (lat > thr1 ? lat : thr1) + 5.0 + 3.0 * ext / 12288.0) / T;
     }
     const int k = kWgPerCu[tile];
@@ -595,11 +748,14 @@ static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int ti
     } else {
         t = boundary + ceil(m) * (load1 + T * (lat > thr1 ? lat : thr1) + 0.5 * store1);
     }
+    // the column layout with its shrinking set of waves (k_sweep_col): measured 0.90-0.92 of tile 9 in one round (120x67 depth 28,
+    // 240x135 depth 24), 0.66-0.76 over several rounds (a third of the LDS traffic)
+    if (tile == 14) t *= m <= k ? 0.9 : 0.75;
     return t / T;
 }
 
 static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fixed_tile, int fixed_T, int *tile, int *T, bool *persist) {
-    static const int tiles[] = {4, 8, 9, 6, 5, 7, 12};
+    static const int tiles[] = {4, 8, 9, 14, 6, 5, 7, 12};
     static const int depths[] = {4, 8, 12, 16, 24, 28};
     double best = 1e30;
     *tile = 9; *T = 8; *persist = false;
@@ -674,6 +830,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         bool persistent = !single && want_persistent && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= (unsigned)kSyncMaxTiles &&
                                 (T % 2 == 0) && n - done > T && hy == T &&
                                 hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
+        if (tile == 14) persistent = false;                 // (the column-layout kernel has no persistent mode)
         if (persistent) {
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) case id: persistent = persistent_possible<LX_, NT_, G_>(ctx, kTiles[tile].nt); break;
             switch (tile) { RTDD_ALL_TILES }
@@ -696,6 +853,11 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         float *Yk = L.P(free0, ip), *Ym = L.P(free1, ip);
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) \
     case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps); break;
+        if (tile == 14) {
+            const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
+            if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles);
+            else hipLaunchKernelGGL(k_sweep_col<false>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles);
+        } else
         switch (tile) { RTDD_ALL_TILES }
 #undef RTDD_TILE_CASE
         ctx->last_info.kernel = 2; ctx->last_info.tile = tile; ctx->last_info.temporal_depth = persistent ? block_sweeps : m; ctx->last_info.persistent = persistent ? 1 : 0;
