@@ -523,8 +523,10 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
                                                     int ip, int rows, int cols, int hx, int hy, int nsweeps, float gamma, int gx, int gy, int xcd_tiles) {
     constexpr int R = 4;
     __shared__ float lut[257];
-    __shared__ float2 edge[2][16][64];         // [buffer][wave][lane] = (its top row, its bottom row)
-    __shared__ int published[16];
+    // [buffer][wave][lane] = (top row value, tag, bottom row value, tag): the tag is the number of the sweep the values are for, + 1,
+    // written by a second instruction BEHIND the values (the LDS serves a wave's accesses in order), so a reader that finds the tag
+    // it wants in its one 8-byte read of (value, tag) holds the right value -- no separate counter poll, one LDS round trip per sweep.
+    __shared__ int4 edge[2][16][64];
     int bx = blockIdx.x, by = blockIdx.y;
     if (xcd_tiles > 0) {
         const int t = ((int)blockIdx.x & 7) * xcd_tiles + ((int)blockIdx.x >> 3);
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = (int)blockDim.x >> 6;
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
-    if (tid < 16) published[tid] = 0;
+    for (int i = tid; i < 2 * 16 * 64; i += (int)blockDim.x) (&edge[0][0][0])[i] = make_int4(0, 0, 0, 0);
     __syncthreads();
     const int eh = R * nwv, TW = 64 - 2 * hx, TH = eh - 2 * hy;
     const int x = bx * TW - hx + lane, y0 = by * TH - hy + R * wv;
@@ -570,20 +572,31 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
     const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
     constexpr uint32_t kTinyT = 2u * 0x0D800000u - 1u;
     const int up_w = wv > 0 ? wv - 1 : wv, dn_w = wv < nwv - 1 ? wv + 1 : wv;
-    const int poll_idx = lane == 0 ? up_w : dn_w;
+    // (the first / last wave reads its own row instead of a missing neighbour: weighted 0 at the image border, discarded halo elsewhere)
+    const int up_half = wv > 0 ? 1 : 0, dn_half = wv < nwv - 1 ? 0 : 1;        // which (value, tag) pair of the entry: 0 = top, 1 = bottom
+    auto publish = [&](int buf, float top, float bottom, int tag) {
+        int *e = (int *)&edge[buf][wv][lane];
+        asm volatile("" ::: "memory");
+        e[0] = __float_as_int(top); e[2] = __float_as_int(bottom);
+        asm volatile("" ::: "memory");                                      // values first, tags behind them
+        __hip_atomic_store(&e[1], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&e[3], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+    };
 
     auto sweep = [&](float (&cur)[R], float (&oth)[R], int s, auto fast, bool last, auto parity) {
         constexpr bool FAST = decltype(fast)::value;
         constexpr int buf = decltype(parity)::value;
-        for (;;) {                               // both neighbouring waves' counters in one LDS access (lane 0: above, the others: below)
-            const int f = __hip_atomic_load(&published[poll_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__builtin_amdgcn_ballot_w64(f < s + 1) == 0) break;
+        float up, dn;
+        for (;;) {
+            const long long *pu = (const long long *)&edge[buf][up_w][lane] + up_half, *pd = (const long long *)&edge[buf][dn_w][lane] + dn_half;
+            const long long u = __hip_atomic_load(pu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (value, tag) in one 8-byte read
+            const long long d = __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            up = __int_as_float((int)u); dn = __int_as_float((int)d);
+            const int tu = (int)(u >> 32), td = (int)(d >> 32);
+            if (__builtin_amdgcn_ballot_w64((tu < td ? tu : td) < s + 1) == 0) break;
             __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // (the first / last wave reads its own row instead of a missing neighbour: weighted 0 at the image border, discarded halo elsewhere)
-        const float up = wv > 0 ? edge[buf][up_w][lane].y : edge[buf][wv][lane].x;
-        const float dn = wv < nwv - 1 ? edge[buf][dn_w][lane].x : edge[buf][wv][lane].y;
         const float omega = omegas[s];
         auto wsum = [&](int g) {
             const float xl = lane_from_prev(cur[g]), xr = lane_from_next(cur[g]);
@@ -616,15 +629,11 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
             }
         };
         pair(0, R - 1);
-        if (!last) {
-            edge[buf ^ 1][wv][lane] = make_float2(oth[0], oth[R - 1]);
-            __hip_atomic_store(&published[wv], s + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if (!last) publish(buf ^ 1, oth[0], oth[R - 1], s + 2);
         pair(1, 2);
     };
 
-    edge[0][wv][lane] = make_float2(a[0], a[R - 1]);
-    __hip_atomic_store(&published[wv], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    publish(0, a[0], a[R - 1], 1);
     using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
     // TRAPEZOID: what sweep s has to produce is the written-back region grown by the sweeps still to come, rows
     // [hy - (n-1-s), eh - hy + (n-1-s)) -- it shrinks by a row per sweep from either side.  A wave none of whose four rows lie in it
@@ -646,7 +655,11 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
         if (s < n && s <= active_until) { sweep(a, b, s, std::false_type{}, s + 1 >= n, P0{}); odd = true; }
     }
     if (active_until < n - 1) {                                      // left early: never hold a neighbour up, nothing of mine is written back
-        __hip_atomic_store(&published[wv], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int bf = 0; bf < 2; bf++) {                             // tags "for ever" in both buffers, values left as they are (finite)
+            int *e = (int *)&edge[bf][wv][lane];
+            __hip_atomic_store(&e[1], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&e[3], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         return;
     }
     // write back the part that is still exact: newest iterate -> Yk, the one before -> Ym
