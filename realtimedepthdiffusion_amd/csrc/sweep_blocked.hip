@@ -599,12 +599,19 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
         }
         const float omega = omegas[s];
         auto wsum = [&](int g) {
-            const float xl = lane_from_prev(cur[g]), xr = lane_from_next(cur[g]);
+            const float xl = lane_from_prev(cur[g]);
             const float xu = g == 0 ? up : cur[g - 1], xd = g == R - 1 ? dn : cur[g + 1];
             const float wu = g == 0 ? wu0 : wd[g - 1];
             float sum = 0.0f;
             sum = CONTRACT ? __builtin_fmaf(wl[g], xl, sum) : sum + wl[g] * xl;
-            sum = CONTRACT ? __builtin_fmaf(wr[g], xr, sum) : sum + wr[g] * xr;
+            if (CONTRACT) {
+                // sum = fma(wr, x of the NEXT lane, sum) with the lane shift as the instruction's own DPP operand (lane 63 reads 0, as
+                // lane_from_next gives it): one instruction instead of v_mov_b32_dpp + v_fmac -- hipcc does not fold wave shifts itself
+                // (s_nop 1: a DPP read needs two wait states after a VALU write of its source, and the hazard recogniser does not look inside asm)
+                asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(sum) : "v"(cur[g]), "v"(wr[g]));
+            } else {
+                sum = sum + wr[g] * lane_from_next(cur[g]);
+            }
             sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
             sum = CONTRACT ? __builtin_fmaf(wd[g], xd, sum) : sum + wd[g] * xd;
             return sum;
