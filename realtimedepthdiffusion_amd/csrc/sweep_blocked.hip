@@ -733,7 +733,7 @@ static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, fl
 //   persistent                 T sweeps + ~8 us halo exchange (6 us for the small tiles); needs nWG <= #CUs, T even,
 //                              halo no wider than a neighbour's centre
 // It only has to rank candidates; it reproduces the measured launch times within ~15 %.
-static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1, 1};
+static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1, 2};
 
 static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int tile, int T, bool persist) {
     const int G = kTiles[tile].g;
