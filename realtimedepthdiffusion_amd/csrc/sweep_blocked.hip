@@ -768,9 +768,10 @@ static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int ti
     } else {
         t = boundary + ceil(m) * (load1 + T * (lat > thr1 ? lat : thr1) + 0.5 * store1);
     }
-    // the column layout with its shrinking set of waves (k_sweep_col): measured 0.90-0.92 of tile 9 in one round (120x67 depth 28,
-    // 240x135 depth 24), 0.66-0.76 over several rounds (a third of the LDS traffic)
-    if (tile == 14) t *= m <= k ? 0.9 : 0.75;
+    // the column layout with its shrinking set of waves (k_sweep_col): measured 0.90-0.92 of tile 9 when every tile is resident at once
+    // (120x67 depth 28, 240x135 depth 24).  Only offered there: over several rounds it beats tile 9 but not the larger tiles (4K: 794
+    // against 1100 Gpx-it/s).
+    if (tile == 14) { if (m > k) return 1e30; t *= 0.9; }
     return t / T;
 }
 

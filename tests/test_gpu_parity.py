@@ -495,3 +495,19 @@ def test_solve_info_names_the_path_that_ran(ctx):
     i = ctx.last_solve_info()
     assert (i.kernel, i.iterations, i.fp_contract) == (4, 12, 1), i.describe()
     ctx.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,iters,small", [(67, 120, 56, True), (135, 240, 48, True), (1080, 1920, 16, False), (2160, 3840, 8, False)])
+def test_automatic_configuration_keeps_the_column_kernel_to_the_small_levels(ctx, rows, cols, iters, small):
+    """The cost model offers the column-layout kernel (tile 14) only where every tile of a launch is resident at once: the two
+    coarsest levels of a 1080p cascade.  At 1080p and 4K it is far slower than the large tiles (a round-2 regression caught by the
+    profile run: 4K 1100 -> 794 Gpx-it/s) -- the choice is part of the contract."""
+    p = make_problem(rows, cols, seed=3)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, iters, 0.0, 0)
+    i = ctx.last_solve_info()
+    ctx.synchronize()
+    assert i.kernel == 2, i.describe()
+    assert (i.tile == 14) == small, i.describe()
