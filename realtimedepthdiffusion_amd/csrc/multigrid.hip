@@ -22,7 +22,10 @@
 namespace rtdd {
 
 constexpr float kTheta = 1e-4f;       // hierarchy only: weaker links become anchors
-constexpr int kNu = 2;                // pre- and post-smoothing sweeps on every level
+#ifndef RTDD_MG_NU
+#define RTDD_MG_NU 2
+#endif
+constexpr int kNu = RTDD_MG_NU;       // pre- and post-smoothing sweeps on every level (the oracle restates 2; other values: experiments only)
 constexpr int kCoarsestSweeps = 30;
 constexpr int kSmallLevel = 16384;    // fallback single-workgroup smoother out of global memory (not used by the cycle as configured)
 
