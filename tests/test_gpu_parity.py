@@ -144,6 +144,31 @@ def test_randomised_shapes_and_options(ctx, oracle, lut):
         assert_bit_equal(got, want, f"trial {trial}: {rows}x{cols} iters {iters} level {level}/{levels} contract {contract} opts {opts}")
 
 
+def test_randomised_column_kernel(ctx, oracle, lut):
+    """The column-layout kernel (tile 14) under 40 random (shape, sweeps, depth, level rule, contraction) draws: single tiles
+    (<= 64 x 64, every wave stays to the end), ragged multi-tile grids, depths from 1 to 28 (waves leave as the needed region shrinks)."""
+    rng = np.random.default_rng(20261004)
+    for trial in range(40):
+        rows = int(rng.integers(1, 300)); cols = int(rng.integers(1, 300))
+        if trial % 4 == 0: rows, cols = int(rng.integers(1, 65)), int(rng.integers(1, 65))
+        iters = int(rng.integers(1, 70))
+        levels = int(rng.integers(1, 4)); level = int(rng.integers(0, levels))
+        contract = int(rng.integers(0, 2))
+        opts = {rt.OPT_SWEEP_KERNEL: 2, rt.OPT_TILE: 14, rt.OPT_TEMPORAL_DEPTH: int(rng.choice([1, 2, 3, 5, 8, 12, 16, 24, 28]))}
+        p = make_problem(rows, cols, seed=2000 + trial)
+        if (p["mask"] == 255).sum() == 0:
+            p["mask"][rows // 2, cols // 2] = 255; p["depth"][rows // 2, cols // 2] = 128
+        free = p["mask"] != 255
+        p["depth"][free] = rng.uniform(0, 255, int(free.sum())).astype(np.float32)
+        want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, level, levels - 1, lut, contract, threads=min(8, oracle.max_threads()))
+        got = _solve_gpu(ctx, p, iters, level, levels, contract, opts=opts)
+        info = ctx.last_solve_info()
+        for k in (rt.OPT_SWEEP_KERNEL, rt.OPT_TILE, rt.OPT_TEMPORAL_DEPTH):
+            ctx.set_option(k, 0)
+        assert info.tile == 14, info.describe()
+        assert_bit_equal(got, want, f"trial {trial}: {rows}x{cols} iters {iters} level {level}/{levels} contract {contract} opts {opts}")
+
+
 def test_persistent_mode_stress_under_uneven_load(oracle, lut):
     """Hand-offs must hold under uneven load with warm caches (cdna_hip_programming.md G16 pitfall 3): 40 solves
     back to back (1000 halo exchanges of 252 workgroups) while a second stream streams 1 GiB through the memory
