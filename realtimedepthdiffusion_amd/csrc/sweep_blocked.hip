@@ -520,7 +520,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 template <bool CONTRACT>
 __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk, const float *__restrict__ Xm, float *__restrict__ Yk, float *__restrict__ Ym,
                                                     const uint32_t *__restrict__ M, const float *__restrict__ lut_g, const float *__restrict__ omegas,
-                                                    int ip, int rows, int cols, int hx, int hy, int nsweeps, float gamma, int gx, int gy, int xcd_tiles) {
+                                                    int ip, int rows, int cols, int hx, int hy, int nsweeps, float gamma, int gx, int gy, int xcd_tiles, int *sync_words) {
     constexpr int R = 4;
     __shared__ float lut[257];
     // [buffer][wave][lane] = (top row value, tag, bottom row value, tag): the tag is the number of the sweep the values are for, + 1,
@@ -584,18 +584,34 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
         asm volatile("" ::: "memory");
     };
 
+    bool gone = false;                           // a wait inside this workgroup ran into its bound (see the read loop): stop waiting
     auto sweep = [&](float (&cur)[R], float (&oth)[R], int s, auto fast, bool last, auto parity) {
         constexpr bool FAST = decltype(fast)::value;
         constexpr int buf = decltype(parity)::value;
         float up, dn;
-        for (;;) {
+        {
             const long long *pu = (const long long *)&edge[buf][up_w][lane] + up_half, *pd = (const long long *)&edge[buf][dn_w][lane] + dn_half;
-            const long long u = __hip_atomic_load(pu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (value, tag) in one 8-byte read
-            const long long d = __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            up = __int_as_float((int)u); dn = __int_as_float((int)d);
-            const int tu = (int)(u >> 32), td = (int)(d >> 32);
-            if (__builtin_amdgcn_ballot_w64((tu < td ? tu : td) < s + 1) == 0) break;
-            __builtin_amdgcn_s_sleep(1);
+            auto read_both = [&]() {                 // (value, tag) of either neighbour in one 8-byte read each; true when both tags are there
+                const long long u = __hip_atomic_load(pu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const long long d = __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                up = __int_as_float((int)u); dn = __int_as_float((int)d);
+                const int tu = (int)(u >> 32), td = (int)(d >> 32);
+                return __builtin_amdgcn_ballot_w64((tu < td ? tu : td) < s + 1) == 0;
+            };
+            if (__builtin_expect(!read_both(), 0)) {                 // the straight path above is the hot one: keep the waiting out of it
+                // Every wave of a workgroup is resident and a leaving wave marks its tags first, so a wait of seconds is a bug: report it
+                // (status 2, persist_sync.hpp) and stop waiting instead of hanging the GPU -- the results are garbage from here on.
+                unsigned spins = 0;
+                while (!gone) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (read_both()) break;
+                    if (++spins > (1u << 22)) {
+                        __hip_atomic_store(&sync_words[kSyncStatus], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gone = true;
+                    }
+                }
+                if (gone) { up = 0.0f; dn = 0.0f; }
+            }
         }
         const float omega = omegas[s];
         auto wsum = [&](int g) {
@@ -876,8 +892,9 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
     case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps); break;
         if (tile == 14) {
             const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
-            if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles);
-            else hipLaunchKernelGGL(k_sweep_col<false>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles);
+            if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
+            else hipLaunchKernelGGL(k_sweep_col<false>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
+            ctx->persistent_used = true;          // (so that the next synchronising call reads the status word)
         } else
         switch (tile) { RTDD_ALL_TILES }
 #undef RTDD_TILE_CASE
