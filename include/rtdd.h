@@ -82,6 +82,8 @@ enum rtdd_option {
     RTDD_OPT_DEBUG_WITHHOLD_TILE = 7, /* testing aid: tile number + 1 whose hand-off flag a persistent launch never publishes (0 = off),
                                        so that its neighbours run into the poll limit -> RTDD_ERR_TIMEOUT */
     RTDD_OPT_DEBUG_POLL_LIMIT_US = 8, /* testing aid: that poll limit in microseconds (0 = the default, 200 ms) */
+    RTDD_OPT_DEBUG_FORCE_STATUS = 13, /* testing aid: value (0..2) stored into the kernels' status word right behind the next temporally blocked
+                                       Jacobi launch, persistent or not, as if a wave of it had given up (one shot: resets to 0) */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),
@@ -98,7 +100,10 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value);
 int rtdd_get_option(rtdd_ctx *ctx, int key, int *value);
 const char *rtdd_last_error(rtdd_ctx *ctx);              /* message of the last failing call on ctx */
 const char *rtdd_status_string(int status);
-int rtdd_version(void);
+int rtdd_version(void);                                  /* major * 100 + minor.  200: rtdd_solve_info grew from 12 to 36 bytes (kernel .. launches);
+                                                          * rtdd_solve_ex / rtdd_refine_depth / rtdd_last_solve_info write the whole struct, so a
+                                                          * caller compiled against a 1xx header must be rebuilt (#define RTDD_VERSION below) */
+#define RTDD_VERSION 200
 
 /* ---- solver (include/GPUSolver.h:6-10) ------------------------------------------------------ */
 

@@ -28,6 +28,7 @@ RELAXATION_AUTO = -1.0                     # rtdd_solve_params.relaxation: SOR c
 OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, _OPT_RESERVED_3, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
 OPT_DEBUG_WITHHOLD_TILE, OPT_DEBUG_POLL_LIMIT_US = 7, 8
 OPT_AUTO_CYCLE_FIXED_NS, OPT_AUTO_CYCLE_FS_PER_PX, OPT_AUTO_SWEEP_FS_PER_PX, OPT_AUTO_SWEEP_FLOOR_NS = 9, 10, 11, 12
+OPT_DEBUG_FORCE_STATUS = 13
 RTDD_ERR_TIMEOUT = 6
 
 # every symbol include/rtdd.h declares (checked by tests/test_abi.py against the header)
@@ -107,6 +108,8 @@ def lib():
         L.rtdd_status_string.restype = C.c_char_p
         for name in C_ABI_SYMBOLS:
             getattr(L, name)        # fail at load time, not at first use, if a symbol is missing
+        if L.rtdd_version() // 100 != 2:    # SolveInfo below is the 36-byte rtdd_solve_info of ABI 2xx
+            raise RtddError(-1, f"{_SO} has ABI version {L.rtdd_version()}, this binding needs 2xx: rebuild")
         _lib = L
     return _lib
 

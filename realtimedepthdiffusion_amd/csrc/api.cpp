@@ -83,7 +83,7 @@ using namespace rtdd;
 #pragma GCC visibility push(default)
 extern "C" {
 
-int rtdd_version(void) { return 100; }
+int rtdd_version(void) { return RTDD_VERSION; }
 
 const char *rtdd_status_string(int s) {
     switch (s) {
@@ -109,6 +109,7 @@ int rtdd_ctx_create(int device, rtdd_ctx **out) {
     rtdd_ctx *ctx = new (std::nothrow) rtdd_ctx();
     if (!ctx) return RTDD_ERR_NOMEM;
     ctx->device = device;
+    for (auto &t : ctx->persist_fit) t[0] = t[1] = -1;
     DeviceGuard g(device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -168,6 +169,7 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_AUTO_SWEEP_FLOOR_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_sweep_floor_ns = value; break;
         case RTDD_OPT_DEBUG_WITHHOLD_TILE: REQUIRE(ctx, value >= 0 && value <= kSyncMaxTiles, "tile number + 1 out of range"); ctx->opt.debug_withhold_tile = value; break;
         case RTDD_OPT_DEBUG_POLL_LIMIT_US: REQUIRE(ctx, value >= 0 && value <= 10000000, "poll limit must be 0..1e7 us"); ctx->opt.debug_poll_limit_us = value; break;
+        case RTDD_OPT_DEBUG_FORCE_STATUS: REQUIRE(ctx, value >= 0 && value <= 2, "status must be 0..2"); ctx->opt.debug_force_status = value; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;
@@ -188,6 +190,7 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_AUTO_SWEEP_FLOOR_NS: *value = ctx->opt.auto_sweep_floor_ns; break;
         case RTDD_OPT_DEBUG_WITHHOLD_TILE: *value = ctx->opt.debug_withhold_tile; break;
         case RTDD_OPT_DEBUG_POLL_LIMIT_US: *value = ctx->opt.debug_poll_limit_us; break;
+        case RTDD_OPT_DEBUG_FORCE_STATUS: *value = ctx->opt.debug_force_status; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;

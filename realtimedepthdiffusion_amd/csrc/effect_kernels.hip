@@ -6,17 +6,8 @@
 // (/root/reference/src/GPUDepthEffect.cu:18-25, 83-91); rows that are not 4-byte aligned take a
 // byte-wise path with identical arithmetic.
 //
-// Defocus in the reference is a per-pixel O(k^2) gather (up to 48 400 taps at 8K,
-// src/GPUDepthEffect.cu:47-60); here it is an exact O(1) lookup in a u32 summed-area table: window
-// sums are < 2^24 so the reference's f32 accumulation is exact, and mod-2^32 subtraction of wrapped
-// prefixes is exact too, so results are bit-identical while the cost no longer depends on the blur
-// radius.  The table is built in three passes chosen for parallelism on 256 CUs:
-//   k_sat_rows   one workgroup per image row: each wave scans a quarter of the row 64 pixels at a time
-//                (lane = pixel, shuffle scan), 12-byte {B,G,R} prefixes stored contiguously;
-//   k_sat_bands  column prefixes INSIDE bands of 32 rows (rows/32 x cols/256 workgroups instead of a
-//                1080-step serial walk), band totals on the side;
-//   k_sat_base   exclusive scan of the band totals (tiny);
-// and k_defocus adds the band base while fetching its four corners (one dwordx3 each).
+// Defocus in the reference is a per-pixel O(k^2) gather (up to 48 400 taps at 8K, src/GPUDepthEffect.cu:47-60); here it is an
+// exact O(1) lookup in a packed 64-bit summed-area table written once -- see "defocus" below.
 #include "rtdd_internal.hpp"
 
 namespace rtdd {
@@ -109,151 +100,337 @@ __global__ __launch_bounds__(256) void k_blend(const uint8_t *__restrict__ orig,
     }
 }
 
-// ---- defocus: summed-area table ------------------------------------------------------------------
-// L has (rows+1) x (cols+1) entries of 3 x u32 {B, G, R} (12 B, moved as dwordx3): L[0][*] = L[*][0] = 0 and, for r >= 1,
-// L[r][c] = sum over rows of r's band up to r-1, columns < c (mod 2^32).  The full prefix is
-// S(r,c) = L[r][c] + base[(r-1)/kBand][c].
-constexpr int kBand = 32;
+// ---- defocus: packed summed-area table ---------------------------------------------------------------
+// The reference gathers up to (2*(K/2))^2 taps per pixel (src/GPUDepthEffect.cu:47-60: 2 916 at 1080p, 12 100 at 4K, 48 400 at 8K).
+// Here: an exact O(1) lookup.  A pixel is packed into ONE 64-bit integer  p = B + G * 2^21 + R * 2^42  and
+//     T[r][c] = sum of p over rows <= r, columns <= c          (plain 64-bit adds, i.e. arithmetic mod 2^64)
+// is stored once, 8 aligned bytes per pixel.  Any rectangle sum  X = T(y1,x1) - T(y1,x0) - T(y0,x1) + T(y0,x0)  (mod 2^64) is the
+// packed integer of its three channel sums; whenever each of those is < 2^21 -- a window of at most kSatMaxArea = 8224 pixels,
+// 8224 * 255 < 2^21 -- the fields do not run into each other and B, G, R are read off X exactly (carries between the fields of the
+// PREFIXES cancel: Z/2^64 is a ring).  Larger windows (12 100 px at 4K, 48 400 at 8K, or an out-of-range depth) are cut into
+// horizontal strips of <= 8224 px that share corner rows: n strips cost 2 (n + 1) loads.  The channel sums are < 2^24 for every
+// nominal window, so the reference's f32 accumulation is exact and so is the u32 -> f32 conversion here: bit-identical results.
+// Round 2 kept 12-byte {B,G,R} u32 entries written by a row pass, rewritten by a band pass, and read 8 times per pixel (table + band
+// base at four corners, unaligned): 60-130 B/px moved against 10 B/px algorithmic.
+//
+// Build, three launches, the table written exactly once:
+//   k_sat_colsum   per band of RB rows and per column: packed sum of the band's pixels                  (reads the image: 3 B/px)
+//   k_sat_colbase  exclusive scan of those sums down the bands, per column (tiny: rows/RB x cols x 8 B)
+//   k_sat_build    one workgroup per band, the full row width: running column sums from the band's base, row prefix by a 64-bit
+//                  DPP wave scan + one LDS exchange of wave totals per four rows, one aligned 32-byte store per four pixels
+// and k_defocus reads its four (or 2 (n + 1)) corners with aligned 8-byte loads.
+typedef unsigned long long u64;
+constexpr int kSatMaxArea = 8224;                                   // 8224 * 255 = 2 097 120 < 2^21
+constexpr u64 kSatFieldMask = (1ull << 21) - 1;
 
-struct u3 { uint32_t x, y, z; };                                    // 12-byte table entry
-__device__ __forceinline__ u3 ld3(const u3 *p) { return *p; }
-__device__ __forceinline__ void st3(u3 *p, uint32_t a, uint32_t b, uint32_t c) { u3 v; v.x = a; v.y = b; v.z = c; *p = v; }
+__device__ __forceinline__ u64 pack_px(uint32_t b, uint32_t g, uint32_t r) { return (u64)(b | (g << 21)) | ((u64)(r << 10) << 32); }
 
-// inclusive prefix sum over the 64 lanes of a wave: the 7-step DPP scan (3 row shifts of the input, row_shr:4 / :8 under bank
-// masks, row_bcast:15 / :31 under row masks) -- VALU only, no LDS crossbar
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#define RTDD_DPP(src, ctrl, rows, banks) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(src), ctrl, rows, banks, true)
-    uint32_t t = v + RTDD_DPP(v, 0x111, 0xF, 0xF);      // row_shr:1
-    t += RTDD_DPP(v, 0x112, 0xF, 0xF);                  // row_shr:2
-    t += RTDD_DPP(v, 0x113, 0xF, 0xF);                  // row_shr:3   -> v[i-3..i] within a row of 16
-    t += RTDD_DPP(t, 0x114, 0xF, 0xE);                  // row_shr:4, banks 1-3
-    t += RTDD_DPP(t, 0x118, 0xF, 0xC);                  // row_shr:8, banks 2-3  -> prefix within each row of 16
-    t += RTDD_DPP(t, 0x142, 0xA, 0xF);                  // row_bcast:15 into rows 1 and 3
-    t += RTDD_DPP(t, 0x143, 0xC, 0xF);                  // row_bcast:31 into rows 2 and 3
-#undef RTDD_DPP
-    return t;
+// four interleaved BGR pixels held in three dwords -> four packed pixels
+__device__ __forceinline__ void unpack4(uint32_t w0, uint32_t w1, uint32_t w2, u64 px[4]) {
+    px[0] = pack_px(w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255);
+    px[1] = pack_px(w0 >> 24, w1 & 255, (w1 >> 8) & 255);
+    px[2] = pack_px((w1 >> 16) & 255, w1 >> 24, w2 & 255);
+    px[3] = pack_px((w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24);
 }
 
-// pass 1: row-wise inclusive prefix of image row y into L[y+1][1..].  One workgroup per row, one wave per 512-pixel segment (4 waves
-// at 1080p, 8 at 4K, 16 at 8K; wider rows loop).  A wave loads its whole segment at once -- 8 groups of 64 pixels, lane = pixel,
-// so the 3-byte loads and the 12-byte stores of a wave instruction are contiguous -- runs the 24 independent DPP scans, chains
-// the group totals in scalar registers, trades segment totals through LDS (one barrier) and stores.  One pass over the row, every
-// load in flight together.
-constexpr int kSatGroups = 8;                                       // 64-pixel groups per wave and pass
-__global__ __launch_bounds__(1024) void k_sat_rows(const uint8_t *__restrict__ orig, size_t op, u3 *__restrict__ L, int rows, int cols) {
-    __shared__ uint32_t seg[2][16][3];
-    const int y = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-    const uint8_t *o = orig + (size_t)y * op;
-    u3 *lrow = L + (size_t)(y + 1) * (cols + 1);
-    if (threadIdx.x == 0) st3(lrow, 0, 0, 0);
-    uint32_t carry[3] = {0, 0, 0};                                  // everything left of this pass (wave-uniform)
-    int buf = 0;
-    for (int x0 = 0; x0 < cols; x0 += nw * 64 * kSatGroups, buf ^= 1) {
-        const int xs = x0 + w * 64 * kSatGroups + lane;
-        uint32_t v[kSatGroups][3];
+// the twelve bytes of pixels x .. x+3 of an image row as three dwords (zero beyond `cols`); VEC: the row is 4-byte aligned
+struct raw12 { uint32_t w0, w1, w2; };
+template <bool VEC>
+__device__ __forceinline__ raw12 load_raw(const uint8_t *__restrict__ row, int x, int cols) {
+    raw12 v;
+    if (VEC && x + 3 < cols) {
+        const uint32_t *q = (const uint32_t *)(row + 3 * (size_t)x);
+        v.w0 = q[0]; v.w1 = q[1]; v.w2 = q[2];
+    } else {
+        uint32_t w[3] = {0, 0, 0};
+        const int n = 3 * min(max(cols - x, 0), 4);
+        const uint8_t *q = row + 3 * (size_t)x;
 #pragma unroll
-        for (int g = 0; g < kSatGroups; g++) {
-            const int x = xs + 64 * g;
-#pragma unroll
-            for (int c = 0; c < 3; c++) v[g][c] = x < cols ? o[3 * (size_t)x + c] : 0u;
-        }
-        uint32_t run[3] = {0, 0, 0};                                // groups of this wave so far (wave-uniform)
-#pragma unroll
-        for (int g = 0; g < kSatGroups; g++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                v[g][c] = wave_incl_scan(v[g][c]) + run[c];
-                run[c] = (uint32_t)__builtin_amdgcn_readlane((int)v[g][c], 63);
-            }
-        if (lane == 0) { seg[buf][w][0] = run[0]; seg[buf][w][1] = run[1]; seg[buf][w][2] = run[2]; }
-        __syncthreads();                                            // (seg is double buffered: one barrier per pass)
-        uint32_t add[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            uint32_t before = 0, all = 0;
-            for (int k = 0; k < nw; k++) { const uint32_t t = seg[buf][k][c]; all += t; if (k < w) before += t; }
-            add[c] = carry[c] + before;
-            carry[c] += all;
-        }
-#pragma unroll
-        for (int g = 0; g < kSatGroups; g++) {
-            const int x = xs + 64 * g;
-            if (x < cols) st3(lrow + x + 1, v[g][0] + add[0], v[g][1] + add[1], v[g][2] + add[2]);
-        }
+        for (int i = 0; i < 12; i++) if (i < n) w[i >> 2] |= (uint32_t)q[i] << (8 * (i & 3));
+        v.w0 = w[0]; v.w1 = w[1]; v.w2 = w[2];
     }
-    if (y == 0) for (int i = threadIdx.x; i <= cols; i += (int)blockDim.x) st3(L + i, 0, 0, 0);
-}
-
-// pass 2: column prefix inside each band of kBand rows, in place; band totals -> tot[band][c]
-__global__ __launch_bounds__(256) void k_sat_bands(u3 *__restrict__ L, u3 *__restrict__ tot, int rows, int width) {
-    const int c = blockIdx.x * 256 + threadIdx.x, band = blockIdx.y;
-    if (c >= width) return;
-    const int ra = band * kBand + 1, rb = min(ra + kBand, rows + 1);
-    uint32_t a0 = 0, a1 = 0, a2 = 0;
-    u3 *p = L + (size_t)ra * width + c;
-    int r = ra;
-    for (; r + 4 <= rb; r += 4) {                                   // 4 independent loads in flight
-        const u3 a = ld3(p), b = ld3(p + (size_t)width), cc = ld3(p + (size_t)2 * width), d = ld3(p + (size_t)3 * width);
-        a0 += a.x; a1 += a.y; a2 += a.z; st3(p, a0, a1, a2);
-        a0 += b.x; a1 += b.y; a2 += b.z; st3(p + (size_t)width, a0, a1, a2);
-        a0 += cc.x; a1 += cc.y; a2 += cc.z; st3(p + (size_t)2 * width, a0, a1, a2);
-        a0 += d.x; a1 += d.y; a2 += d.z; st3(p + (size_t)3 * width, a0, a1, a2);
-        p += (size_t)4 * width;
-    }
-    for (; r < rb; r++) { const u3 a = ld3(p); a0 += a.x; a1 += a.y; a2 += a.z; st3(p, a0, a1, a2); p += width; }
-    st3(tot + (size_t)band * width + c, a0, a1, a2);
-}
-
-// pass 3: base[b][c] = sum of the totals of bands < b (in place on tot); 8 loads in flight per step
-__global__ __launch_bounds__(256) void k_sat_base(u3 *__restrict__ tot, int nbands, int width) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= width) return;
-    uint32_t a0 = 0, a1 = 0, a2 = 0;
-    for (int b0 = 0; b0 < nbands; b0 += 8) {
-        u3 t[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) if (b0 + j < nbands) t[j] = ld3(tot + (size_t)(b0 + j) * width + c);
-#pragma unroll
-        for (int j = 0; j < 8; j++) if (b0 + j < nbands) { st3(tot + (size_t)(b0 + j) * width + c, a0, a1, a2); a0 += t[j].x; a1 += t[j].y; a2 += t[j].z; }
-    }
-}
-
-__device__ __forceinline__ u3 sat_at(const u3 *__restrict__ L, const u3 *__restrict__ base, int width, int r, int c) {
-    u3 v; v.x = 0; v.y = 0; v.z = 0;
-    if (r == 0) return v;
-    const u3 a = ld3(L + (size_t)r * width + c), b = ld3(base + (size_t)((r - 1) / kBand) * width + c);
-    v.x = a.x + b.x; v.y = a.y + b.y; v.z = a.z + b.z;
     return v;
 }
 
-// simulateDefocus (K9) -- src/GPUDepthEffect.cu:29-72
-__global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ orig, size_t op, const float *__restrict__ depth, size_t dp,
-                                                 const u3 *__restrict__ L, const u3 *__restrict__ base, uint8_t *__restrict__ art, size_t ap,
-                                                 int rows, int cols, int kernelSize) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    const float d = ((const float *)((const char *)depth + (size_t)y * dp))[x];
-    const double kd = (double)((float)kernelSize * d) / 255.0;      // :43  int*float -> float, / double
-    int k;                                                          // (int) of a double: define the UB cases
-    if (!(kd > -2147483648.0)) k = 0; else if (kd >= 2147483647.0) k = 2147483647; else k = (int)kd;
-    const int h = k / 2;                                            // C division truncates toward zero
-    const int ya = max(y - h, 0), yb = min(y + h, rows);
-    const int xa = max(x - h, 0), xb = min(x + h, cols);
-    const uint8_t *o = orig + (size_t)y * op + 3 * x;
-    uint8_t *a = art + (size_t)y * ap + 3 * x;
-    if (h <= 0 || yb <= ya || xb <= xa) {                           // count == 0 (:62-66)
-        a[0] = o[0]; a[1] = o[1]; a[2] = o[2];
-        return;
+#define RTDD_DPP64(src, ctrl, rows, banks)                                                                       \
+    (((u64)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((src) >> 32), ctrl, rows, banks, true) << 32) | \
+     (u64)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(src), ctrl, rows, banks, true))
+
+// inclusive prefix sum of a 64-bit value over the 64 lanes of a wave (the 7-step DPP scan: VALU only)
+__device__ __forceinline__ u64 wave_incl_scan64(u64 v) {
+    u64 t = v + RTDD_DPP64(v, 0x111, 0xF, 0xF);         // row_shr:1
+    t += RTDD_DPP64(v, 0x112, 0xF, 0xF);                // row_shr:2
+    t += RTDD_DPP64(v, 0x113, 0xF, 0xF);                // row_shr:3   -> v[i-3..i] within a row of 16
+    t += RTDD_DPP64(t, 0x114, 0xF, 0xE);                // row_shr:4, banks 1-3
+    t += RTDD_DPP64(t, 0x118, 0xF, 0xC);                // row_shr:8, banks 2-3  -> prefix within each row of 16
+    t += RTDD_DPP64(t, 0x142, 0xA, 0xF);                // row_bcast:15 into rows 1 and 3
+    t += RTDD_DPP64(t, 0x143, 0xC, 0xF);                // row_bcast:31 into rows 2 and 3
+    return t;
+}
+// ... over the 16 lanes of each DPP row only (the wave totals of a workgroup: at most 16)
+__device__ __forceinline__ u64 row16_incl_scan64(u64 v) {
+    u64 t = v + RTDD_DPP64(v, 0x111, 0xF, 0xF);
+    t += RTDD_DPP64(v, 0x112, 0xF, 0xF);
+    t += RTDD_DPP64(v, 0x113, 0xF, 0xF);
+    t += RTDD_DPP64(t, 0x114, 0xF, 0xE);
+    t += RTDD_DPP64(t, 0x118, 0xF, 0xC);
+    return t;
+}
+__device__ __forceinline__ u64 readlane64(u64 v, int lane) {
+    return ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32) | (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+}
+
+struct alignas(16) u64x2 { u64 a, b; };
+
+// pass 1: colsum[band][x] = packed sum of the pixels of column x in rows [band*RB, band*RB + RB).  A thread owns four columns;
+// eight rows of loads are in flight at a time.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_sat_colsum(const uint8_t *__restrict__ orig, size_t op, u64 *__restrict__ colsum, int tp, int rows, int cols, int RB) {
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, band = blockIdx.y;
+    if (x >= tp) return;
+    const int ra = band * RB, rb = min(ra + RB, rows);
+    u64 s[4] = {0, 0, 0, 0};
+    for (int r = ra; r < rb; r += 8) {
+        raw12 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = load_raw<VEC>(orig + (size_t)min(r + i, rb - 1) * op, x, cols);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            u64 px[4];
+            unpack4(v[i].w0, v[i].w1, v[i].w2, px);
+            if (r + i < rb) { s[0] += px[0]; s[1] += px[1]; s[2] += px[2]; s[3] += px[3]; }
+        }
     }
-    const float count = (float)((yb - ya) * (xb - xa));
-    const int width = cols + 1;
-    const u3 s00 = sat_at(L, base, width, ya, xa), s01 = sat_at(L, base, width, ya, xb);
-    const u3 s10 = sat_at(L, base, width, yb, xa), s11 = sat_at(L, base, width, yb, xb);
-    // exact: the true window sum is < 2^24, so mod-2^32 arithmetic and the f32 conversion lose nothing (:68-70)
-    a[0] = (uint8_t)store_u8((float)(s11.x - s01.x - s10.x + s00.x) / count);
-    a[1] = (uint8_t)store_u8((float)(s11.y - s01.y - s10.y + s00.y) / count);
-    a[2] = (uint8_t)store_u8((float)(s11.z - s01.z - s10.z + s00.z) / count);
+    u64x2 *out = (u64x2 *)(colsum + (size_t)band * tp + x);
+    out[0] = u64x2{s[0], s[1]}; out[1] = u64x2{s[2], s[3]};
+}
+
+// pass 2: in place, colsum[band][x] -> sum of colsum[b][x] over b < band.  One workgroup per 64 columns (lane = column); its waves
+// split the bands (at most kScanChunk each, all loads in flight), trade totals through LDS, and write their share's exclusive prefixes.
+constexpr int kScanChunk = 32;
+__global__ __launch_bounds__(1024) void k_sat_colbase(u64 *__restrict__ colsum, int tp, int nbands) {
+    __shared__ u64 tot[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    const int x = min(blockIdx.x * 64 + lane, tp - 1);             // (the last workgroup's spare lanes repeat column tp-1: same values, same stores)
+    const int chunk = min((nbands + nw - 1) / nw, kScanChunk);      // bands per wave and round
+    u64 carry = 0;                                                  // bands before this round of nw * chunk
+    for (int b0 = 0; b0 < nbands; b0 += nw * chunk) {
+        const int ba = min(b0 + w * chunk, nbands), bb = min(ba + chunk, nbands);
+        u64 v[kScanChunk], sum = 0;
+#pragma unroll
+        for (int i = 0; i < kScanChunk; i++) v[i] = ba + i < bb ? colsum[(size_t)(ba + i) * tp + x] : 0ull;
+#pragma unroll
+        for (int i = 0; i < kScanChunk; i++) sum += v[i];
+        __syncthreads();                                            // (tot may still be read from the round before)
+        tot[w][lane] = sum;
+        __syncthreads();
+        u64 run = carry, all = 0;
+        for (int k = 0; k < nw; k++) { const u64 t = tot[k][lane]; all += t; if (k < w) run += t; }
+        carry += all;
+#pragma unroll
+        for (int i = 0; i < kScanChunk; i++) if (ba + i < bb) { colsum[(size_t)(ba + i) * tp + x] = run; run += v[i]; }
+    }
+}
+
+// pass 3: the table.  Workgroup = band of RB rows x the full row width, 4 consecutive pixels per thread (so a wave covers 256
+// pixels and rows up to 4096 pixels need ONE sweep of the row; wider rows loop over column ranges with a per-row carry in LDS).
+// Four rows at a time, the next four rows' loads already in flight: running column sums col[j] (they start at the band's base),
+// in-thread prefix over the 4 pixels, 64-bit wave scan of the thread totals, wave totals to LDS, ONE barrier, prefix of the <= 16
+// wave totals by a 16-lane scan, two aligned 16-byte stores per row.
+template <bool VEC>
+__global__ __launch_bounds__(1024) void k_sat_build(const uint8_t *__restrict__ orig, size_t op, const u64 *__restrict__ colbase, u64 *__restrict__ T,
+                                                    int tp, int rows, int cols, int RB) {
+    __shared__ u64 wtot[2][4][16];                                  // [buffer][row of the group of four][wave]
+    __shared__ u64 rowcarry[2][32];                                 // [parity of the column range][row of the band]: everything left of the range
+    const int tid = threadIdx.x, lane = tid & 63, nt = (int)blockDim.x, nw = nt >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int band = blockIdx.x, r0 = band * RB;
+    if (tid < 64) rowcarry[tid >> 5][tid & 31] = 0;
+    __syncthreads();
+    int buf = 0, par = 0;
+    for (int x0 = 0; x0 < cols; x0 += nt * 4, par ^= 1) {
+        const int x = x0 + tid * 4;
+        u64 col[4] = {0, 0, 0, 0};
+        raw12 nxt[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) nxt[i] = load_raw<VEC>(orig + (size_t)min(r0 + i, rows - 1) * op, x, cols);
+        if (x < tp) {
+            const u64x2 *q = (const u64x2 *)(colbase + (size_t)band * tp + x);
+            const u64x2 a = q[0], b = q[1];
+            col[0] = a.a; col[1] = a.b; col[2] = b.a; col[3] = b.b;
+        }
+        for (int sub = 0; sub < RB; sub += 4, buf ^= 1) {
+            raw12 cur[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) cur[i] = nxt[i];
+            if (sub + 4 < RB) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) nxt[i] = load_raw<VEC>(orig + (size_t)min(r0 + sub + 4 + i, rows - 1) * op, x, cols);
+            }
+            u64 s[4][4], excl[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                u64 px[4];
+                unpack4(cur[i].w0, cur[i].w1, cur[i].w2, px);
+                if (r0 + sub + i < rows) {                          // (rows past the image: never stored; the band ends with them)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) col[j] += px[j];
+                }
+                s[i][0] = col[0]; s[i][1] = s[i][0] + col[1]; s[i][2] = s[i][1] + col[2]; s[i][3] = s[i][2] + col[3];
+                const u64 incl = wave_incl_scan64(s[i][3]);
+                excl[i] = incl - s[i][3];
+                if (lane == 63) wtot[buf][i][w] = incl;             // the wave's total of row i
+            }
+            __syncthreads();
+            // lanes 16 i .. 16 i + 15 take row i's wave totals: ONE 16-lane scan serves the four rows
+            const u64 t = (lane & 15) < nw ? wtot[buf][lane >> 4][lane & 15] : 0;
+            const u64 inc = row16_incl_scan64(t), exc = inc - t;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = r0 + sub + i;
+                const u64 before = readlane64(exc, 16 * i + w), all = readlane64(inc, 16 * i + nw - 1);
+                const u64 left = rowcarry[par][sub + i];
+                const u64 add = left + before + excl[i];
+                if (r < rows && x < tp) {
+                    u64x2 *q = (u64x2 *)(T + (size_t)r * tp + x);
+                    q[0] = u64x2{s[i][0] + add, s[i][1] + add}; q[1] = u64x2{s[i][2] + add, s[i][3] + add};
+                }
+                if (tid == 0) rowcarry[par ^ 1][sub + i] = left + all;   // read again only after the next barrier
+            }
+        }
+    }
+}
+
+// T(r, c) with T(-1, .) = T(., -1) = 0
+__device__ __forceinline__ u64 sat_at(const u64 *__restrict__ T, int tp, int r, int c) {
+    const u64 v = T[(uint32_t)(max(r, 0) * tp + max(c, 0))];
+    return (r < 0 || c < 0) ? 0ull : v;
+}
+
+// k / 2 of  int k = kernelSize * depth / 255.0  (src/GPUDepthEffect.cu:43: int * float -> float, / double, truncation), without the
+// f64 divide.  v = (float)kernelSize * depth is an f32, so the double quotient v / 255.0 never rounds across an integer (a non-integer
+// exact quotient is at least 2^-24 relative away from one, the rounding error is 2^-53) and (int) of it is floor(v / 255) exactly:
+// q0 = v * (1/255) is within 1 of it, the remainder v - 255 k0 is exact in f32 for v >= 256, one correction step.  v < 510 (k < 2),
+// negative and NaN products give a half-width <= 0: the reference's loops do not run and the pixel is copied (0 returned here).
+// Products beyond 255 * 2^22 are clamped: any k/2 >= max(rows, cols) selects the whole (clipped) image anyway.
+__device__ __forceinline__ int half_window(int kernelSize, float d) {
+    float v = (float)kernelSize * d;
+    if (!(v >= 510.0f)) return 0;
+    v = fminf(v, 1069547520.0f);                                    // 255 * 2^22
+    int k = (int)(v * (1.0f / 255.0f));
+    const float r = __builtin_fmaf(-255.0f, (float)k, v);           // exact
+    k += r < 0.0f ? -1 : (r >= 255.0f ? 1 : 0);
+    return k >> 1;
+}
+
+// (uchar)(sum / count) of src/GPUDepthEffect.cu:68-70 (f32 divide, truncation) for an exact integer sum s < 2^24 and count < 2^16: a
+// non-integer quotient <= 255 is at least 1/count > 2^-16 below the next integer, more than the f32 half-ulp 2^-17 there, so the
+// rounded quotient truncates to floor(s / count) -- computed with the shared reciprocal and one exact integer correction.
+__device__ __forceinline__ uint32_t quot_u8(uint32_t s, uint32_t count, float rc) {
+    int n = (int)((float)s * rc);
+    const int rem = (int)s - n * (int)count;
+    n += rem < 0 ? -1 : (rem >= (int)count ? 1 : 0);
+    return (uint32_t)min(n, 255);
+}
+
+// simulateDefocus (K9) -- src/GPUDepthEffect.cu:29-72.  Lane = pixel, wave = 64 pixels of one row, workgroup = 64 x 8 pixels (each
+// wave two rows: their depth loads, then their 8 corner loads are all in flight before any is used; measured 4K smooth depth
+// 50.8 / 48.2 / 55.7 / 75.0 us for 1 / 2 / 4 / 8 rows per wave -- the kernel is bound by the lines its gathers pull from L2, and a
+// wave that spreads over more rows keeps fewer of them in L1 between its left- and right-corner loads).  Workgroups are numbered so
+// that each XCD (dispatch: workgroup p -> XCD p % 8) takes a contiguous band of tile rows: its L2 then holds one eighth of the table
+// plus the rows a window reaches beyond it.  `orig` and `art` move as dwords: the three dwords of a quad of pixels are loaded / stored
+// by its first three lanes and re-cut into pixels with one quad-permute each (VEC: rows 4-byte aligned; otherwise, and in a ragged
+// last tile, bytes).
+#ifndef RTDD_DEFOCUS_ROWS
+#define RTDD_DEFOCUS_ROWS 2
+#endif
+constexpr int kDefocusRows = RTDD_DEFOCUS_ROWS;                     // rows per wave
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ orig, size_t op, const float *__restrict__ depth, size_t dp,
+                                                 const u64 *__restrict__ T, int tp, uint8_t *__restrict__ art, size_t ap,
+                                                 int rows, int cols, int kernelSize, int gx, int ntiles, int xcd_tiles) {
+    const int p = blockIdx.x;
+    const int tile = xcd_tiles > 0 ? (p & 7) * xcd_tiles + (p >> 3) : p;
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = (tile % gx) * 64, x = x0 + lane, xc = min(x, cols - 1);
+    const int yw = (tile / gx) * (4 * kDefocusRows) + wv * kDefocusRows;
+    const bool whole = VEC && x0 + 64 <= cols;                      // wave-uniform: the dword path
+    const int j = lane & 3;
+    float d[kDefocusRows];
+    uint32_t opx[kDefocusRows];                                     // this pixel's B | G << 8 | R << 16
+#pragma unroll
+    for (int i = 0; i < kDefocusRows; i++) {
+        const int y = min(yw + i, rows - 1);
+        d[i] = ((const float *)((const char *)depth + (size_t)y * dp))[xc];
+        const uint8_t *orow = orig + (size_t)y * op;
+        if (whole) {
+            const uint32_t L = j < 3 ? ((const uint32_t *)(orow + 3 * (size_t)x0))[3 * (lane >> 2) + j] : 0u;
+            const uint32_t prv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x90, 0xF, 0xF, true);   // quad_perm:[0,0,1,2]
+            opx[i] = __builtin_amdgcn_alignbit(L, prv, (32 - 8 * j) & 31) & 0xFFFFFFu;
+        } else {
+            const uint8_t *o = orow + 3 * (size_t)xc;
+            opx[i] = o[0] | (o[1] << 8) | (o[2] << 16);
+        }
+    }
+    int ya[kDefocusRows], yb[kDefocusRows], xa[kDefocusRows], xb[kDefocusRows];
+    u64 c00[kDefocusRows], c01[kDefocusRows], c10[kDefocusRows], c11[kDefocusRows];
+#pragma unroll
+    for (int i = 0; i < kDefocusRows; i++) {
+        const int y = min(yw + i, rows - 1);
+        const int h = half_window(kernelSize, d[i]);
+        ya[i] = max(y - h, 0); yb[i] = (int)min((long long)y + h, (long long)rows);
+        xa[i] = max(xc - h, 0); xb[i] = (int)min((long long)xc + h, (long long)cols);
+        // a window too large for one lookup fetches its first strip's corners here (the rest below); h == 0 fetches T(y-1, x-1) four times
+        c00[i] = sat_at(T, tp, ya[i] - 1, xa[i] - 1); c01[i] = sat_at(T, tp, ya[i] - 1, xb[i] - 1);
+        c10[i] = sat_at(T, tp, yb[i] - 1, xa[i] - 1); c11[i] = sat_at(T, tp, yb[i] - 1, xb[i] - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < kDefocusRows; i++) {
+        const int y = yw + i;
+        uint32_t res = opx[i];                                      // count == 0 (:62-66): the pixel itself
+        const int wd = xb[i] - xa[i], ht = yb[i] - ya[i];
+        if (wd > 0 && ht > 0) {
+            const uint32_t cnt = (uint32_t)ht * (uint32_t)wd;
+            uint32_t sb, sg, sr;
+            if (cnt <= (uint32_t)kSatMaxArea) {                     // every nominal window up to 2560x1440, most beyond
+                const u64 X = c11[i] - c10[i] - c01[i] + c00[i];
+                sb = (uint32_t)(X & kSatFieldMask); sg = (uint32_t)((X >> 21) & kSatFieldMask); sr = (uint32_t)(X >> 42);
+            } else {                                                // strips of <= kSatMaxArea pixels (columns too, should a row be wider)
+                sb = sg = sr = 0;
+                const int cw = min(wd, kSatMaxArea), rh = max(kSatMaxArea / cw, 1);
+                for (int xs = xa[i]; xs < xb[i]; xs += cw) {
+                    const int xe = min(xs + cw, xb[i]);
+                    u64 D0 = sat_at(T, tp, ya[i] - 1, xe - 1) - sat_at(T, tp, ya[i] - 1, xs - 1);
+                    for (int ys = ya[i]; ys < yb[i]; ys += rh) {
+                        const int ye = min(ys + rh, yb[i]);
+                        const u64 D1 = sat_at(T, tp, ye - 1, xe - 1) - sat_at(T, tp, ye - 1, xs - 1);
+                        const u64 X = D1 - D0;
+                        sb += (uint32_t)(X & kSatFieldMask); sg += (uint32_t)((X >> 21) & kSatFieldMask); sr += (uint32_t)(X >> 42);
+                        D0 = D1;
+                    }
+                }
+            }
+            if (cnt < 65536u && (sb | sg | sr) < (1u << 24)) {      // nominal: exact sums, exact integer quotients (quot_u8)
+                const float rc = __builtin_amdgcn_rcpf((float)cnt);
+                res = quot_u8(sb, cnt, rc) | (quot_u8(sg, cnt, rc) << 8) | (quot_u8(sr, cnt, rc) << 16);
+            } else {                                                // (an out-of-range depth: the reference's own f32 sums round here)
+                const float count = (float)cnt;
+                res = store_u8((float)sb / count) | (store_u8((float)sg / count) << 8) | (store_u8((float)sr / count) << 16);
+            }
+        }
+        if (y < rows) {                                             // wave-uniform
+            uint8_t *arow = art + (size_t)y * ap;
+            if (whole) {
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)res, 0xF9, 0xF, 0xF, true);   // quad_perm:[1,2,3,3]
+                const uint32_t out = (res >> (8 * j)) | (nxt << ((24 - 8 * j) & 31));
+                if (j < 3) ((uint32_t *)(arow + 3 * (size_t)x0))[3 * (lane >> 2) + j] = out;
+            } else if (x < cols) {
+                uint8_t *a = arow + 3 * (size_t)x;
+                a[0] = (uint8_t)res; a[1] = (uint8_t)(res >> 8); a[2] = (uint8_t)(res >> 16);
+            }
+        }
+    }
 }
 
 static inline dim3 grid64x4(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
@@ -286,24 +463,37 @@ int launch_haze(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *dept
 }
 
 int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *depth, size_t dp, uint8_t *art, size_t ap, int rows, int cols) {
-    const int width = cols + 1, nbands = (rows + kBand - 1) / kBand;
-    const size_t need = ((size_t)(rows + 1) * width + (size_t)nbands * width) * 3 + 16;     // in u32 words (3-word entries)
+    const int tp = (cols + 3) / 4 * 4;                                  // table row pitch in entries: 32-byte aligned groups of four
+    // band height: one workgroup per band builds the table, so enough bands to occupy the chip (270 / 135 / 135 workgroups of 8 / 16 / 16
+    // waves at 1080p / 4K / 8K); a band costs 8 B per column three times over (colsum, its scan, the build's read)
+    static const int rb_env = getenv("RTDD_DEFOCUS_BAND") ? atoi(getenv("RTDD_DEFOCUS_BAND")) : 0;
+    const int RB = rb_env >= 4 && rb_env <= 32 && rb_env % 4 == 0 ? rb_env : rows <= 1536 ? 4 : rows <= 3072 ? 16 : 32;
+    const int nbands = (rows + RB - 1) / RB;
+    const size_t need = (((size_t)rows + nbands) * tp * sizeof(u64) + 256) / sizeof(uint32_t);   // table + band bases, in u32 words
     if (ctx->sat_elems < need) {
         if (ctx->sat) { RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream)); RTDD_HIP(ctx, hipFree(ctx->sat)); ctx->sat = nullptr; ctx->sat_elems = 0; }
         RTDD_HIP(ctx, hipMalloc((void **)&ctx->sat, need * sizeof(uint32_t)));
         ctx->sat_elems = need;
     }
-    u3 *L = (u3 *)ctx->sat, *base = L + (size_t)(rows + 1) * width;
+    u64 *T = (u64 *)ctx->sat, *base = T + (size_t)rows * tp;
     const int kernelSize = 0.025 * sqrtf(rows * rows + cols * cols);    // :42, evaluated once on the host (sqrtf is correctly rounded on both)
-    int sat_waves = (cols + 64 * kSatGroups - 1) / (64 * kSatGroups);      // one wave per 512-pixel segment, at most 16
-    if (sat_waves > 16) sat_waves = 16;
-    hipLaunchKernelGGL(k_sat_rows, dim3(rows), dim3(64 * sat_waves), 0, ctx->stream, orig, op, L, rows, cols);
-    RTDD_LAUNCH_CHECK(ctx, "k_sat_rows");
-    hipLaunchKernelGGL(k_sat_bands, dim3((width + 255) / 256, nbands), dim3(256), 0, ctx->stream, L, base, rows, width);
-    RTDD_LAUNCH_CHECK(ctx, "k_sat_bands");
-    hipLaunchKernelGGL(k_sat_base, dim3((width + 255) / 256), dim3(256), 0, ctx->stream, base, nbands, width);
-    RTDD_LAUNCH_CHECK(ctx, "k_sat_base");
-    hipLaunchKernelGGL(k_defocus, grid64x4(rows, cols), dim3(256), 0, ctx->stream, orig, op, depth, dp, L, base, art, ap, rows, cols, kernelSize);
+    const bool vin = (uintptr_t)orig % 4 == 0 && op % 4 == 0, vout = vin && (uintptr_t)art % 4 == 0 && ap % 4 == 0;
+    const dim3 g1((tp / 4 + 255) / 256, nbands);
+    if (vin) hipLaunchKernelGGL(k_sat_colsum<true>, g1, dim3(256), 0, ctx->stream, orig, op, base, tp, rows, cols, RB);
+    else hipLaunchKernelGGL(k_sat_colsum<false>, g1, dim3(256), 0, ctx->stream, orig, op, base, tp, rows, cols, RB);
+    RTDD_LAUNCH_CHECK(ctx, "k_sat_colsum");
+    int scan_waves = (nbands + 3) / 4; if (scan_waves > 16) scan_waves = 16;
+    hipLaunchKernelGGL(k_sat_colbase, dim3((tp + 63) / 64), dim3(64 * scan_waves), 0, ctx->stream, base, tp, nbands);
+    RTDD_LAUNCH_CHECK(ctx, "k_sat_colbase");
+    int build_waves = (tp / 4 + 63) / 64; if (build_waves > 16) build_waves = 16;
+    if (vin) hipLaunchKernelGGL(k_sat_build<true>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, orig, op, base, T, tp, rows, cols, RB);
+    else hipLaunchKernelGGL(k_sat_build<false>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, orig, op, base, T, tp, rows, cols, RB);
+    RTDD_LAUNCH_CHECK(ctx, "k_sat_build");
+    const int gx = (cols + 63) / 64, gy = (rows + 4 * kDefocusRows - 1) / (4 * kDefocusRows), ntiles = gx * gy;
+    const int xcd_tiles = ntiles >= 64 ? (ntiles + 7) / 8 : 0;
+    const dim3 g4(xcd_tiles > 0 ? 8 * xcd_tiles : ntiles);
+    if (vout) hipLaunchKernelGGL(k_defocus<true>, g4, dim3(256), 0, ctx->stream, orig, op, depth, dp, T, tp, art, ap, rows, cols, kernelSize, gx, ntiles, xcd_tiles);
+    else hipLaunchKernelGGL(k_defocus<false>, g4, dim3(256), 0, ctx->stream, orig, op, depth, dp, T, tp, art, ap, rows, cols, kernelSize, gx, ntiles, xcd_tiles);
     RTDD_LAUNCH_CHECK(ctx, "k_defocus");
     return RTDD_OK;
 }

@@ -56,6 +56,7 @@ struct Options {
     int auto_sweep_floor_ns = 2500;      // ... but never below one launch-bound sweep
     int debug_withhold_tile = 0;     // RTDD_OPT_DEBUG_WITHHOLD_TILE: tile number + 1 whose exchange flag is never published (0 = off)
     int debug_poll_limit_us = 0;     // RTDD_OPT_DEBUG_POLL_LIMIT_US: exchange poll limit (0 = default, 200 ms)
+    int debug_force_status = 0;      // RTDD_OPT_DEBUG_FORCE_STATUS: one-shot value for the status word behind the next blocked launch
 };
 
 }  // namespace rtdd
@@ -78,7 +79,8 @@ struct rtdd_ctx {
     int *sync_words = nullptr;      // control words of the persistent kernels (persist_sync.hpp); allocated with the context
     int sync_header[2] = {0, 0};    // what sync_words[kSyncWithhold], [kSyncLimit] currently hold on the device
     rtdd_solve_info last_info{};    // of the most recent solve; kernel/tile/temporal_depth/persistent are filled in by the sweep launchers
-    bool persistent_used = false;   // a persistent launch happened since the last status check
+    bool persistent_used = false;   // a launch that can set the status word (sync_words[kSyncStatus]) happened since the last status check
+    signed char persist_fit[16][2];  // per (tile id, contraction): does one workgroup of the persistent kernel fit a CU of THIS device (-1 = not asked yet)
     uint32_t *sat = nullptr;        // defocus summed-area table scratch
     size_t sat_elems = 0;
     int num_cus = 256;

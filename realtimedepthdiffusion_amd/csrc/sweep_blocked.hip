@@ -722,9 +722,10 @@ static bool fits_one_per_cu(K kernel, int nthreads) {
 }
 
 template <int LX, int NT, int G>
-static bool persistent_possible(const rtdd_ctx *ctx, int nthreads) {
-    static int cache[2] = {-1, -1};
-    int &c = cache[ctx->opt.fp_contract ? 1 : 0];
+static bool persistent_possible(rtdd_ctx *ctx, int tile, int nthreads) {
+    // the answer is a property of (device, kernel): cached in the context, which belongs to one device and is driven by one host
+    // thread at a time (include/rtdd.h) -- not in a function-local static shared by every context and thread
+    signed char &c = ctx->persist_fit[tile][ctx->opt.fp_contract ? 1 : 0];
     if (c < 0) c = ctx->opt.fp_contract ? fits_one_per_cu(k_sweep_blocked<LX, NT, G, true, true>, nthreads) : fits_one_per_cu(k_sweep_blocked<LX, NT, G, false, true>, nthreads);
     return c == 1;
 }
@@ -873,7 +874,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
                                 hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
         if (tile == 14) persistent = false;                 // (the column-layout kernel has no persistent mode)
         if (persistent) {
-#define RTDD_TILE_CASE(id, LX_, NT_, G_) case id: persistent = persistent_possible<LX_, NT_, G_>(ctx, kTiles[tile].nt); break;
+#define RTDD_TILE_CASE(id, LX_, NT_, G_) case id: persistent = persistent_possible<LX_, NT_, G_>(ctx, tile, kTiles[tile].nt); break;
             switch (tile) { RTDD_ALL_TILES }
 #undef RTDD_TILE_CASE
         }
@@ -898,10 +899,16 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
             if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
             else hipLaunchKernelGGL(k_sweep_col<false>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
-            ctx->persistent_used = true;          // (so that the next synchronising call reads the status word)
         } else
         switch (tile) { RTDD_ALL_TILES }
 #undef RTDD_TILE_CASE
+        // every blocked launch can set the status word (the bounded wait of a wave for its neighbour waves, status 2, exists in
+        // the launch-per-block instantiation too): the next synchronising call must read it whatever the mode
+        ctx->persistent_used = true;
+        if (ctx->opt.debug_force_status) {                          // testing aid (include/rtdd.h): as if a wave of this launch had given up
+            RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncStatus), ctx->opt.debug_force_status, 1, ctx->stream));
+            ctx->opt.debug_force_status = 0;
+        }
         ctx->last_info.kernel = 2; ctx->last_info.tile = tile; ctx->last_info.temporal_depth = persistent ? block_sweeps : m; ctx->last_info.persistent = persistent ? 1 : 0;
         // where the results are: the plain launch writes the spare pair; the persistent one the exchange buffer of its
         // last block's parity (blocks 0,2,.. -> spare pair, 1,3,.. -> the input pair)

@@ -147,8 +147,59 @@ def make_full(name="Dog"):
     print(name, "full size", bgr.shape, "levels", c.P, "labels", np.unique(ann[ann != 32]))
 
 
+def make_dataset():
+    """ALL twelve bundled pairs at their own resolution (src/main.cpp:93-113,160-173,232-295 run on dataset/images +
+    dataset/annotations).  Stored DECODED and lossless -- tests/golden/dataset/<name>.png (RGB pixels as the JPEG decoder of
+    the authoring container produced them) and <name>_ann.png (channel 0 of the annotation; R = G = B in all twelve) -- so
+    JPEG decoder differences cannot leak in.  Inputs only; of the oracle's outputs the manifest keeps sha256 hashes (every
+    level's depth in both contraction variants, the u8 map, the three effects), which the GPU test re-derives on the box."""
+    import json
+    from cascade_ref import Cascade
+    oracle.build()
+    lut = oracle.load_weights(0.4)
+    out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dataset")
+    os.makedirs(out_dir, exist_ok=True)
+    manifest = {}
+    for f in sorted(os.listdir(f"{REF}/images")):
+        if not f.endswith(".jpg"):
+            continue
+        name = f[:-4]
+        rgb = np.array(Image.open(f"{REF}/images/{name}.jpg").convert("RGB"))
+        ann3 = np.array(Image.open(f"{REF}/annotations/{name}.png").convert("RGB"))
+        assert (ann3[..., 0] == ann3[..., 1]).all() and (ann3[..., 0] == ann3[..., 2]).all() and ann3.shape == rgb.shape
+        ann = np.ascontiguousarray(ann3[..., 0])
+        Image.fromarray(rgb, "RGB").save(os.path.join(out_dir, f"{name}.png"), optimize=True)
+        Image.fromarray(ann, "L").save(os.path.join(out_dir, f"{name}_ann.png"), optimize=True)
+        bgr = np.ascontiguousarray(rgb[..., ::-1])
+        entry = {"rows": int(rgb.shape[0]), "cols": int(rgb.shape[1]), "labels": [int(v) for v in np.unique(ann[ann != 32])],
+                 "coverage": float((ann != 32).mean()), "rgb_sha": sha(rgb), "annotation_sha": sha(ann)}
+        for contract in (1, 0):
+            c = Cascade(oracle, bgr, ann, lut, contract, threads=8)
+            c.estimate(1000)
+            entry["levels"] = c.P
+            entry["sizes"] = [list(s) for s in c.size]
+            entry["gray_sizes"] = [list(g.shape) for g in c.gray]
+            entry[f"depth_sha_c{contract}"] = [sha(c.depth[l]) for l in range(c.P)]
+            entry[f"depth_u8_sha_c{contract}"] = sha(c.depth_u8)
+            if contract == 1:
+                entry["gray_sha"] = [sha(g) for g in c.gray]
+                entry["desaturate_sha"] = sha(oracle.desaturate(bgr, c.gray[0], c.depth[0], 1))
+                entry["haze_sha"] = sha(oracle.haze(bgr, c.depth[0], 1))
+                entry["defocus_sha"] = sha(oracle.defocus(bgr, c.depth[0], threads=8))
+                first = c.depth[0].copy()
+            else:
+                entry["spread_c0_c1_level0"] = float(np.abs(first - c.depth[0]).max())
+        manifest[name] = entry
+        print(name, entry["rows"], entry["cols"], "levels", entry["levels"], "sizes", entry["sizes"], "gray", entry["gray_sizes"])
+    with open(os.path.join(out_dir, "manifest.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--full":
+    if len(sys.argv) > 1 and sys.argv[1] == "--dataset":
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        make_dataset()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--full":
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
         make_full(*sys.argv[2:])
     else:

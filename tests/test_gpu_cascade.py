@@ -111,6 +111,33 @@ def test_estimate_1080p_full_cascade(oracle, lut):
         assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), ref.depth_u8)
 
 
+@pytest.mark.parametrize("rows,cols,levels,seed", [(2160, 3840, 6, 1234), (4320, 7680, 7, 1234)])
+def test_estimate_4k_and_8k_full_cascades(oracle, lut, rows, cols, levels, seed):
+    """src/main.cpp:95,261-288 at 3840x2160 (P = 6: 507 Mpixel-iterations) and 7680x4320 (P = 7: 1005): every level of the
+    cascade bit for bit against the oracle cascade on the host cores.  The coarsest level of both is odd-sized (67 rows under a
+    135-row level): the host-pyrUp branch and the ceil/floor gray quirk sit inside."""
+    bgr, ann = _bgr(rows, cols, seed)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads())
+    ref.estimate(1000)
+    assert ref.P == levels
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        assert c.pyramid_create(rows, cols) == levels
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann))
+        c.estimate_depth(1000); c.synchronize()
+        for l in range(levels):
+            assert np.array_equal(c.pyramid_download(rt.IMG_GRAY, l), ref.gray[l]), f"gray {l}"
+            assert np.array_equal(c.pyramid_download(rt.IMG_SCRIBBLE, l), ref.scribble[l]), f"scribble {l}"
+        for l in range(levels - 1, -1, -1):
+            got = c.pyramid_download(rt.IMG_DEPTH, l)
+            assert np.abs(got - ref.depth[l]).max() <= 1e-4
+            assert_bit_equal(got, ref.depth[l], f"{cols}x{rows} cascade, level {l}")
+        assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), ref.depth_u8)
+        ref.estimate(1000)                                              # --live: the warm-started second frame
+        c.estimate_depth(1000); c.synchronize()
+        assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, 0), ref.depth[0], f"{cols}x{rows} cascade, second (warm-started) estimate")
+
+
 @pytest.mark.parametrize("name", NAMES[:2])
 def test_refine_depth_converges_the_estimate(oracle, name):
     """rtdd_refine_depth (extension): estimate, then SOR cycles on the finest level to a 1e-4 residual -- the same sweep

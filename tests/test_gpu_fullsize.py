@@ -1,4 +1,8 @@
-"""BASELINE configs 3 and 5 at their full sizes, on the GPU, against the oracle (through the C ABI).
+"""The north star's 4K (and 8K) Jacobi stencil sweep and BASELINE configs 3 and 5 at their full sizes, on the GPU, against
+the oracle (through the C ABI).
+
+North star: the reference's hot loop (src/GPUSolver.cu:295-309) at 3840x2160 x 1000 sweeps and 7680x4320 x 200 sweeps in the
+library's DEFAULT configuration -- the very kernel instantiation `bench.py`'s `sweep_4k` record times -- bit for bit.
 
 Config 3: 3840x2160, red-black Gauss-Seidel / SOR to a 1e-4 residual (`rtdd_solve_ex`, RTDD_METHOD_RED_BLACK_GS).
 Config 5: 7680x4320, multigrid V-cycles (RTDD_METHOD_MULTIGRID).
@@ -41,6 +45,14 @@ def problem_4k(oracle):
     return p
 
 
+@pytest.fixture(scope="module")
+def problem_8k(oracle):
+    rows, cols = 4320, 7680
+    p = make_problem(rows, cols, seed=1234)
+    p["idx"] = oracle.index_to_weight(p["gray"], None, 0, 0)
+    return p
+
+
 def sor_cycle_sweeps(rows, cols, cycles_needed):
     """Sweep count of rtdd_solve_ex's RTDD_RELAXATION_AUTO schedule (include/rtdd.h) when cycle `cycles_needed - 1` is the
     first to reach the tolerance in its k-th polish block: returned as the set of admissible totals."""
@@ -54,6 +66,58 @@ def sor_cycle_sweeps(rows, cols, cycles_needed):
             if cycle == cycles_needed - 1:
                 ok.add(done)
     return ok
+
+
+def _jacobi_at_size(ctx, oracle, lut, p, iters, contract, what):
+    rows, cols = p["gray"].shape
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    ctx.set_option(rt.OPT_FP_CONTRACT, contract)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, 0, 0, lut, contract, threads=oracle.max_threads())
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, iters, 1e-5, 0)
+    info = ctx.last_solve_info()
+    ctx.synchronize()
+    got = down(d)
+    assert info.kernel == 2 and info.iterations == iters, info.describe()          # the temporally blocked kernel, automatic tile / depth
+    assert np.abs(got - want).max() <= 1e-4, f"{what}: {info.describe()}"
+    assert_bit_equal(got, want, f"{what} [{info.describe()}]")
+    dir_ = p["mask"] == 255
+    assert np.array_equal(got[dir_], p["depth"][dir_])
+    return info
+
+
+@pytest.mark.parametrize("contract", [1, 0])
+def test_north_star_4k_1000_jacobi_sweeps_bit_exact(ctx, oracle, lut, problem_4k, contract):
+    """3840x2160 x 1000 Chebyshev-Jacobi sweeps, default options: what `sweep_4k` in the bench line measures."""
+    info = _jacobi_at_size(ctx, oracle, lut, problem_4k, 1000, contract, "4K x 1000 Jacobi")
+    assert info.persistent == 0 and info.launches == -(-1000 // info.temporal_depth), info.describe()   # too many tiles to be resident: launch per block
+
+
+def test_north_star_4k_odd_sweep_count_and_second_seed(ctx, oracle, lut):
+    """Another image and a sweep count that is no multiple of the temporal depth (a short last block)."""
+    p = make_problem(2160, 3840, seed=77)
+    _jacobi_at_size(ctx, oracle, lut, p, 203, 1, "4K x 203 Jacobi, seed 77")
+
+
+@pytest.mark.parametrize("tile,depth", [(6, 8), (5, 8), (7, 12), (8, 8), (10, 12), (4, 8)])
+def test_4k_jacobi_every_large_tile_bit_exact(ctx, oracle, lut, problem_4k, tile, depth):
+    """The tile shapes the cost model can pick for large images, each forced at 4K for 64 sweeps."""
+    p = problem_4k
+    rows, cols = p["gray"].shape
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 64, 0, 0, lut, 1, threads=oracle.max_threads())
+    ctx.set_option(rt.OPT_SWEEP_KERNEL, 2); ctx.set_option(rt.OPT_TILE, tile); ctx.set_option(rt.OPT_TEMPORAL_DEPTH, depth)
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 64, 1e-5, 0)
+    info = ctx.last_solve_info()
+    ctx.synchronize()
+    assert info.tile == tile, info.describe()      # (temporal_depth reports the LAST launch: the short tail block, or the tile's cap)
+    assert_bit_equal(down(d), want, f"4K x 64, tile {tile} depth {depth}")
+
+
+def test_north_star_8k_200_jacobi_sweeps_bit_exact(ctx, oracle, lut, problem_8k):
+    """7680x4320 x 200 sweeps, default options (the HBM-resident size: 564 MB at 17 B/px)."""
+    _jacobi_at_size(ctx, oracle, lut, problem_8k, 200, 1, "8K x 200 Jacobi")
 
 
 @pytest.mark.parametrize("contract,omega", [(1, 1.9), (0, 1.0)])
@@ -94,14 +158,6 @@ def test_config3_4k_sor_cycles_to_1e_4(ctx, oracle, lut, problem_4k):
     ctx.solve_ex(d2, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=20, tolerance=0.0, relaxation=1.0)
     assert_bit_equal(down(d2), x, "20 Gauss-Seidel sweeps from the converged 4K image")
     assert oracle.residual_mt(x, p["idx"], p["mask"], lut, 1) <= 1e-4
-
-
-@pytest.fixture(scope="module")
-def problem_8k(oracle):
-    rows, cols = 4320, 7680
-    p = make_problem(rows, cols, seed=1234)
-    p["idx"] = oracle.index_to_weight(p["gray"], None, 0, 0)
-    return p
 
 
 def test_config5_8k_multigrid_two_cycles_bit_exact(ctx, oracle, lut, problem_8k):

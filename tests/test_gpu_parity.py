@@ -72,7 +72,8 @@ def test_solver_bit_exact(ctx, oracle, lut, shape, level, levels, iters, contrac
     assert_bit_equal(got, want, f"solver {shape} level {level}")
 
 
-@pytest.mark.parametrize("tile,depth", [(1, 1), (1, 4), (1, 7), (1, 8), (1, 16), (2, 4), (2, 8), (2, 5), (3, 4), (3, 12), (3, 16), (12, 8), (13, 8), (13, 5), (9, 28), (9, 24), (11, 8), (4, 28), (14, 8), (14, 28), (14, 5), (14, 1)])
+@pytest.mark.parametrize("tile,depth", [(1, 1), (1, 4), (1, 7), (1, 8), (1, 16), (2, 4), (2, 8), (2, 5), (3, 4), (3, 12), (3, 16), (12, 8), (13, 8), (13, 5), (9, 28), (9, 24), (11, 8), (4, 28), (14, 8), (14, 28), (14, 5), (14, 1),
+                                        (5, 8), (5, 12), (6, 8), (6, 12), (7, 8), (7, 12), (8, 8), (8, 12), (10, 8), (10, 12), (4, 8), (4, 12)])
 @pytest.mark.parametrize("shape,iters,level,levels", [((200, 333), 37, 0, 1), ((67, 120), 64, 1, 2), ((300, 130), 24, 0, 2), ((129, 129), 19, 0, 1)])
 def test_blocked_kernel_bit_exact(ctx, oracle, lut, tile, depth, shape, iters, level, levels):
     """Temporal blocking is only a re-schedule: any tile shape / depth must reproduce the oracle bit for bit."""
@@ -497,6 +498,28 @@ def test_persistent_timeout_is_reported_bounded_and_recoverable(ctx, oracle, lut
     d3 = up(p["depth"])
     ctx.GPUMatrixFreeSolver(d3, m, g, rows, cols, 0.4, 64, 0.0, 0); ctx.synchronize()
     assert_bit_equal(down(d3), want, "solve after a timed-out one")
+
+
+@pytest.mark.parametrize("rows,cols,persistent", [(2160, 3840, 0), (270, 480, 0), (1080, 1920, 1)])
+def test_status_word_is_read_after_every_blocked_launch(ctx, oracle, lut, rows, cols, persistent):
+    """The intra-workgroup wait of the blocked kernel is bounded in the launch-per-block instantiation too (status 2).  Whatever
+    the mode, the next synchronising call must report it -- not a later, unrelated persistent launch (round-2 advisor finding)."""
+    p = make_problem(rows, cols, seed=6)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+    ctx.set_option(rt.OPT_PERSISTENT, persistent)
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    ctx.set_option(rt.OPT_DEBUG_FORCE_STATUS, 2)
+    ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 24, 0.0, 0)
+    info = ctx.last_solve_info()
+    assert info.kernel == 2 and info.persistent == persistent, info.describe()
+    with pytest.raises(rt.RtddError) as e:
+        ctx.synchronize()
+    assert e.value.status == rt.RTDD_ERR_TIMEOUT and "neighbouring wave" in str(e.value)
+    ctx.synchronize()                                                  # reported once, then cleared
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 24, 0, 0, lut, 1, threads=oracle.max_threads())
+    d2 = up(p["depth"])
+    ctx.GPUMatrixFreeSolver(d2, m, g, rows, cols, 0.4, 24, 0.0, 0); ctx.synchronize()
+    assert_bit_equal(down(d2), want, "solve after a reported status")
 
 
 def test_solve_info_names_the_path_that_ran(ctx):
