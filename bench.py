@@ -67,20 +67,44 @@ def free_port():
     return p
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout_s=1500.0):
     """`python3 bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and relay rank 0's JSON line.
-    Nothing in this process has touched the GPU (no torch import yet)."""
+    Nothing in this process has touched the GPU (no torch import yet).  Every child is watched: the first rank that exits non-zero
+    (or the deadline) ends the others -- fresh children, never an exec -- so a rank that dies before the rendezvous cannot leave the
+    rest waiting in init_process_group."""
+    import tempfile
     port = free_port()
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + timeout_s
+    failed = 0
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [rc for rc in rcs if rc not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = abs(bad[0]) if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            print(f"[bench] launcher: a rank exited with {failed} (or the deadline passed); the other ranks were stopped", file=sys.stderr)
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return failed
 
 
 def cpu_baseline(rows, cols, method="jacobi", seconds_target=12.0):
@@ -90,14 +114,14 @@ def cpu_baseline(rows, cols, method="jacobi", seconds_target=12.0):
     p = make_problem(rows, cols, seed=1234)
     lut = oracle.load_weights(0.4)
     threads = oracle.max_threads()
-    if method in ("rbgs", "sor_cycles"):              # scalar in-place sweep: one thread
+    if method in ("rbgs", "sor_cycles"):              # the in-place red-black sweep, each colour's rows over the host cores (orc_rbgs_sweeps_mt)
         idx = oracle.index_to_weight(p["gray"], None, 0, 0)
         d = p["depth"].copy(); n = 0; t = time.perf_counter()
         while time.perf_counter() - t < seconds_target:
-            oracle.rbgs_sweep(d, idx, p["mask"], lut, 1, 1.9); n += 1
+            oracle.rbgs_sweeps_mt(d, idx, p["mask"], lut, 1, 1.9, 8, threads=threads); n += 8
         el = time.perf_counter() - t
-        return {"value": rows * cols * n / el / 1e6, "unit": "Mpixel-iterations/s", "cores": 1, "kind": "port",
-                "sample": f"{n} red-black SOR sweeps of the same {cols}x{rows} problem, scalar C, {el:.1f} s"}
+        return {"value": rows * cols * n / el / 1e6, "unit": "Mpixel-iterations/s", "cores": threads, "kind": "port",
+                "sample": f"{n} red-black SOR sweeps of the same {cols}x{rows} problem, OpenMP over the rows of each colour, {el:.1f} s"}
     if method == "multigrid":                         # scalar restatement of the V-cycle: hierarchy setup + ONE cycle
         idx = oracle.index_to_weight(p["gray"], None, 0, 0)
         d = p["depth"].copy(); t = time.perf_counter()
@@ -135,9 +159,12 @@ def estimate_ms(rt, ctx, p, rows, cols, dev, n=20):
     ctx.synchronize()
     ms = (time.perf_counter() - t) / n * 1e3
     pxit = sum((rows >> l) * (cols >> l) * int(1000 / 2 ** (P - 1 - l)) for l in range(P))
+    kernels = []
+    for l in range(1):                          # what the finest level ran (rtdd_last_solve_info reports the last solve: level 0)
+        i = ctx.last_solve_info(); kernels.append(f"level 0: tile {i.tile}, {i.temporal_depth} sweeps per launch, persistent {i.persistent}")
     ctx.pyramid_destroy()
     return {"what": f"{cols}x{rows} {P}-level cascade, {pxit / 1e6:.1f} Mpixel-iterations, device-resident", "ms": ms,
-            "Mpixel_iterations_per_s": pxit / ms / 1e3}
+            "Mpixel_iterations_per_s": pxit / ms / 1e3, "finest_level": kernels[0]}
 
 
 def valu_roofline(px_sweeps_per_s, method):
@@ -240,6 +267,8 @@ def main():
     ap.add_argument("--persistent", type=int, default=-1)
     ap.add_argument("--method", default=None, choices=["jacobi", "rbgs", "sor_cycles", "multigrid"],
                     help="override the workload's method; everything but jacobi is an EXTENSION (not the headline)")
+    ap.add_argument("--verify", action="store_true", help="after the timed region every rank compares the depth map of each of its images (last step) with the CPU oracle, bit for bit; "
+                    "the line then carries `verified` (checker only: outside the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="everything but the GPU work (launcher, rendezvous, sharding, aggregation): the N > 1 path on a CPU-only box")
     args = ap.parse_args()
 
@@ -271,21 +300,22 @@ def main():
         import torch.distributed as dist
         # The data path has NO collective (independent images); the process group only serves the timing barrier and
         # the MAX/SUM of two scalars.  RCCL ("nccl") is used when it comes up, gloo otherwise -- the result is the same.
-        if dry or share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-                dist.barrier()
-            except Exception as e:                                  # noqa: BLE001
-                print(f"[bench] rank {rank}: nccl unavailable ({e!r}); using gloo for the timing barrier", file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo")
+        # One backend for ALL ranks, decided before the rendezvous (RTDD_BENCH_BACKEND; default RCCL on GPUs, gloo for --dry-run and
+        # for ranks sharing a GPU): a per-rank fallback could leave the ranks on different backends, waiting at the first barrier.
+        # A rank that cannot bring the backend up fails loudly and the launcher ends the others.
+        import datetime
+        backend = os.environ.get("RTDD_BENCH_BACKEND") or ("gloo" if (dry or share_gpu) else "nccl")
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=120), **kw)
 
-    if args.workload not in WORKLOADS:
-        r_, c_, i_ = (int(v) for v in args.workload.split("x"))
-        WORKLOADS[args.workload] = dict(rows=r_, cols=c_, iters=i_)
+    if args.workload not in WORKLOADS:          # ROWSxCOLSxITERS, or batchB_ROWSxCOLSxITERS (a fixed batch of B images dealt round-robin)
+        spec = args.workload
+        extra = {}
+        if spec.startswith("batch"):
+            b_, spec = spec[5:].split("_", 1)
+            extra["batch"] = int(b_)
+        r_, c_, i_ = (int(v) for v in spec.split("x"))
+        WORKLOADS[args.workload] = dict(rows=r_, cols=c_, iters=i_, **extra)
     w = WORKLOADS[args.workload]
     rows, cols, iters = w["rows"], w["cols"], w["iters"]
     method = args.method or w.get("method", "jacobi")
@@ -370,7 +400,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not dry else "none (--dry-run: no GPU work)",
         "config": {"workload": (f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps (BASELINE configs[1])" if default_line else
-                                f"{args.workload}: {batch} independent {cols}x{rows} images x {iters} Chebyshev-Jacobi sweeps, image i on rank i % {world}, one stream per GPU (BASELINE configs[3])" if batch else
+                                f"{args.workload}: {batch} independent {cols}x{rows} images x {iters} Chebyshev-Jacobi sweeps, image i on rank i % {world}, one stream per GPU" + (" (BASELINE configs[3])" if args.workload == "batch64_1080p" else "") if batch else
                                 f"{args.workload} ({method})"),
                    "images_per_step": n_images, "images_this_rank": len(my_images), "sweeps_per_launch": sweeps_per_launch},
     }
@@ -395,6 +425,11 @@ def main():
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "counters_latest.json")))
             k = prof.get(args.workload if not (args.sweep_kernel or args.tile or args.temporal_depth or args.persistent >= 0 or args.method) else "", {})
+            # recorded counters describe ONE kernel instantiation: they are attached only if this run launched the same one
+            # (tile id and persistence recorded with them by scripts/make_counters_json.py), else the line says why not
+            if k and method == "jacobi" and not (k.get("tile") == info.tile and k.get("persistent") == info.persistent):
+                out["roofline"]["counters_source"] = f"not attached: {k.get('source')} recorded tile {k.get('tile')} persistent {k.get('persistent')}, this run launched tile {info.tile} persistent {info.persistent}"
+                k = {}
             if k:
                 if method == "multigrid":       # a chain of kernels: all of them together, per solve (setup + cycles + residual checks)
                     out["roofline"]["traffic"] = k.get("hbm_bytes_per_solve_all_kernels_corrected")
@@ -410,6 +445,24 @@ def main():
                 out["roofline"]["counters_source"] = k.get("source")
         except (OSError, ValueError, KeyError):
             pass
+    if args.verify and not dry:
+        # the checker (outside the timed region): each rank's results of the LAST step against the oracle on the host cores
+        import hashlib
+        import oracle
+        lut = oracle.load_weights(0.4)
+        bad, shas = [], []
+        for k, p in enumerate(problems):
+            got = rt.to_host(depths[args.warmup + args.steps - 1][k])
+            if method == "jacobi":
+                want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, 0, 0, lut, 1, threads=max(1, oracle.max_threads() // world))
+                if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                    bad.append(my_images[k])
+            shas.append(hashlib.sha256(got.tobytes()).hexdigest()[:16])
+        flag = torch.tensor([len(bad)], dtype=torch.float64, device=agg_dev)
+        if dist is not None:
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        out["verified"] = {"against": "oracle.solve, bit for bit" if method == "jacobi" else "(hash only: no fixed-count oracle for this method)", "images_differing_all_ranks": int(flag.item()),
+                           "rank0_images": [my_images[k] for k in range(len(problems))], "rank0_sha256_16": shas}
     if executed:
         out["config"]["converged"] = {"tolerance": tolerance, "iterations": [e[0] for e in executed], "unit": "cycles" if method == "multigrid" else "sweeps",
                                       "residual": max(e[1] for e in executed), "start": "cold (depth 255 + labels)"}
@@ -417,6 +470,7 @@ def main():
     if not dry and rank == 0 and world == 1 and default_line and not args.no_estimate:      # outside the timed region
         c2 = rt.Context(local); c2.set_stream(torch.cuda.current_stream().cuda_stream); c2.GPULoadWeights(0.4)
         out["estimate"] = estimate_ms(rt, c2, problems[0], rows, cols, dev)      # second half of BASELINE's metric
+        out["estimate_4k"] = estimate_ms(rt, c2, make_problem(2160, 3840, seed=1234), 2160, 3840, dev, n=10)   # the 6-level 4K cascade (src/main.cpp:95,261-288)
         c2.close()
         out["sweep_4k"] = sweep_4k(rt, dev)                                      # the north star's 4K stencil sweep
         out["effects"] = effects(rt, dev)

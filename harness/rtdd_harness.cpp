@@ -154,7 +154,8 @@ struct Job {
 };
 
 // One GPU: context + stream + device staging, runs `count` estimates; keeps the last result on the host.
-static int run_device(int device, const Job &job, int count, bool live, std::vector<unsigned char> *depth_u8, std::vector<unsigned char> *art, double *ms_per_estimate) {
+static int run_device(int device, const Job &job, int count, bool live, std::vector<unsigned char> *depth_u8, std::vector<unsigned char> *art, double *ms_per_estimate,
+                      std::vector<std::vector<unsigned char>> *every_map = nullptr) {
     // everything this function owns, released on EVERY return path (the CK() early returns included)
     struct Owned {
         rtdd_ctx *ctx = nullptr; hipStream_t stream = nullptr; unsigned char *d_bgr = nullptr, *d_ann = nullptr;
@@ -214,6 +215,7 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
         depth_u8->resize((size_t)rows * cols);
         CK(rtdd_download(ctx, depth_u8->data(), cols, p_u8, pi_u8, cols, rows));   // main.cpp:291 (synchronises)
         if (!job.effect.empty()) { art->resize((size_t)rows * cols * 3); CK(rtdd_download(ctx, art->data(), (size_t)cols * 3, p_art, pi_art, (size_t)cols * 3, rows)); }
+        if (every_map) every_map->push_back(*depth_u8);                 // --write-all: the n-th estimate of this device
     }
     *ms_per_estimate = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (count > 0 ? count : 1);
     CK(rtdd_ctx_synchronize(ctx));                                      // also reports a persistent launch that gave up (RTDD_ERR_TIMEOUT)
@@ -222,7 +224,7 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
 
 int main(int argc, const char *argv[]) {
     if (argc == 1) { std::printf("Usage: rtdd_harness -i image.ppm [-a annotation.pgm] [-o prefix] [--effect defocus|desaturation|haze] [--iters N] [--refine sor|mg|auto [--tolerance T]]\n"
-                                 "                    [--paint x,y,label,radius]... [--live N] [--devices D --batch B] [--png]\n"
+                                 "                    [--paint x,y,label,radius]... [--live N] [--devices D --batch B [--write-all]] [--png]\n"
                                  "       rtdd_harness --convert in.(png|ppm|pgm) out.(png|ppm|pgm)       (8-bit PNG <-> PNM, no GPU)\n"); return 0; }
     if (argc == 4 && !std::strcmp(argv[1], "--convert")) {               // file format conversion only (no GPU): PNG <-> PNM
         Pnm im;
@@ -231,7 +233,7 @@ int main(int argc, const char *argv[]) {
     }
     Job job;
     std::string in, an, out = "";
-    bool png = false;
+    bool png = false, write_all = false;
     int devices = 1, batch = 1, live = 0;
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -245,6 +247,7 @@ int main(int argc, const char *argv[]) {
         else if (!std::strcmp(argv[i], "--devices")) devices = std::atoi(next());
         else if (!std::strcmp(argv[i], "--batch")) batch = std::atoi(next());
         else if (!std::strcmp(argv[i], "--live")) live = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--write-all")) write_all = true;           // every estimate of a --batch: <out>DepthMap_<b>.pgm|png
         else if (!std::strcmp(argv[i], "--png")) png = true;                       // DepthMap.png / ArtisticEffect.png like the reference
         else if (!std::strcmp(argv[i], "--paint")) { Paint p{0, 0, 0, 0}; if (std::sscanf(next(), "%d,%d,%d,%d", &p.x, &p.y, &p.label, &p.radius) == 4) job.paints.push_back(p); }
         else if (!std::strcmp(argv[i], "-h")) std::printf("Usage:\n -i input image (binary PPM)\n -a annotated image (binary PGM)\n");
@@ -267,6 +270,7 @@ int main(int argc, const char *argv[]) {
     if (devices > ndev) devices = ndev;
 
     std::vector<std::vector<unsigned char>> depth(devices), art(devices);
+    std::vector<std::vector<std::vector<unsigned char>>> every(devices);   // [device][n-th estimate on it]: image b = n * devices + device
     std::vector<double> ms(devices, 0.0);
     std::vector<int> rcs(devices, 0), counts(devices, 0);
     for (int b = 0; b < batch; b++) counts[b % devices]++;               // image b -> device b % D
@@ -274,7 +278,7 @@ int main(int argc, const char *argv[]) {
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     for (int d = 0; d < devices; d++)
-        th.emplace_back([&, d]() { rcs[d] = counts[d] ? run_device(d, job, counts[d], live > 0, &depth[d], &art[d], &ms[d]) : 0; });
+        th.emplace_back([&, d]() { rcs[d] = counts[d] ? run_device(d, job, counts[d], live > 0, &depth[d], &art[d], &ms[d], write_all ? &every[d] : nullptr) : 0; });
     for (auto &t : th) t.join();
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (int d = 0; d < devices; d++) if (rcs[d]) return 4;
@@ -288,6 +292,12 @@ int main(int argc, const char *argv[]) {
         for (size_t i = 0; i < o.size(); i += 3) { o[i] = art[0][i + 2]; o[i + 2] = art[0][i]; }     // BGR -> RGB for the file
         if (!write_image(out + (png ? "ArtisticEffect.png" : "ArtisticEffect.ppm"), rgb.w, rgb.h, 3, o.data())) return 5;
     }
+    if (write_all)
+        for (int d = 0; d < devices; d++)
+            for (size_t n = 0; n < every[d].size(); n++) {
+                const std::string name = out + "DepthMap_" + std::to_string(n * devices + d) + (png ? ".png" : ".pgm");
+                if (!write_image(name, rgb.w, rgb.h, 1, every[d][n].data())) { std::printf("cannot write %s\n", name.c_str()); return 5; }
+            }
     std::printf("Saving images...\n");                                   // main.cpp:317
     return 0;
 }

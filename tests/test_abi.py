@@ -41,6 +41,18 @@ def test_reference_mangled_symbols_are_exported(so):
         assert s in asm
 
 
+def test_mangled_names_come_from_the_references_own_headers(so):
+    """tests/golden/reference_mangled_symbols.txt was derived by g++ from /root/reference/include/*.h (make_mangled.py): the
+    library exports exactly those, the Python list agrees, and where the reference is present the derivation is repeated."""
+    fixture = open(os.path.join(ROOT, "tests", "golden", "reference_mangled_symbols.txt")).read().split()
+    assert fixture == rt.DROPIN_SYMBOLS and set(fixture) <= _exported(so)
+    if os.path.isdir("/root/reference/include"):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_mangled", os.path.join(ROOT, "tests", "golden", "make_mangled.py"))
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+        assert mod.derive() == fixture
+
+
 def test_no_signature_leaks_cxx_or_torch_types():
     header = open(os.path.join(ROOT, "include", "rtdd.h")).read()
     assert 'extern "C"' in header

@@ -52,3 +52,26 @@ def test_two_ranks_share_one_gpu_for_real():
     assert d["n_gpus"] == 2 and d["config"]["images_per_step"] == 2 and d["value"] > 0
     assert d["config"]["persistent"] == 0                      # ranks sharing a GPU never launch persistently
     assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_two_ranks_results_equal_the_oracle():
+    """Two ranks through the launcher, three images each (a fixed batch of 6 dealt round-robin), and every rank's depth maps
+    compared with the oracle bit for bit (--verify): the product under N > 1, not just its plumbing."""
+    import bench
+    bench.WORKLOADS  # noqa: B018  (the module imports without touching the GPU)
+    d = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--workload", "batch6_540x960x120", "--verify"], env={"RTDD_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["images_per_step"] == 6 and d["config"]["images_this_rank"] == 3
+    v = d["verified"]
+    assert v["images_differing_all_ranks"] == 0 and v["rank0_images"] == [0, 2, 4] and "bit for bit" in v["against"], v
+
+
+@pytest.mark.gpu
+def test_config4_batch64_on_one_gpu_verified():
+    """BASELINE configs[3] at N = 1 (the base of the scaling curve): 64 independent 1080p images x 1000 sweeps on one GPU, one
+    stream, every one of the 64 depth maps equal to the oracle's (--verify)."""
+    d = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--workload", "batch64_1080p", "--verify"], timeout=900)
+    assert d["n_gpus"] == 1 and d["config"]["images_per_step"] == 64 and d["config"]["images_this_rank"] == 64 and d["scaling"] == "strong"
+    assert "configs[3]" in d["config"]["workload"]
+    assert d["verified"]["images_differing_all_ranks"] == 0 and len(d["verified"]["rank0_images"]) == 64
+    assert d["config"]["persistent"] == 1 and d["value"] > 0

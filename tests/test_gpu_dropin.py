@@ -1,0 +1,90 @@
+"""All ten of the reference's functions, called through their Itanium-mangled names (what an unchanged main.cpp links against)
+on raw device pointers, in main.cpp's order (-m gpu):
+
+    GPUAllocateDeviceMemory (src/main.cpp:149) -> GPULoadWeights (:155) -> GPUPaintImage (:56, two mouse-drag samples) ->
+    GPUPyrDownAnnotation per level (:249) -> GPUConvertToFloat (:257) -> per level GPUMatrixFreeSolver (:266) [+ pyrUp and
+    GPUConvertToFloat (:281)] -> GPUSimulateDefocus / Desaturation / Haze (:192, :206, :220) -> GPUFreeDeviceMemory (:336)
+
+against the same sequence composed from the oracle (tests/cascade_ref.py).  The OpenCV steps between the calls (gray pyramid,
+pyrUp, convertTo) are done by this test on the host with the oracle's restatements and uploaded, as main.cpp does with
+cv::pyrDown / cv::pyrUp for odd sizes (:244-246, :276-278).  The shim binds to a process-global default context and, like the
+reference, returns from the solver synchronised."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import realtimedepthdiffusion_amd as rt
+from cascade_ref import Cascade
+from gpu_util import assert_bit_equal, down, up
+from test_gpu_cascade import _bgr
+
+pytestmark = pytest.mark.gpu
+vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+
+
+def _img(t):
+    return vp(t.data_ptr()), sz(t.stride(0) * t.element_size())
+
+
+def _fn(name):
+    f = getattr(rt.lib(), name)
+    f.restype = None
+    return f
+
+
+@pytest.mark.parametrize("rows,cols", [(270, 481), (624, 672)])
+def test_all_ten_reference_symbols_in_main_cpp_order(oracle, lut, rows, cols):
+    import torch
+    bgr, ann = _bgr(rows, cols, 21)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=min(8, oracle.max_threads()))
+    P = ref.P
+    paints = [(cols // 3, rows // 2, 192, 9), (cols // 2, rows // 3, 0, 12)]        # (x, y, label, radius): main.cpp:41-57
+    for x, y, label, radius in paints:
+        oracle.paint_image(x, y, label, radius, ref.edited[0], ref.scribble[0])
+    ref.estimate(1000)
+
+    _fn("_Z23GPUAllocateDeviceMemoryiii")(i32(rows), i32(cols), i32(P))
+    _fn("_Z14GPULoadWeightsf")(f32(0.4))
+    # the caller's images (GpuMats in main.cpp:117-137): edited / scribble / gray / depth per level
+    sizes = ref.size
+    edited = [up(np.zeros(s + (3,), np.uint8)) for s in sizes]; scribble = [up(np.zeros(s, np.uint8)) for s in sizes]
+    gray = [up(g) for g in ref.gray]                                               # cvtColor + cv::pyrDown chain (host, main.cpp:102-113)
+    depth = [up(np.full(s, 255.0, np.float32)) for s in sizes]
+    e0 = bgr.copy(); lab = ann != 32; e0[lab] = ann[lab][:, None]                  # annotation decode, main.cpp:160-168
+    edited[0] = up(e0); scribble[0] = up(np.where(lab, 255, ann).astype(np.uint8))
+    paint = _fn("_Z13GPUPaintImageiiiiPhmS_mii")
+    for x, y, label, radius in paints:
+        paint(i32(x), i32(y), i32(label), i32(radius), *_img(edited[0]), *_img(scribble[0]), i32(rows), i32(cols))
+    torch.cuda.synchronize()
+    assert np.array_equal(down(scribble[0]), ref.scribble[0]) and np.array_equal(down(edited[0]), ref.edited[0])
+    pyrdown = _fn("_Z20GPUPyrDownAnnotationPhmS_miiS_mS_mii")
+    for l in range(1, P):
+        pyrdown(*_img(scribble[l - 1]), *_img(edited[l - 1]), i32(sizes[l - 1][0]), i32(sizes[l - 1][1]),
+                *_img(scribble[l]), *_img(edited[l]), i32(sizes[l][0]), i32(sizes[l][1]))
+    convert = _fn("_Z17GPUConvertToFloatPhmPfmS_mii")
+    convert(*_img(edited[P - 1]), *_img(depth[P - 1]), *_img(scribble[P - 1]), i32(sizes[P - 1][0]), i32(sizes[P - 1][1]))
+    solve = _fn("_Z19GPUMatrixFreeSolverPfmPhmS0_miififi")
+    for l in range(P - 1, -1, -1):
+        iters = int(np.float32(1000) / np.float32(2.0) ** ((P - 1) - l))
+        solve(*_img(depth[l]), *_img(scribble[l]), *_img(gray[l]), i32(sizes[l][0]), i32(sizes[l][1]), f32(0.4), i32(iters), f32(1e-5), i32(l))
+        got = down(depth[l])                                                        # no synchronize: the solver returns synchronised (GPUSolver.cu:314)
+        assert_bit_equal(got, ref.depth[l], f"mangled GPUMatrixFreeSolver, level {l}")
+        assert np.array_equal(down(scribble[l]), ref.scribble[l]) and np.array_equal(down(edited[l])[..., 0], ref.edited[l][..., 0])
+        if l > 0:
+            depth[l - 1] = up(oracle.pyrup_f32(got, *sizes[l - 1], contract=1))     # cv::cuda::pyrUp / cv::pyrUp (main.cpp:272-279)
+            convert(*_img(edited[l - 1]), *_img(depth[l - 1]), *_img(scribble[l - 1]), i32(sizes[l - 1][0]), i32(sizes[l - 1][1]))
+    orig = up(bgr); art = up(np.zeros_like(bgr))
+    _fn("_Z18GPUSimulateDefocusPhmPfmS_mii")(*_img(orig), *_img(depth[0]), *_img(art), i32(rows), i32(cols))
+    torch.cuda.synchronize()
+    assert np.array_equal(down(art), oracle.defocus(bgr, ref.depth[0], threads=oracle.max_threads()))
+    _fn("_Z23GPUSimulateDesaturationPhmS_mPfmS_mii")(*_img(orig), *_img(gray[0]), *_img(depth[0]), *_img(art), i32(rows), i32(cols))
+    torch.cuda.synchronize()
+    assert np.array_equal(down(art), oracle.desaturate(bgr, ref.gray[0], ref.depth[0], 1))
+    _fn("_Z15GPUSimulateHazePhmPfmS_mii")(*_img(orig), *_img(depth[0]), *_img(art), i32(rows), i32(cols))
+    torch.cuda.synchronize()
+    diff = np.abs(down(art).astype(np.int32) - oracle.haze(bgr, ref.depth[0], 1).astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4
+    _fn("_Z19GPUFreeDeviceMemoryi")(i32(P))
+    # after the free the shim reports the call-order violation like the reference would fail: prints, does not crash
+    solve(*_img(depth[0]), *_img(scribble[0]), *_img(gray[0]), i32(rows), i32(cols), f32(0.4), i32(1), f32(1e-5), i32(0))

@@ -100,6 +100,22 @@ def test_harness_batch_and_paint(tmp_path):
     assert np.array_equal(_read_pnm(tmp_path / "DepthMap.pgm"), d3)
 
 
+def test_harness_batch_of_eight_writes_eight_identical_maps(tmp_path):
+    """SURVEY 4, multi-GPU tier at N = 1: --batch 8 --write-all writes the depth map of EVERY one of the eight independent
+    estimates; each equals the single-image result bitwise (and the golden map)."""
+    g = load(NAMES[1])
+    _write_pnm(tmp_path / "img.ppm", g["bgr"][..., ::-1])
+    _write_pnm(tmp_path / "ann.pgm", g["annotation"])
+    args = [BIN, "-i", str(tmp_path / "img.ppm"), "-a", str(tmp_path / "ann.pgm"), "-o", str(tmp_path) + "/"]
+    subprocess.check_output(args, text=True)
+    single = _read_pnm(tmp_path / "DepthMap.pgm")
+    assert np.array_equal(single, g["depth_u8"])
+    out = subprocess.check_output(args + ["--batch", "8", "--devices", "8", "--write-all"], text=True)   # --devices is capped at what the box has
+    assert "8 estimate(s) on" in out
+    for b in range(8):
+        assert np.array_equal(_read_pnm(tmp_path / f"DepthMap_{b}.pgm"), single), f"image {b} of the batch"
+
+
 @pytest.mark.parametrize("how,unit", [("sor", "sweeps"), ("mg", "cycles")])
 def test_harness_refine_extension(tmp_path, how, unit):
     """--refine: rtdd_refine_depth after the estimate, reported on stdout; the depth map stays a valid one."""
