@@ -36,8 +36,17 @@ void omega_schedule(int n, std::vector<float> &out) {
     }
 }
 
-int prepare_persistent_launch(rtdd_ctx *ctx) {
-    RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, kSyncMaxTiles * sizeof(int), ctx->stream));
+// The per-tile flags are never reset between launches: a persistent launch with `nblocks` blocks is handed the base value
+// *flag_base = the context's running epoch, its workgroups publish and wait for flag_base + 1 .. flag_base + nblocks - 1, and the epoch
+// advances past them.  Launches of one context are stream-ordered, so every flag a launch finds is below its base.  (Round 2 zeroed
+// the 1024 flags with a hipMemsetAsync in front of every persistent launch: a ~5 us fill kernel per pyramid level and per solve.)
+int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
+    if (ctx->flag_epoch > (1 << 30) - nblocks - 2) {                  // (once in ~10^7 solves) start over
+        RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, kSyncMaxTiles * sizeof(int), ctx->stream));
+        ctx->flag_epoch = 0;
+    }
+    *flag_base = ctx->flag_epoch;
+    ctx->flag_epoch += nblocks + 1;
     const int limit = ctx->opt.debug_poll_limit_us > 0 ? ctx->opt.debug_poll_limit_us * 100 : 0;        // 10 ns ticks
     if (ctx->sync_header[0] != ctx->opt.debug_withhold_tile || ctx->sync_header[1] != limit) {
         RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncWithhold), ctx->opt.debug_withhold_tile, 1, ctx->stream));
@@ -474,8 +483,11 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     if (rc != RTDD_OK) return rc;
 
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-    rc = launch_finish(ctx, L, ip, s.pk, depth, depthPitch, rows, cols);
-    if (rc != RTDD_OK) return rc;
+    ctx->deferred_plane = s.pk;
+    if (!ctx->defer_finish) {
+        rc = launch_finish(ctx, L, ip, s.pk, depth, depthPitch, rows, cols, ctx->finish_u8, ctx->finish_u8_pitch);
+        if (rc != RTDD_OK) return rc;
+    }
     if (prof) {
         RTDD_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
         const int slot = ctx->prof_pending % rtdd_ctx::kProfSlots;

@@ -88,9 +88,15 @@ template <bool CONTRACT>
 __global__ __launch_bounds__(256) void k_pyrup_inject(const float *__restrict__ src, size_t sp, int rows, int cols,
                                                       float *__restrict__ dst, size_t dp, int drows, int dcols,
                                                       const uint8_t *__restrict__ edited, size_t ep,
-                                                      const uint8_t *__restrict__ mask, size_t mp) {
+                                                      const uint8_t *__restrict__ mask, size_t mp,
+                                                      float *__restrict__ coarse_out, size_t cp) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dcols || y >= drows) return;
+    // the estimate driver reads the coarse level straight from the solver's plane; the caller-visible coarse depth image (the
+    // solver's copy-back, src/GPUSolver.cu:311-312) is written here on the side: fine pixel (2c, 2r) stores coarse pixel (c, r)
+    // (the fine level is at least twice the coarse one in both directions, so every coarse pixel has one)
+    if (coarse_out && !((x | y) & 1) && (x >> 1) < cols && (y >> 1) < rows)
+        ((float *)((char *)coarse_out + (size_t)(y >> 1) * cp))[x >> 1] = ((const float *)((const char *)src + (size_t)(y >> 1) * sp))[x >> 1];
     float *out = (float *)((char *)dst + (size_t)y * dp) + x;
     if (mask && mask[(size_t)y * mp + x] == 255) { *out = (float)edited[(size_t)y * ep + 3 * x]; return; }
 #define SROW(r) ((const float *)((const char *)src + (size_t)(r) * sp))
@@ -161,9 +167,10 @@ int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, in
     return RTDD_OK;
 }
 int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
-                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp) {
-    if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject<true>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp);
-    else hipLaunchKernelGGL(k_pyrup_inject<false>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp);
+                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out, size_t cp) {
+    if (coarse_out && (drows < 2 * rows || dcols < 2 * cols)) return fail(ctx, RTDD_ERR_INVALID, "pyrUp: the fine level must be at least twice the coarse one");
+    if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject<true>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp);
+    else hipLaunchKernelGGL(k_pyrup_inject<false>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp);
     RTDD_LAUNCH_CHECK(ctx, "k_pyrup_inject");
     return RTDD_OK;
 }

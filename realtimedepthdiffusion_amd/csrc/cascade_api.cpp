@@ -173,18 +173,34 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
                                (const uint8_t *)p->scribble[P - 1].ptr, p->scribble[P - 1].pitch, p->edited[P - 1].rows, p->edited[P - 1].cols);   // :257-259
     for (int l = P - 1; l >= 0 && rc == RTDD_OK; l--) {                        // :261-288
         const int iters = (int)(maxIterations / powf(2.0, (P - 1) - l));       // :263
-        if (p->depth[l].rows > 0 && p->depth[l].cols > 0)
+        const bool solved = p->depth[l].rows > 0 && p->depth[l].cols > 0;
+        // Two launches less per level than the calls spelt out: above the finest level the solver's copy-back is left to the pyrUp
+        // kernel (which reads the result plane directly and writes depth[l] on the side); at the finest level the copy-back also
+        // writes the u8 map (:290).  Same values in the same buffers (tests/test_gpu_cascade.py compares every level's image).
+        ctx->defer_finish = solved && l > 0;
+        ctx->finish_u8 = l == 0 ? (uint8_t *)p->depth_u8.ptr : nullptr; ctx->finish_u8_pitch = p->depth_u8.pitch;
+        if (solved)
             rc = rtdd_matrix_free_solver(ctx, (float *)p->depth[l].ptr, p->depth[l].pitch, (const uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch,
                                          (const uint8_t *)p->gray[l].ptr, p->gray[l].pitch, p->depth[l].rows, p->depth[l].cols, 0.4f, iters, 1e-5f, l);
+        const bool deferred = ctx->defer_finish;
+        ctx->defer_finish = false; ctx->finish_u8 = nullptr;
         if (rc == RTDD_OK && l > 0) {
             DeviceGuard g(ctx->device);
-            rc = launch_pyrup_inject(ctx, (const float *)p->depth[l].ptr, p->depth[l].pitch, p->depth[l].rows, p->depth[l].cols,
+            const float *src = (const float *)p->depth[l].ptr; size_t sp = p->depth[l].pitch;
+            float *coarse_out = nullptr;
+            if (deferred) {                                                     // the level's result is still in the solver's plane
+                const size_t ip = plane_pitch(p->depth[l].cols);
+                src = ctx->levels[l].P(ctx->deferred_plane, ip); sp = ip * sizeof(float);
+                coarse_out = (float *)p->depth[l].ptr;
+            }
+            rc = launch_pyrup_inject(ctx, src, sp, p->depth[l].rows, p->depth[l].cols,
                                      (float *)p->depth[l - 1].ptr, p->depth[l - 1].pitch, p->depth[l - 1].rows, p->depth[l - 1].cols,
                                      (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch,
-                                     (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch);                                      // :272-283
+                                     (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch, coarse_out, p->depth[l].pitch);     // :272-283
         }
     }
     if (rc != RTDD_OK) return rc;
+    if (p->depth[0].rows > 0 && p->depth[0].cols > 0) return RTDD_OK;         // the u8 map left the solver's copy-back (above)
     DeviceGuard g(ctx->device);
     return launch_depth_to_u8(ctx, (const float *)p->depth[0].ptr, p->depth[0].pitch, (uint8_t *)p->depth_u8.ptr, p->depth_u8.pitch, p->rows, p->cols);   // :290
 }

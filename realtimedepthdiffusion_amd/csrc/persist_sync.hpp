@@ -12,7 +12,8 @@
 //   [kSyncWithhold]  debug (RTDD_OPT_DEBUG_WITHHOLD_TILE): tile number + 1 whose flag is never published (0 = off), to make the
 //                    timeout path testable.
 //   [kSyncLimit]     poll limit in 10 ns ticks of s_memrealtime (0 = kDefaultPollLimit).
-//   [kSyncFlags ..]  one block counter per tile, zeroed by the host before every persistent launch.
+//   [kSyncFlags ..]  one block counter per tile.  Monotonic over the life of the context: launch L's workgroups publish base_L + block
+//                    number, base_L handed in by the host (api.cpp prepare_persistent_launch), so nothing is zeroed between launches.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,6 +31,7 @@ constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: le
 // Protocol (cdna_hip_programming.md Guideline 16, R1): write-through (sc1) payload stores; EVERY storing wave drains vmcnt;
 // workgroup barrier; ONE lane stores the flag (agent-scope atomic); 8 lanes poll the neighbours' flags relaxed with s_sleep;
 // ONE agent acquire; barrier; plain vector loads.
+template <bool ACQUIRE = true>
 __device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, int tid, int tile_id, int bx, int by, int gx, int gy, int value) {
     int *flags = sync_words + kSyncFlags;
     if (tid == 0 && __hip_atomic_load(&sync_words[kSyncWithhold], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tile_id + 1)
@@ -59,7 +61,10 @@ __device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, in
             }
         }
     }
-    if (tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // ACQUIRE = false: the caller reads the handed-off bytes with 16-byte sc1 loads only (MI355X_MICROARCH.md, "Valid forms": the
+    // polling wave after its poll has matched, the other waves after the barrier below)
+    if (ACQUIRE && tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (!ACQUIRE && tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the polls themselves have returned
     __syncthreads();
     return __hip_atomic_load(dead_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
 }

@@ -54,7 +54,7 @@ __device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
 template <int LX, int NT, int G, bool CONTRACT, bool SOR, bool PERSIST>
 __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, const uint32_t *__restrict__ M,
                                                         const float *__restrict__ lut_g, int ip, int rows, int cols, int hx, int hy, int nsweeps, float omega, int gx, int gy, int xcd_tiles,
-                                                        int block_sweeps, int *sync_words) {
+                                                        int block_sweeps, int *sync_words, int flag_base) {
     static_assert(G % 2 == 0, "the compile-time colour pattern needs an even number of rows per thread");
     constexpr int EW = 4 * LX, NTR = NT / LX;
     typedef float f4r __attribute__((ext_vector_type(4)));
@@ -248,16 +248,30 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every storing wave drains its write-through stores
         __syncthreads();
-        if (exchange_wait(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, blk + 1)) return;      // flag, bounded poll, acquire, barrier (persist_sync.hpp)
+        if (exchange_wait<false>(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, barrier (persist_sync.hpp)
+        // no agent acquire: every halo load is a 16-byte sc1 load into the tile's registers, all issued, then ONE wait the loaded
+        // registers pass through (as in sweep_blocked.hip; MI355X_MICROARCH.md "Valid forms", table row 1)
+        typedef float f4v_t __attribute__((ext_vector_type(4)));
+        f4v_t hv[G];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int y = y0 + g, ty = tr * G + g;
             const bool central = xin && ty >= hy && ty < eh - hy;
+            hv[g] = a[g];
             if (colok && y >= 0 && y < rows && !central) {             // a halo pixel inside the image: some neighbour's centre
-                const float4 vx = *(const float4 *)(Ex + (size_t)y * ip + x0);
-                const float xv[4] = {vx.x, vx.y, vx.z, vx.w};
+                const float *q = Ex + (size_t)y * ip + x0;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hv[g]) : "v"(q) : "memory");
+            }
+        }
+        static_assert(G == 4, "the wait below lists four registers");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]) :: "memory");
 #pragma unroll
-                for (int i = 0; i < 4; i++) a[g][i] = x0 + i < cols ? xv[i] : 0.0f;
+        for (int g = 0; g < G; g++) {
+            const int y = y0 + g, ty = tr * G + g;
+            const bool central = xin && ty >= hy && ty < eh - hy;
+            if (colok && y >= 0 && y < rows && !central) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) a[g][i] = x0 + i < cols ? hv[g][i] : 0.0f;
             }
         }
     }
@@ -310,11 +324,11 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
         // costs more than a launch there (540x960: 265 -> 250), so they keep one launch per block.
         const bool persistent = !single && ctx->opt.persistent && (int)(grid.x * grid.y) <= ctx->num_cus && (int)(grid.x * grid.y) >= ctx->num_cus / 2 && grid.x * grid.y <= 1000 &&
                                 n - done > m && m == depth && hx <= TW && hy <= TH;
-        int block_sweeps = m;
+        int block_sweeps = m, flag_base = 0;
         if (persistent) {
-            { const int rc_ = prepare_persistent_launch(ctx); if (rc_ != RTDD_OK) return rc_; }   // zero the tile flags, debug words
-            ctx->persistent_used = true;
             m = n - done;
+            { const int rc_ = prepare_persistent_launch(ctx, (m + block_sweeps - 1) / block_sweeps, &flag_base); if (rc_ != RTDD_OK) return rc_; }   // this launch's flag values, debug words
+            ctx->persistent_used = true;
         }
         int out = -1;
         for (int i = 0; i < 4; i++) if (i != *plane && i != keep) { out = i; break; }      // `keep`: a plane the caller still needs (-1: none)
@@ -323,8 +337,8 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
         const bool sor = omega != 1.0f;
         const int xcd_tiles = single ? 0 : ((int)(grid.x * grid.y) + 7) / 8;
         const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
-#define RTDD_RBGS_GO(NT_, C_, S_) do { if (persistent) hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_, true>), launch_grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega, (int)grid.x, (int)grid.y, xcd_tiles, block_sweeps, ctx->sync_words); \
-        else hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_, false>), launch_grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega, (int)grid.x, (int)grid.y, xcd_tiles, block_sweeps, ctx->sync_words); } while (0)
+#define RTDD_RBGS_GO(NT_, C_, S_) do { if (persistent) hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_, true>), launch_grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega, (int)grid.x, (int)grid.y, xcd_tiles, block_sweeps, ctx->sync_words, flag_base); \
+        else hipLaunchKernelGGL((k_rbgs_blocked<32, NT_, 4, C_, S_, false>), launch_grid, dim3(nthreads), 0, ctx->stream, X, Y, L.M(ip), ctx->lut_dev, (int)ip, rows, cols, hx, hy, m, omega, (int)grid.x, (int)grid.y, xcd_tiles, block_sweeps, ctx->sync_words, flag_base); } while (0)
         const int variant = (big ? 4 : 0) | (ctx->opt.fp_contract ? 2 : 0) | (sor ? 1 : 0);
         switch (variant) {
             case 0: RTDD_RBGS_GO(512, false, false); break;

@@ -77,6 +77,14 @@ struct rtdd_ctx {
     int omega_cap = 0;
     float *residual_dev = nullptr;  // extension: residual reduction target
     int *sync_words = nullptr;      // control words of the persistent kernels (persist_sync.hpp); allocated with the context
+    // The estimate driver (cascade_api.cpp) takes two launches out of every pyramid level: with `defer_finish` set rtdd_solve_ex leaves
+    // its result in plane `deferred_plane` (the pyrUp kernel of the next level then reads it there and writes the caller's buffer on
+    // the side), and a non-null `finish_u8` makes the final copy-back write the u8 depth map too.
+    bool defer_finish = false;
+    int deferred_plane = -1;
+    uint8_t *finish_u8 = nullptr;
+    size_t finish_u8_pitch = 0;
+    int flag_epoch = 0;             // the per-tile flags of the persistent kernels only ever grow: base value of the next persistent launch (api.cpp)
     int sync_header[2] = {0, 0};    // what sync_words[kSyncWithhold], [kSyncLimit] currently hold on the device
     rtdd_solve_info last_info{};    // of the most recent solve; kernel/tile/temporal_depth/persistent are filled in by the sweep launchers
     bool persistent_used = false;   // a launch that can set the status word (sync_words[kSyncStatus]) happened since the last status check
@@ -134,7 +142,7 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
 // sweep_blocked.hip
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
                           int *pk, int *pm, int *launches);
-int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols);
+int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols, uint8_t *u8 = nullptr, size_t u8Pitch = 0);
 int launch_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch, const float *depth, size_t depthPitch,
                            int32_t *index2, int level, int rows, int cols);
 int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, float *host_out);
@@ -165,16 +173,16 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
 int launch_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, uint8_t *gray, size_t gp, int rows, int cols);
 int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, int cols, uint8_t *dst, size_t dp);
 int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
-                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp);
+                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out = nullptr, size_t cp = 0);
 int launch_depth_to_u8(rtdd_ctx *ctx, const float *src, size_t sp, uint8_t *dst, size_t dp, int rows, int cols);
 int launch_decode_annotation(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, const uint8_t *ann, size_t ap, uint8_t *edited, size_t ep,
                              uint8_t *scribble, size_t sp, int rows, int cols);
 int launch_fill_f32(rtdd_ctx *ctx, float *dst, size_t dp, int rows, int cols, float v);
 void pyramid_free(rtdd_ctx *ctx);
 
-// persistent kernels (persist_sync.hpp): zero the per-tile flags and refresh the debug words before a persistent launch;
+// persistent kernels (persist_sync.hpp): reserve the launch's flag values and refresh the debug words before a persistent launch;
 // read the status word where the stream has just been synchronised (-> RTDD_ERR_TIMEOUT, status cleared)
-int prepare_persistent_launch(rtdd_ctx *ctx);
+int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base);
 int check_persistent_status(rtdd_ctx *ctx);
 
 // the reference's host-side omega recurrence (src/GPUSolver.cu:282-299)

@@ -262,24 +262,40 @@ __global__ __launch_bounds__(256) void k_sweep1(const float *__restrict__ X, flo
 // ------------------------------------------------------------------------------------------------
 // k_finish: dense result plane -> caller's pitched buffer (copyToPitchedData, src/GPUSolver.cu:122-134)
 // ------------------------------------------------------------------------------------------------
+// `u8` (optional): the same values as GpuMat::convertTo(CV_8UC1) makes them -- saturate(round-half-even), src/main.cpp:290 -- so that the
+// finest level of an estimate needs no k_depth_to_u8 launch of its own.
+__device__ __forceinline__ uint8_t round_u8(float v) {
+    const float r = __builtin_rintf(v);
+    return !(r >= 0.0f) ? 0 : (r >= 255.0f ? 255 : (uint8_t)(int)r);
+}
+
 __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
-                                                int rows, int cols) {
+                                                int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
-    ((float *)((char *)depth + (size_t)y * depthPitch))[x] = X[(size_t)y * ip + x];
+    const float v = X[(size_t)y * ip + x];
+    ((float *)((char *)depth + (size_t)y * depthPitch))[x] = v;
+    if (u8) u8[(size_t)y * u8Pitch + x] = round_u8(v);
 }
 
 // four pixels per thread when the caller's rows are 16-byte aligned (a group past the end of the row: pixel by pixel)
 __global__ __launch_bounds__(256) void k_finish4(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
-                                                 int rows, int cols) {
+                                                 int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch) {
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x0 >= cols || y >= rows) return;
     const float4 v = *(const float4 *)(X + (size_t)y * ip + x0);
     float *o = (float *)((char *)depth + (size_t)y * depthPitch) + x0;
+    const float t[4] = {v.x, v.y, v.z, v.w};
     if (x0 + 3 < cols) *(float4 *)o = v;
-    else { const float t[4] = {v.x, v.y, v.z, v.w}; for (int i = 0; i < 4; i++) if (x0 + i < cols) o[i] = t[i]; }
+    else { for (int i = 0; i < 4; i++) if (x0 + i < cols) o[i] = t[i]; }
+    if (u8) {
+        uint8_t *q = u8 + (size_t)y * u8Pitch + x0;
+        if (x0 + 3 < cols && u8Pitch % 4 == 0 && (uintptr_t)u8 % 4 == 0)
+            *(uint32_t *)q = (uint32_t)round_u8(t[0]) | ((uint32_t)round_u8(t[1]) << 8) | ((uint32_t)round_u8(t[2]) << 16) | ((uint32_t)round_u8(t[3]) << 24);
+        else { for (int i = 0; i < 4; i++) if (x0 + i < cols) q[i] = round_u8(t[i]); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -428,11 +444,11 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
     return RTDD_OK;
 }
 
-int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols) {
+int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols, uint8_t *u8, size_t u8Pitch) {
     if ((uintptr_t)depth % 16 == 0 && depthPitch % 16 == 0)
-        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols);
+        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch);
     else
-        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols);
+        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch);
     RTDD_LAUNCH_CHECK(ctx, "k_finish");
     return RTDD_OK;
 }

@@ -45,6 +45,14 @@ __device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 
+// 16-byte sc1 load to registers (bypasses this CU's L1, served by L2 / memory): with EVERY load of handed-off bytes of this form, every
+// store of them sc1 and drained, and the flag protocol of persist_sync.hpp, the consumer needs no agent-scope acquire
+// (MI355X_MICROARCH.md, "Valid forms", table row 1).  The value is NOT there when the statement returns: wait_loads() below.
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_sc1(f4v_t &dst, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+
 // Result stores.  RTDD_STORE_MODE (diagnostic knob): 0 plain, 1 non-temporal, 2 write-through (sc1).
 #ifndef RTDD_STORE_MODE
 #define RTDD_STORE_MODE 0
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
                                                       const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
                                                       const float *__restrict__ omegas, int ip, int rows, int cols,
                                                       int hx, int hy, int nsweeps, float gamma,
-                                                      int block_sweeps, int *sync_words, int gx, int gy, int xcd_tiles) {
+                                                      int block_sweeps, int *sync_words, int gx, int gy, int xcd_tiles, int flag_base) {
     // block_sweeps == nsweeps: the plain time-blocked launch (results -> Yk/Ym).
     // block_sweeps <  nsweeps: PERSISTENT mode -- the workgroup keeps its tile in registers for the whole solve and,
     // every block_sweeps (= halo width, even) sweeps, trades halo strips with its 8 neighbours through memory instead
@@ -462,9 +470,13 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
             __syncthreads();
             RTDD_XT(1);
-            if (exchange_wait(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, blk + 1)) return;      // flag, bounded poll, acquire, barrier
+#ifndef RTDD_EXCHANGE_ACQUIRE
+#define RTDD_EXCHANGE_ACQUIRE 0
+#endif
+            if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, (acquire,) barrier
             RTDD_XT(2);
             RTDD_XT(3);
+#if RTDD_EXCHANGE_ACQUIRE
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const int y = y0 + g, ty = tr * G + g;
@@ -472,13 +484,49 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
                 const bool ok = colok && y >= 0 && y < rows;
                 if (ok && !central) {                                    // a halo pixel inside the image: some neighbour's centre
                     const size_t off = (size_t)y * ip + x0;
-                    // plain vector loads behind the agent acquire (sc1 scalar loads instead of the acquire measured 2 % slower)
-                    const float4 vx = *(const float4 *)(Ek + off), vp = *(const float4 *)(Em + off);
+                    const float4 vx = *(const float4 *)(Ek + off), vp = *(const float4 *)(Em + off);      // plain vector loads behind the agent acquire
                     const float xv[4] = {vx.x, vx.y, vx.z, vx.w}, pv[4] = {vp.x, vp.y, vp.z, vp.w};
 #pragma unroll
                     for (int i = 0; i < 4; i++) { const bool in = x0 + i < cols; a[g][i] = in ? xv[i] : 0.0f; b[g][i] = in ? pv[i] : 0.0f; }
                 }
             }
+#else
+            // No acquire: every halo load is a 16-byte sc1 load straight into the tile's registers (the strips were stored sc1 and drained
+            // before their owner's flag; the polling wave loads after its poll, the others after the barrier exchange_wait ends with).
+            // Round 2 measured the acquire at 0.8-0.9 us of a 15.7 us block.  All loads are issued, then ONE wait that the loaded
+            // registers pass through (so that no use can be scheduled in front of it).
+            f4v_t hk[G], hm[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int y = y0 + g, ty = tr * G + g;
+                const bool central = xin && ty >= hy && ty < eh - hy;
+                const bool ok = colok && y >= 0 && y < rows;
+                hk[g] = a[g]; hm[g] = b[g];
+                if (ok && !central) {                                    // a halo pixel inside the image: some neighbour's centre
+                    const size_t off = (size_t)y * ip + x0;
+                    load_sc1(hk[g], Ek + off); load_sc1(hm[g], Em + off);
+                }
+            }
+            if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hk[0]), "+v"(hm[0]) :: "memory");
+            else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hk[0]), "+v"(hm[0]), "+v"(hk[1]), "+v"(hm[1]) :: "memory");
+            else if constexpr (G == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hk[0]), "+v"(hm[0]), "+v"(hk[1]), "+v"(hm[1]), "+v"(hk[2]), "+v"(hm[2]) :: "memory");
+            else if constexpr (G == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hk[0]), "+v"(hm[0]), "+v"(hk[1]), "+v"(hm[1]), "+v"(hk[2]), "+v"(hm[2]), "+v"(hk[3]), "+v"(hm[3]) :: "memory");
+            else {
+                static_assert(G == 6, "add a wait for this G");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hk[0]), "+v"(hm[0]), "+v"(hk[1]), "+v"(hm[1]), "+v"(hk[2]), "+v"(hm[2]) :: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hk[3]), "+v"(hm[3]), "+v"(hk[4]), "+v"(hm[4]), "+v"(hk[5]), "+v"(hm[5]) :: "memory");
+            }
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int y = y0 + g, ty = tr * G + g;
+                const bool central = xin && ty >= hy && ty < eh - hy;
+                const bool ok = colok && y >= 0 && y < rows;
+                if (ok && !central) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const bool in = x0 + i < cols; a[g][i] = in ? hk[g][i] : 0.0f; b[g][i] = in ? hm[g][i] : 0.0f; }
+                }
+            }
+#endif
         }
         (void)ntiles;
         RTDD_XT(4);
@@ -732,10 +780,10 @@ static bool persistent_possible(rtdd_ctx *ctx, int tile, int nthreads) {
 
 template <int LX, int NT, int G>
 static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, float *Xk, float *Xm, float *Yk, float *Ym, const uint32_t *M,
-                       const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma, int block_sweeps) {
+                       const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma, int block_sweeps, int flag_base) {
     const bool persist = block_sweeps < n;
     const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
-#define RTDD_LAUNCH(C, P) hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, C, P>), launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma, block_sweeps, ctx->sync_words, (int)grid.x, (int)grid.y, xcd_tiles)
+#define RTDD_LAUNCH(C, P) hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, C, P>), launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma, block_sweeps, ctx->sync_words, (int)grid.x, (int)grid.y, xcd_tiles, flag_base)
     if (ctx->opt.fp_contract) { if (persist) RTDD_LAUNCH(true, true); else RTDD_LAUNCH(true, false); }
     else { if (persist) RTDD_LAUNCH(false, true); else RTDD_LAUNCH(false, false); }
 #undef RTDD_LAUNCH
@@ -878,11 +926,12 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             switch (tile) { RTDD_ALL_TILES }
 #undef RTDD_TILE_CASE
         }
+        int flag_base = 0;
         if (persistent) {
-            { const int rc_ = prepare_persistent_launch(ctx); if (rc_ != RTDD_OK) return rc_; }   // zero the tile flags, debug words
-            ctx->persistent_used = true;
             block_sweeps = T;
             m = n - done;
+            { const int rc_ = prepare_persistent_launch(ctx, (m + T - 1) / T, &flag_base); if (rc_ != RTDD_OK) return rc_; }   // this launch's flag values, debug words
+            ctx->persistent_used = true;
         }
         // XCD-aware tile placement (RTDD_XCD_REMAP=0 turns it off): +1.5-4 % persistent (strips traded inside one L2), +8 % at 4K
         // launch-per-block (a tile's halo is its neighbours' centre: the same XCD reads both)
@@ -894,7 +943,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         float *Xk = L.P(*pk, ip), *Xm = L.P(*pm, ip);
         float *Yk = L.P(free0, ip), *Ym = L.P(free1, ip);
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) \
-    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps); break;
+    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps, flag_base); break;
         if (tile == 14) {
             const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
             if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
