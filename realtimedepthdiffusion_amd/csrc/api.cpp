@@ -42,7 +42,7 @@ void omega_schedule(int n, std::vector<float> &out) {
 // the 1024 flags with a hipMemsetAsync in front of every persistent launch: a ~5 us fill kernel per pyramid level and per solve.)
 int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
     if (ctx->flag_epoch > (1 << 30) - nblocks - 2) {                  // (once in ~10^7 solves) start over
-        RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, kSyncMaxTiles * sizeof(int), ctx->stream));
+        RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, (size_t)kSyncMaxTiles * kSyncFlagStride * sizeof(int), ctx->stream));
         ctx->flag_epoch = 0;
     }
     *flag_base = ctx->flag_epoch;

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
     __shared__ float4 edge[2][NTR][2][LX];
     __shared__ int published[NT / 64];
     __shared__ int dead_s;                     // the launch has failed (persist_sync.hpp): leave
+    __shared__ int seen_s;                     // exchange_wait: the newest flag value some polling wave has seen at all its neighbours
 
     // XCD-aware placement as in sweep_blocked.hip: workgroup p (on XCD p % 8) takes tile (p % 8) * xcd_tiles + p / 8
     int bx = blockIdx.x, by = blockIdx.y;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
     const int tid = threadIdx.x;
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
     if (tid < NT / 64) published[tid] = 0;
-    if (tid == 0) dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; seen_s = flag_base; }
     __syncthreads();
     if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
 
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every storing wave drains its write-through stores
         __syncthreads();
-        if (exchange_wait<false>(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, barrier (persist_sync.hpp)
+        if (exchange_wait<false>(sync_words, &dead_s, &seen_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, barrier (persist_sync.hpp)
         // no agent acquire: every halo load is a 16-byte sc1 load into the tile's registers, all issued, then ONE wait the loaded
         // registers pass through (as in sweep_blocked.hip; MI355X_MICROARCH.md "Valid forms", table row 1)
         typedef float f4v_t __attribute__((ext_vector_type(4)));

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     __shared__ float4 edge[2][NTR][2][LX];     // [buffer][thread row][0 = its top row, 1 = its bottom row][lane]
     __shared__ int published[NT / 64 + 1];     // per wave: number of sweeps whose edge rows it has published; [NT/64]: the maximum over the waves
     __shared__ int dead_s;                     // the launch has failed (persist_sync.hpp): leave
+    __shared__ int seen_s;                     // exchange_wait: the newest flag value some polling wave has seen at all its neighbours
 
     // (gx, gy) = the grid of tiles.  xcd_tiles > 0 (every multi-tile launch): a 1-D launch of 8 * xcd_tiles workgroups in which
     // workgroup p -- dispatched to XCD p % 8 -- takes tile number (p % 8) * xcd_tiles + p / 8, so that each XCD owns a run
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     const int tid = threadIdx.x;
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];       // blockDim.x <= NT: small levels launch only the thread rows they need
     if (tid <= NT / 64) published[tid] = 0;
-    if (tid == 0) dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; seen_s = flag_base; }
     __syncthreads();
     if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
 
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 #ifndef RTDD_EXCHANGE_ACQUIRE
 #define RTDD_EXCHANGE_ACQUIRE 0
 #endif
-            if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, (acquire,) barrier
+            if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, &seen_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, (acquire,) barrier
             RTDD_XT(2);
             RTDD_XT(3);
 #if RTDD_EXCHANGE_ACQUIRE

@@ -10,8 +10,9 @@ make -j4 >/dev/null
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -fvisibility=hidden -I../../include -I."
 OBJS=""
 for f in solver_kernels sweep_blocked rbgs_blocked multigrid image_kernels effect_kernels cascade api cascade_api dropin; do
-    if echo " $FILES " | grep -q " $f.hip "; then
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $DEFS -c $f.hip -o /tmp/${f}_$NAME.o
+    ext=hip; [ -f $f.cpp ] && ext=cpp
+    if echo " $FILES " | grep -q " $f.$ext "; then
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $DEFS -c $f.$ext -o /tmp/${f}_$NAME.o
         OBJS="$OBJS /tmp/${f}_$NAME.o"
     else
         OBJS="$OBJS $f.o"

@@ -92,7 +92,9 @@ all_bytes = (2 * TOTALS.get("fetch", {}).get("FETCH_SIZE", 0.0) + TOTALS.get("wr
 summary["hbm_bytes_per_solve_all_kernels_corrected"] = all_bytes
 summary["kernel_ms_per_solve_clean_trace"] = sum(k["total_ms"] for k in kernels.values()) / 25.0      # --steps 20 --warmup 5
 json.dump(summary, open(f"profiles/{rnd}_{wl}_counters.json", "w"), indent=1)
-latest[wl] = {"hbm_bytes_per_solve_all_kernels_corrected": all_bytes, "kernel_ms_per_solve_clean_trace": summary["kernel_ms_per_solve_clean_trace"], "kernel": dom, "source": f"profiles/{rnd}_{wl}_counters.json", "mean_duration_us": kernels[dom]["mean_duration_us"],
+cfg = bench.get("trace.json", {}).get("config", {})      # what the profiled command launched: bench.py attaches these counters only to a run of the same kernel
+latest[wl] = {"tile": cfg.get("tile"), "persistent": cfg.get("persistent"), "temporal_depth": cfg.get("temporal_depth"),
+              "hbm_bytes_per_solve_all_kernels_corrected": all_bytes, "kernel_ms_per_solve_clean_trace": summary["kernel_ms_per_solve_clean_trace"], "kernel": dom, "source": f"profiles/{rnd}_{wl}_counters.json", "mean_duration_us": kernels[dom]["mean_duration_us"],
               "hbm_bytes_per_launch_corrected": kernels[dom].get("hbm_bytes_per_launch_corrected"), "valu_issue_frac_counted": kernels[dom].get("valu_issue_frac_counted")}
 json.dump(latest, open(latest_path, "w"), indent=1)
 print(dom, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in kernels[dom].items() if k != "sq_per_launch"})
