@@ -104,6 +104,30 @@ def test_defocus_bit_exact(ctx, oracle, shape):
     assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=min(8, oracle.max_threads())))
 
 
+@pytest.mark.parametrize("shape,align", [((67, 121), 1), ((131, 259), 1), ((40, 4099), 4), ((9, 70), 1), ((300, 66), 2)])
+def test_defocus_unaligned_rows_and_ragged_tiles(ctx, oracle, shape, align):
+    """Caller pitches that are no multiple of 4 bytes (the byte paths of the table build and of the lookup), widths that leave a
+    ragged last 64-pixel tile and a ragged last group of four, and a row wider than one sweep of the build's workgroup (4096 px:
+    the per-row carry between column ranges)."""
+    rows, cols = shape
+    depth, _ = _depth(rows, cols, 43)
+    orig = _rgb(rows, cols, 18)
+    art = up(np.zeros_like(orig), align)
+    ctx.GPUSimulateDefocus(up(orig, align), up(depth), art, rows, cols)
+    assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=min(8, oracle.max_threads())))
+
+
+def test_defocus_windows_beyond_one_lookup(ctx, oracle):
+    """Windows of more than 8224 pixels (the packed table's 21-bit fields) are summed in strips: a small image with a depth far
+    above 255 makes every window the whole (clipped) image -- 160 x 120 = 19 200 pixels, three strips."""
+    rows, cols = 120, 160
+    orig = _rgb(rows, cols, 20)
+    depth = np.full((rows, cols), 4000.0, np.float32); depth[::7, ::5] = 900.0; depth[3::11, 1::3] = 255.0
+    art = up(np.zeros_like(orig))
+    ctx.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+    assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=min(8, oracle.max_threads())))
+
+
 def test_defocus_out_of_range_depth_is_defined(ctx, oracle):
     rows, cols = 120, 160
     orig = _rgb(rows, cols, 19)
