@@ -88,7 +88,8 @@ enum rtdd_option {
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),
                                        12 = 128x96 (16 px/thread, 768 threads), 13 = 128x96 (24 px/thread, 512 threads),
-                                       14 = 64x64 in the column layout (1 px x 4 rows per thread; small pyramid levels) */
+                                       14 = 64x64 in the column layout (1 px x 4 rows per thread; small pyramid levels),
+                                       15 = 64x32 and 16 = 64x48 in the column layout */
 };
 
 /* ---- context ------------------------------------------------------------------------------- */

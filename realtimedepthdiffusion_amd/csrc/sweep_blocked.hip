@@ -182,14 +182,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     }
     RTDD_STAMP(0);
     const int tid = threadIdx.x;
-    for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];       // blockDim.x <= NT: small levels launch only the thread rows they need
-    if (tid <= NT / 64) published[tid] = 0;
-    if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; seen_s = flag_base; }
-    __syncthreads();
-    if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
-
     const int lx = tid % LX, tr = tid / LX;
-    const int ntr = (int)blockDim.x / LX;          // thread rows actually launched
+    const int ntr = (int)blockDim.x / LX;          // thread rows actually launched (blockDim.x <= NT: small levels launch only the thread rows they need)
     const int eh = ntr * G;                        // rows of the extended tile actually covered
     const int TW = EW - 2 * hx, TH = eh - 2 * hy;
     const int x0 = bx * TW - hx + 4 * lx;
@@ -203,19 +197,34 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     bool unsafe = false;                       // some pixel of this lane has a denormal divisor
     uint32_t dirichlet = 0;                    // bit g*4+i
 
-    // ---- load the extended tile once -----------------------------------------------------------
+    // ---- load the extended tile once: every load is issued BEFORE the weight table is staged in LDS and the barrier behind it, so
+    // that a launch pays one memory round trip, not two in a row (launch-per-block: 125 launches per 1000 sweeps at 4K) ------------
+    float4 vxr[G], vpr[G];
+    uint4 mr[G], mup = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int y = y0 + g;
+        vxr[g] = make_float4(0, 0, 0, 0); vpr[g] = vxr[g]; mr[g] = make_uint4(0, 0, 0, 0);
+        if (colok && y >= 0 && y < rows) {
+            const size_t off = (size_t)y * ip + x0;
+            vxr[g] = *(const float4 *)(Xk + off);
+            vpr[g] = *(const float4 *)(Xm + off);
+            mr[g] = *(const uint4 *)(M + off);
+        }
+    }
+    if (colok && y0 - 1 >= 0 && y0 < rows) mup = *(const uint4 *)(M + (size_t)(y0 - 1) * ip + x0);     // the row above the block: its down-weights
+    for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
+    if (tid <= NT / 64) published[tid] = 0;
+    if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; seen_s = flag_base; }
+    __syncthreads();
+    if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
+
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const int y = y0 + g;
         const bool ok = colok && y >= 0 && y < rows;
-        float4 vx = make_float4(0, 0, 0, 0), vp = vx;
-        uint4 m = make_uint4(0, 0, 0, 0);
-        if (ok) {
-            const size_t off = (size_t)y * ip + x0;
-            vx = *(const float4 *)(Xk + off);
-            vp = *(const float4 *)(Xm + off);
-            m = *(const uint4 *)(M + off);
-        }
+        const float4 vx = vxr[g], vp = vpr[g];
+        const uint4 m = mr[g];
         const float xv[4] = {vx.x, vx.y, vx.z, vx.w}, pv[4] = {vp.x, vp.y, vp.z, vp.w};
         const uint32_t mv[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
@@ -236,9 +245,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     }
     {   // weights towards the row above the block: the down-weights of row y0-1
         const int y = y0 - 1;
-        uint4 m = make_uint4(0, 0, 0, 0);
+        const uint4 m = mup;
         const bool ok = colok && y >= 0 && y + 1 < rows;
-        if (ok) m = *(const uint4 *)(M + (size_t)y * ip + x0);
         const uint32_t mv[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) wu0[i] = (ok && x0 + i < cols) ? lut[(mv[i] >> 8) & 255] : 0.0f;
@@ -346,7 +354,14 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RTDD_TL(1, s);
 #endif
-        const float omega = omegas[s];
+        // omega and gamma stay SCALAR operands (RTDD_SCALAR_FACTORS=0 moves them to VGPRs): in isolation v_fma_f32 with an SGPR operand
+        // issues at 4.8 cycles per wave-instruction and SIMD and with three VGPRs at 3.2 (scripts/ubench/valu_mix.hip,
+        // profiles/r03_valu_mix.txt), but inside this loop the vector form measured 0.5-1.5 % SLOWER (1080p, 4K: EXPERIMENTS.md)
+#ifndef RTDD_SCALAR_FACTORS
+#define RTDD_SCALAR_FACTORS 1
+#endif
+        float omega = omegas[s], gamma_v = gamma;
+        if (!RTDD_SCALAR_FACTORS) asm volatile("" : "+v"(omega), "+v"(gamma_v));
         float xl0[G], xr3[G];                    // filled per group (each costs a register until its row is done)
         // weighted sum of pixel (g, i): solveDiffusion, src/GPUSolver.cu:73-106, absent neighbours carried as (w = 0, x = 0)
         auto wsum = [&](int g, int i) {
@@ -402,8 +417,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
                     // :104 min(max(r,0),255): v_med3_f32 returns min3 when an operand is NaN, i.e. 0 here, like fmax/fmin
                     const float r = __builtin_amdgcn_fmed3f(q[g][i], 0.0f, 255.0f);        // cnt == 0 was replaced by 1 (sum is 0 there): r = 0 (:103)
                     const float x = cur[g][i], prev = oth[g][i];
-                    const float v = CONTRACT ? __builtin_fmaf(omega, __builtin_fmaf(gamma, r - x, x) - prev, prev)      // src/GPUSolver.cu:259
-                                             : (omega * (gamma * (r - x) + x - prev)) + prev;
+                    const float v = CONTRACT ? __builtin_fmaf(omega, __builtin_fmaf(gamma_v, r - x, x) - prev, prev)      // src/GPUSolver.cu:259
+                                             : (omega * (gamma_v * (r - x) + x - prev)) + prev;
                     oth[g][i] = (dirichlet >> (g * 4 + i)) & 1u ? x : v;                    // x_{k+1} replaces x_{k-1}
                 }
             }
@@ -588,22 +603,35 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = (int)blockDim.x >> 6;
-    for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
-    for (int i = tid; i < 2 * 16 * 64; i += (int)blockDim.x) (&edge[0][0][0])[i] = make_int4(0, 0, 0, 0);
-    __syncthreads();
     const int eh = R * nwv, TW = 64 - 2 * hx, TH = eh - 2 * hy;
     const int x = bx * TW - hx + lane, y0 = by * TH - hy + R * wv;
     const bool colok = x >= 0 && x < cols;
     float a[R], b[R], wr[R], wd[R], wl[R], cnt[R], rcp[R], wu0;
     bool dir[R], unsafe = false;
+    // The tile's loads are issued BEFORE the weight table is staged in LDS, so that the launch pays one memory round trip, not two in a
+    // row (these levels are 36 + 21 launches of ~13.6 us: -0.7 us each).
+    uint32_t mraw[R], mup = 0;
 #pragma unroll
     for (int g = 0; g < R; g++) {
         const int y = y0 + g;
         const bool in = colok && y >= 0 && y < rows;
         const size_t off = (size_t)(in ? y : 0) * ip + (in ? x : 0);
-        const uint32_t m = in ? M[off] : 0u;
+        mraw[g] = in ? M[off] : 0u;
         a[g] = in ? Xk[off] : 0.0f;
         b[g] = in ? Xm[off] : 0.0f;
+    }
+    {
+        const int y = y0 - 1;
+        if (colok && y >= 0 && y + 1 < rows) mup = M[(size_t)y * ip + x];
+    }
+    for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
+    for (int i = tid; i < 2 * 16 * 64; i += (int)blockDim.x) (&edge[0][0][0])[i] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < R; g++) {
+        const int y = y0 + g;
+        const bool in = colok && y >= 0 && y < rows;
+        const uint32_t m = mraw[g];
         wr[g] = (in && x + 1 < cols) ? lut[m & 255] : 0.0f;
         wd[g] = (in && y + 1 < rows) ? lut[(m >> 8) & 255] : 0.0f;
         dir[g] = in && (m & kMetaDirichlet);
@@ -612,7 +640,7 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
     {
         const int y = y0 - 1;
         const bool ok = colok && y >= 0 && y + 1 < rows;
-        wu0 = ok ? lut[(M[(size_t)y * ip + x] >> 8) & 255] : 0.0f;
+        wu0 = ok ? lut[(mup >> 8) & 255] : 0.0f;
     }
 #pragma unroll
     for (int g = 0; g < R; g++) {
@@ -638,10 +666,12 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
     };
 
     bool gone = false;                           // a wait inside this workgroup ran into its bound (see the read loop): stop waiting
+    const int tile_id_tl = by * gx + bx; (void)tile_id_tl;
     auto sweep = [&](float (&cur)[R], float (&oth)[R], int s, auto fast, bool last, auto parity) {
         constexpr bool FAST = decltype(fast)::value;
         constexpr int buf = decltype(parity)::value;
         float up, dn;
+        RTDD_TL(0, s);
         {
             const long long *pu = (const long long *)&edge[buf][up_w][lane] + up_half, *pd = (const long long *)&edge[buf][dn_w][lane] + dn_half;
             auto read_both = [&]() {                 // (value, tag) of either neighbour in one 8-byte read each; true when both tags are there
@@ -666,7 +696,11 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
                 if (gone) { up = 0.0f; dn = 0.0f; }
             }
         }
-        const float omega = omegas[s];
+#ifdef RTDD_TIMELINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        RTDD_TL(1, s);
+        const float omega = omegas[s], gamma_v = gamma;     // (scalar operands: the vector form measured no faster, see k_sweep_blocked)
         auto wsum = [&](int g) {
             const float xl = lane_from_prev(cur[g]);
             const float xu = g == 0 ? up : cur[g - 1], xd = g == R - 1 ? dn : cur[g + 1];
@@ -676,8 +710,11 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
             if (CONTRACT) {
                 // sum = fma(wr, x of the NEXT lane, sum) with the lane shift as the instruction's own DPP operand (lane 63 reads 0, as
                 // lane_from_next gives it): one instruction instead of v_mov_b32_dpp + v_fmac -- hipcc does not fold wave shifts itself
-                // (s_nop 1: a DPP read needs two wait states after a VALU write of its source, and the hazard recogniser does not look inside asm)
-                asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(sum) : "v"(cur[g]), "v"(wr[g]));
+                // (a DPP read needs two wait states after a VALU write of its SOURCE register and five after a VALU write of EXEC; the hazard
+                // recogniser does not look inside asm.  The source here is cur[g], last written by the previous sweep's update dozens of
+                // instructions earlier, and the loop has no v_cmpx: tests/test_isa_hazards.py checks both on the disassembly of every build
+                // instead of paying an s_nop 1 -- 1.5 of ~60 issue cycles per pixel -- in front of every one)
+                asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(sum) : "v"(cur[g]), "v"(wr[g]));
             } else {
                 sum = sum + wr[g] * lane_from_next(cur[g]);
             }
@@ -699,14 +736,16 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
                 const int g = gs[k];
                 const float r = __builtin_amdgcn_fmed3f(qs[k], 0.0f, 255.0f);
                 const float xc = cur[g], prev = oth[g];
-                const float v = CONTRACT ? __builtin_fmaf(omega, __builtin_fmaf(gamma, r - xc, xc) - prev, prev)      // src/GPUSolver.cu:259
-                                         : (omega * (gamma * (r - xc) + xc - prev)) + prev;
+                const float v = CONTRACT ? __builtin_fmaf(omega, __builtin_fmaf(gamma_v, r - xc, xc) - prev, prev)      // src/GPUSolver.cu:259
+                                         : (omega * (gamma_v * (r - xc) + xc - prev)) + prev;
                 oth[g] = dir[g] ? xc : v;
             }
         };
         pair(0, R - 1);
         if (!last) publish(buf ^ 1, oth[0], oth[R - 1], s + 2);
+        RTDD_TL(2, s);
         pair(1, 2);
+        RTDD_TL(3, s);
     };
 
     publish(0, a[0], a[R - 1], 1);
@@ -756,8 +795,10 @@ struct TileCfg { int lx, nt, g; };
 // id -> (lanes per tile row, threads, rows per thread); extended tile = 4*lx wide, nt/lx*g tall
 static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 1024, 4}, {32, 1024, 3}, {32, 512, 3}, {16, 512, 3}, {16, 256, 3}, {32, 1024, 2},
                                  {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}, {32, 768, 4}, {32, 512, 6},
-                                 {16, 1024, 1} /* 14: tile 9's geometry in the column layout (k_sweep_col) */};
-constexpr int kNumTiles = 14;
+                                 {16, 1024, 1} /* 14: tile 9's geometry in the column layout (k_sweep_col) */,
+                                 {16, 512, 1} /* 15: the column layout on 64 x 32 (8 waves) */, {16, 768, 1} /* 16: ... on 64 x 48 (12 waves) */};
+constexpr int kNumTiles = 16;
+static inline bool is_col_tile(int tile) { return tile >= 14; }
 
 // Can every workgroup of a persistent launch be resident at once?  Asked of the runtime once per kernel (the answer depends on the
 // kernel's registers and LDS): at least one workgroup of `nthreads` threads per CU, and no more workgroups than CUs.  A launch that
@@ -803,7 +844,7 @@ static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, fl
 //   persistent                 T sweeps + ~8 us halo exchange (6 us for the small tiles); needs nWG <= #CUs, T even,
 //                              halo no wider than a neighbour's centre
 // It only has to rank candidates; it reproduces the measured launch times within ~15 %.
-static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1, 2};
+static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1, 2, 4, 2};
 
 static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int tile, int T, bool persist) {
     const int G = kTiles[tile].g;
@@ -819,7 +860,7 @@ static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int ti
     const double bw = img_bytes > 2e8 ? 17600.0 : 22600.0;      // bytes/us per CU: 4.5 TB/s from HBM (8K), 5.8 TB/s from the Infinity Cache
     const double load1 = small * ext * 12.0 / bw, store1 = small * (double)TW * TH * 8.0 / bw;
     if (persist) {
-        if (tile == 14 || nwg > cus || (T & 1) || hx > TW || T > TH || n <= T) return 1e30;
+        if (is_col_tile(tile) || nwg > cus || (T & 1) || hx > TW || T > TH || n <= T) return 1e30;
         return (T * (lat > thr1 ? lat : thr1) + 5.0 + 3.0 * ext / 12288.0) / T;
     }
     const int k = kWgPerCu[tile];
@@ -921,7 +962,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         bool persistent = !single && want_persistent && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= (unsigned)kSyncMaxTiles &&
                                 (T % 2 == 0) && n - done > T && hy == T &&
                                 hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
-        if (tile == 14) persistent = false;                 // (the column-layout kernel has no persistent mode)
+        if (is_col_tile(tile)) persistent = false;          // (the column-layout kernel has no persistent mode)
         if (persistent) {
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) case id: persistent = persistent_possible<LX_, NT_, G_>(ctx, tile, kTiles[tile].nt); break;
             switch (tile) { RTDD_ALL_TILES }
@@ -945,7 +986,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         float *Yk = L.P(free0, ip), *Ym = L.P(free1, ip);
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) \
     case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps, flag_base); break;
-        if (tile == 14) {
+        if (is_col_tile(tile)) {
             const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
             if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
             else hipLaunchKernelGGL(k_sweep_col<false>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);

@@ -7,9 +7,9 @@
 #include <cstdlib>
 namespace rtdd {
 int fail(rtdd_ctx *, int s, const char *, hipError_t) { return s; }
-int prepare_persistent_launch(rtdd_ctx *ctx) {
+int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
     if (!ctx->sync_words) { (void)hipMalloc((void **)&ctx->sync_words, kSyncWords * sizeof(int)); (void)hipMemset(ctx->sync_words, 0, kSyncWords * sizeof(int)); }
-    (void)hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, kSyncMaxTiles * sizeof(int), ctx->stream);
+    *flag_base = ctx->flag_epoch; ctx->flag_epoch += nblocks + 1;
     return 0;
 }
 }
@@ -19,7 +19,7 @@ int main(int argc, char **argv) {
     int nsweeps = argc > 5 ? atoi(argv[5]) : 32;
     rtdd_ctx ctx; ctx.opt.tile = tile; ctx.opt.temporal_depth = T; ctx.opt.persistent = argc > 6 ? atoi(argv[6]) : 1; ctx.num_cus = 256;
     { int t = argc > 7 ? atoi(argv[7]) : 100; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_tile), &t, sizeof(t)); }
-    rtdd::prepare_persistent_launch(&ctx);
+    { int fb; rtdd::prepare_persistent_launch(&ctx, 0, &fb); for (auto &t : ctx.persist_fit) t[0] = t[1] = -1; }
     Level L; size_t ip = plane_pitch(cols); L.elems = plane_elems(rows, cols);
     std::vector<float> h(L.elems); for (auto &v : h) v = (float)(rand() % 25500) / 100.0f;
     std::vector<uint32_t> hm(L.elems); for (auto &v : hm) v = (rand() % 12) | ((rand() % 12) << 8) | ((rand() % 10 == 0) ? kMetaDirichlet : 0);
@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
     unsigned long long t0 = ~0ull;
     for (int w = 0; w < 16; w++) if (tl[w][0][0]) t0 = std::min(t0, tl[w][0][0]);
     printf("%dx%d tile %d T %d, %d sweeps; per wave and sweep: top-of-sweep / rows-in-hand / published / end, in shader cycles from the first stamp\n", cols, rows, tile, T, nsweeps);
-    for (int s = 0; s < std::min(nsweeps, 24); s++) {
+    for (int s = 0; s < std::min(nsweeps, 30); s++) {
         printf("sweep %2d:", s);
         for (int w = 0; w < 16; w++) if (tl[w][s][0]) printf(" w%-2d %6llu+%4llu+%4llu+%4llu |", w, tl[w][s][0] - t0, tl[w][s][1] - tl[w][s][0], tl[w][s][2] - tl[w][s][1], tl[w][s][3] - tl[w][s][2]);
         printf("\n");
