@@ -59,6 +59,10 @@ VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 # path: 392 VALU instructions per 2 sweeps x 12 pixels; 4 fma for the sum, 3 for the divide, 1.5 for the tiny-numerator test, 6
 # for clamp + update + Dirichlet select, 0.5 DPP, ~1.3 bookkeeping).  Halo redundancy is NOT counted: `achieved` is useful work.
 VALU_OPS = {"jacobi": 16.3, "rbgs": 15.0, "sor_cycles": 15.0}
+# What the sweep's instruction MIX can issue at: scripts/ubench/valu_mix.hip (profiles/r03_valu_mix.txt) measures 3.77 cycles per
+# wave-instruction and SIMD for one pixel's forms in their proportions at 4 waves per SIMD -- clamp, compare, DPP and select forms run at
+# the SIMD-16 rate, plain fma at 3.2 -- against the 2 cycles `peak` assumes.  Reported beside `frac`, never instead of it.
+VALU_MIX_CYCLES = 3.77
 
 
 def free_port():
@@ -172,7 +176,8 @@ def valu_roofline(px_sweeps_per_s, method):
     if ops is None:
         return None
     achieved = ops * px_sweeps_per_s / 1e12
-    return {"achieved": achieved, "peak": VALU_PEAK_TOPS, "frac": achieved / VALU_PEAK_TOPS, "ops_per_pixel_sweep": ops}
+    return {"achieved": achieved, "peak": VALU_PEAK_TOPS, "frac": achieved / VALU_PEAK_TOPS, "ops_per_pixel_sweep": ops,
+            "mix_issue_cycles_measured": VALU_MIX_CYCLES, "frac_of_mix_issue_rate": achieved / VALU_PEAK_TOPS * VALU_MIX_CYCLES / 2.0}
 
 
 def sweep_4k(rt, dev, steps=10):
@@ -415,6 +420,7 @@ def main():
         if v is not None:
             out["roofline"] = {"bound": "valu", "achieved": v["achieved"], "peak": v["peak"], "unit": "Tlane-op/s", "frac": v["frac"], "traffic": None,
                                "kernel": kname, "launch_us": launch_us, "ops_per_pixel_sweep": v["ops_per_pixel_sweep"],
+                               "mix_issue_cycles_measured": v["mix_issue_cycles_measured"], "frac_of_mix_issue_rate": v["frac_of_mix_issue_rate"],
                                "definition": "useful pixel-sweeps/s of the kernel x VALU operations per pixel-sweep (static ISA count) / (256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz); halo redundancy not credited",
                                "hbm_equivalent": hbm_equivalent}
         else:                                   # the V-cycle is a chain of streaming kernels: HBM is its roof

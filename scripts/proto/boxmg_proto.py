@@ -36,8 +36,12 @@ def fine_level(gray, mask, beta=0.4):
     free = mask != 255
     D = np.where(free, wr + wd + shift(wr, 0, -1) + shift(wd, -1, 0), 0.0)          # includes links to Dirichlet pixels
     theta = float(os.environ.get("THETA", "0"))                                      # links weaker than theta stay in D only (anchors)
-    E = np.where(free & shift(free, 0, 1) & (wr >= theta), wr, 0.0)                   # links to inactive points are dropped
-    S = np.where(free & shift(free, 1, 0) & (wd >= theta), wd, 0.0)
+    rel = float(os.environ.get("REL", "0"))                                          # experiment: links weaker than rel x the strongest link of EITHER endpoint stay in D only
+    mx = np.maximum(np.maximum(wr, wd), np.maximum(shift(wr, 0, -1), shift(wd, -1, 0)))
+    okr = wr >= rel * np.minimum(mx, shift(mx, 0, 1)) if os.environ.get("RELMODE", "min") == "min" else wr >= rel * np.maximum(mx, shift(mx, 0, 1))
+    okd = wd >= rel * np.minimum(mx, shift(mx, 1, 0)) if os.environ.get("RELMODE", "min") == "min" else wd >= rel * np.maximum(mx, shift(mx, 1, 0))
+    E = np.where(free & shift(free, 0, 1) & (wr >= theta) & okr, wr, 0.0)             # links to inactive points are dropped
+    S = np.where(free & shift(free, 1, 0) & (wd >= theta) & okd, wd, 0.0)
     DT = np.dtype(os.environ.get("DT", "float64"))
     return tuple(a.astype(DT) for a in (E, S, np.zeros_like(E), np.zeros_like(E), D)), (wr.astype(DT), wd.astype(DT), free)
 

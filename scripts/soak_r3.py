@@ -1,0 +1,62 @@
+"""Round-3 soak of the persistent hand-off (sc1 halo loads without an agent acquire, monotonic flags): N back-to-back persistent
+1080p solves -- 3 of 5 Chebyshev-Jacobi x 1000 (125 exchanges of 252 workgroups each), 1 red-black SOR x 200, 1 V-cycle x 3 -- while a
+second stream streams 1 GiB through the memory system every third solve (uneven load, warm caches), then M cold 1080p estimates.
+EVERY Jacobi result must equal the CPU oracle's bits (computed once here), every other result its first run's, and
+rtdd_ctx_synchronize must never report a timeout.  usage: soak_r3.py [N solves] [M estimates]"""
+import sys, os, time, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import oracle                                             # the checker (this is a test script, not the product)
+import realtimedepthdiffusion_amd as rt
+from realtimedepthdiffusion_amd.synth import make_problem
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+m_est = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+rows, cols = 1080, 1920
+p = make_problem(rows, cols, seed=1234)
+lut = oracle.load_weights(0.4)
+want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 1000, 0, 0, lut, 1, threads=oracle.max_threads())
+ref = {"jacobi": hashlib.sha1(want.tobytes()).hexdigest()}
+main, side = torch.cuda.Stream(), torch.cuda.Stream()
+c = rt.Context(0); c.set_stream(main.cuda_stream); c.GPULoadWeights(0.4); c.GPUAllocateDeviceMemory(rows, cols, 1)
+m = rt.device_image(p["mask"]); g = rt.device_image(p["gray"]); src = rt.device_image(p["depth"])
+noise = torch.empty(256 << 20, dtype=torch.float32, device="cuda:0")
+torch.cuda.synchronize()
+t = time.time()
+for i in range(n):
+    kind = ("jacobi", "jacobi", "jacobi", "sor", "mg")[i % 5]
+    with torch.cuda.stream(main):
+        d = src.clone()
+    main.synchronize()
+    if i % 3 == 0:
+        with torch.cuda.stream(side):
+            noise.mul_(1.0001)                            # a bandwidth hog overlapping this solve
+    if kind == "jacobi": c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 1000, 1e-5, 0)
+    elif kind == "sor": c.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=200, relaxation=1.9)
+    else: c.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_MULTIGRID, maxIterations=3)
+    c.synchronize()                                       # raises on RTDD_ERR_TIMEOUT
+    h = hashlib.sha1(d.cpu().numpy().tobytes()).hexdigest()
+    assert ref.setdefault(kind, h) == h, (i, kind, "differs from " + ("the ORACLE" if kind == "jacobi" else "its first run"))
+    if i % 1000 == 999: print(i + 1, "solves ok, %.1f s" % (time.time() - t), flush=True)
+print("soak ok:", n, "solves (every Jacobi result == the oracle's bits),", {k: v[:12] for k, v in ref.items()}, flush=True)
+c.close(); torch.cuda.synchronize()
+
+from cascade_ref import Cascade                           # tests/cascade_ref.py
+bgr = np.repeat(p["gray"][..., None], 3, 2)
+ann = np.where(p["mask"] == 255, p["edited"][..., 0], 32).astype(np.uint8)
+cas = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads()); cas.estimate(1000)
+ref_e = hashlib.sha1(cas.depth[0].tobytes()).hexdigest()
+c = rt.Context(0); c.set_stream(main.cuda_stream); c.GPULoadWeights(0.4); c.pyramid_create(rows, cols)
+img, an = rt.device_image(bgr), rt.device_image(ann)
+torch.cuda.synchronize()
+t = time.time()
+for i in range(m_est):
+    c.pyramid_set_image(img); c.pyramid_set_annotation(an)          # resets the depth pyramid: a cold estimate
+    if i % 3 == 0:
+        with torch.cuda.stream(side):
+            noise.mul_(1.0001)
+    c.estimate_depth(1000)
+    c.synchronize()
+    h = hashlib.sha1(c.pyramid_download(rt.IMG_DEPTH, 0).tobytes()).hexdigest()
+    assert h == ref_e, (i, "estimate differs from the oracle cascade")
+    if i % 500 == 499: print(i + 1, "estimates ok, %.1f s" % (time.time() - t), flush=True)
+print("soak ok:", m_est, "estimates, every one == the oracle cascade's bits", ref_e[:12])
