@@ -170,6 +170,15 @@ def haze(orig, depth, contract):
     return art
 
 
+def expf_det(x):
+    """The deterministic exp of orc_haze (orc_expf_det) on an array; returns (values, how many differ from this host's libm expf)."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().orc_expf_vs_libm.restype = C.c_int
+    n = int(lib().orc_expf_vs_libm(_p(x), _p(out), C.c_int(x.size)))
+    return out, n
+
+
 def residual(x, idx, mask, lut, contract):
     rows, cols = x.shape
     x = np.ascontiguousarray(x, np.float32)

@@ -338,15 +338,49 @@ ORC_API void orc_defocus_at(const uint8_t *orig, size_t origPitch, const float *
 
 /* =====================================================================================
  * a12  GPUSimulateHaze (K10) -- src/GPUDepthEffect.cu:74-93
- * expf here is host libm; the CUDA device expf (<= 2 ulp) is not reproducible anywhere.
+ * The reference calls CUDA's device expf (<= 2 ulp, libdevice): not reproducible anywhere.  Up to round 2 this restatement
+ * used the host libm's expf and the GPU a device exp, equal in all but ~2^-29 of cases -- a tolerance, not an identity.
+ * Now BOTH sides evaluate exp by the same fixed sequence of IEEE f64 operations (no libm): k = rint(x / ln 2), r = x - k ln 2
+ * with a two-part ln 2 (fma), a degree-13 Taylor polynomial in Horner form (fma; truncation < 2^-57 for |r| <= 0.35), scaling
+ * by 2^k, ONE rounding to f32.  Faithful (< 0.5000001 ulp; orc_expf_vs_libm below counts where it differs from this host's
+ * expf: tests/test_oracle.py), and identical on the host and on the device by construction
+ * (csrc/effect_kernels.hip expf_det: the same literals, the same operations, no contraction on either side).
  * ===================================================================================*/
+static float orc_expf_det(float x) {
+    if (x != x) return x;
+    if (x > 89.0f) return INFINITY;
+    if (x < -104.0f) return 0.0f;                        /* exp(-104) < 2^-150: rounds to 0 */
+    const double xd = (double)x;
+    const double kd = rint(xd * 0x1.71547652b82fep+0);
+    const double r = fma(-kd, 0x1.a39ef35793c76p-33, fma(-kd, 0x1.62e42fee00000p-1, xd));
+    double p = 0x1.6124613a86d09p-33;                    /* 1/13! ... 1/2! */
+    p = fma(p, r, 0x1.1eed8eff8d898p-29); p = fma(p, r, 0x1.ae64567f544e4p-26); p = fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = fma(p, r, 0x1.71de3a556c734p-19); p = fma(p, r, 0x1.a01a01a01a01ap-16); p = fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = fma(p, r, 0x1.6c16c16c16c17p-10); p = fma(p, r, 0x1.1111111111111p-7); p = fma(p, r, 0x1.5555555555555p-5);
+    p = fma(p, r, 0x1.5555555555555p-3); p = fma(p, r, 0x1.0000000000000p-1); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    union { uint64_t u; double d; } s;
+    s.u = (uint64_t)((int)kd + 1023) << 52;              /* 2^k, k in [-151, 129] */
+    return (float)(p * s.d);
+}
+
+/* test hook: out[i] = orc_expf_det(x[i]); returns how many of them differ from this host's libm expf */
+ORC_API int orc_expf_vs_libm(const float *x, float *out, int n) {
+    int differ = 0;
+    for (int i = 0; i < n; i++) {
+        out[i] = orc_expf_det(x[i]);
+        const float l = expf(x[i]);
+        if (!(out[i] == l) && !(out[i] != out[i] && l != l)) differ++;
+    }
+    return differ;
+}
+
 ORC_API void orc_haze(const uint8_t *orig, size_t origPitch, const float *depth, size_t depthPitch,
                       uint8_t *art, size_t artPitch, int rows, int cols, int contract) {
     for (int y = 0; y < rows; y++) {
         const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
         for (int x = 0; x < cols; x++) {
             float beta = 2;
-            float t = expf((float)((double)(-beta * drow[x]) / 255.0)); /* :88 */
+            float t = orc_expf_det((float)((double)(-beta * drow[x]) / 255.0)); /* :88 */
             for (int c = 0; c < 3; c++) {                                /* :89-91 */
                 float o = (float)orig[(size_t)y * origPitch + x * 3 + c];
                 float w = (1 - t) * 255;

@@ -27,11 +27,28 @@ __device__ __forceinline__ uint32_t desat_px(float d, float g, float o) {
     return store_u8(CONTRACT ? __builtin_fmaf(f, g, t) : f * g + t);
 }
 
-// simulateHaze (K10) -- src/GPUDepthEffect.cu:74-93.  exp is evaluated in f64 and rounded once to f32: the
-// correctly rounded expf in all but ~2^-29 of cases, which is also what the host libm the oracle uses delivers.
+// simulateHaze (K10) -- src/GPUDepthEffect.cu:74-93.  exp by the SAME fixed sequence of IEEE f64 operations as the CPU restatement's
+// deterministic exp (the test infrastructure's a12 section: the same literals, the same fma chain, one rounding to f32, no libm on either side), so the
+// transmission t -- and with it every output byte -- is bit-identical to the restatement's.  (CUDA's device expf, which the
+// reference calls, is a <= 2 ulp libdevice routine and not reproducible anywhere; this one is faithful to < 0.5000001 ulp.)
+__device__ __forceinline__ float expf_det(float x) {
+    if (x != x) return x;
+    if (x > 89.0f) return __builtin_inff();
+    if (x < -104.0f) return 0.0f;                                   // exp(-104) < 2^-150: rounds to 0
+    const double xd = (double)x;
+    const double kd = __builtin_rint(xd * 0x1.71547652b82fep+0);
+    const double r = __builtin_fma(-kd, 0x1.a39ef35793c76p-33, __builtin_fma(-kd, 0x1.62e42fee00000p-1, xd));
+    double p = 0x1.6124613a86d09p-33;                               // 1/13! ... 1/2!
+    p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29); p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26); p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19); p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16); p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10); p = __builtin_fma(p, r, 0x1.1111111111111p-7); p = __builtin_fma(p, r, 0x1.5555555555555p-5);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3); p = __builtin_fma(p, r, 0x1.0000000000000p-1); p = __builtin_fma(p, r, 1.0); p = __builtin_fma(p, r, 1.0);
+    const double s = __builtin_bit_cast(double, (unsigned long long)((int)kd + 1023) << 52);      // 2^k, k in [-151, 129]
+    return (float)(p * s);
+}
 __device__ __forceinline__ float haze_t(float d) {
     const float arg = (float)((double)(-2.0f * d) / 255.0);        // :88
-    return (float)exp((double)arg);
+    return expf_det(arg);
 }
 template <bool CONTRACT>
 __device__ __forceinline__ uint32_t haze_px(float t, float w, float o) {

@@ -88,8 +88,7 @@ def test_effects_match_golden(ctx, name):
     ctx.GPUSimulateDefocus(o, d, art, 256, 256)
     assert np.array_equal(down(art), g["defocus"])
     ctx.GPUSimulateHaze(o, d, art, 256, 256)
-    diff = np.abs(down(art).astype(np.int32) - g["haze_c1"].astype(np.int32))
-    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4
+    assert np.array_equal(down(art), g["haze_c1"])
 
 
 @pytest.mark.parametrize("name", NAMES)

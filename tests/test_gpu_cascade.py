@@ -187,5 +187,4 @@ def test_full_size_dataset_pair_end_to_end(oracle, lut):
         c.GPUSimulateDefocus(o, d, art, rows, cols)
         assert np.array_equal(down(art), oracle.defocus(bgr, ref.depth[0], threads=min(8, oracle.max_threads())))
         c.GPUSimulateHaze(o, d, art, rows, cols)
-        diff = np.abs(down(art).astype(np.int32) - oracle.haze(bgr, ref.depth[0], 1).astype(np.int32))
-        assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4
+        assert np.array_equal(down(art), oracle.haze(bgr, ref.depth[0], 1))          # bit-exact since round 3: one deterministic exp on both sides

@@ -83,8 +83,7 @@ def test_all_ten_reference_symbols_in_main_cpp_order(oracle, lut, rows, cols):
     assert np.array_equal(down(art), oracle.desaturate(bgr, ref.gray[0], ref.depth[0], 1))
     _fn("_Z15GPUSimulateHazePhmPfmS_mii")(*_img(orig), *_img(depth[0]), *_img(art), i32(rows), i32(cols))
     torch.cuda.synchronize()
-    diff = np.abs(down(art).astype(np.int32) - oracle.haze(bgr, ref.depth[0], 1).astype(np.int32))
-    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4
+    assert np.array_equal(down(art), oracle.haze(bgr, ref.depth[0], 1))
     _fn("_Z19GPUFreeDeviceMemoryi")(i32(P))
     # after the free the shim reports the call-order violation like the reference would fail: prints, does not crash
     solve(*_img(depth[0]), *_img(scribble[0]), *_img(gray[0]), i32(rows), i32(cols), f32(0.4), i32(1), f32(1e-5), i32(0))

@@ -3,9 +3,8 @@ compared with the CPU oracle on the same seeded inputs.
 
 Stated tolerance (BASELINE.json north_star): depth maps within 1e-4 max-abs.  Because the HIP
 kernels repeat the oracle's f32 operations one for one, the tests assert the stronger property
--- BIT-EXACT equality -- for the solver, the index pass, the annotation kernels, desaturation
-and defocus; haze (device exp vs host libm expf) is held to <= 1 grey level on <= 1e-4 of the
-values."""
+-- BIT-EXACT equality -- for the solver, the index pass, the annotation kernels and the three
+depth effects (haze since round 3: one deterministic exp on both sides)."""
 import numpy as np
 import pytest
 

@@ -262,3 +262,19 @@ def test_summed_area_restatement_of_defocus_agrees_with_the_literal_gather(oracl
     assert np.array_equal(defocus_by_summed_area_table(orig, depth), lit)
     ys = np.array([0, 10, 299, 150, 77]); xs = np.array([0, 400, 419, 200, 5])
     assert np.array_equal(oracle.defocus_at(orig, depth, ys, xs), lit[ys, xs])
+
+
+def test_deterministic_exp_of_the_haze_restatement(oracle):
+    """orc_expf_det (the exp the haze restatement and the GPU kernel share: a fixed f64 operation sequence, no libm): equal to the
+    correctly rounded f32 of numpy's f64 exp on 3 M samples, special values as IEEE wants them, and different from this host's libm expf on
+    well under 0.2 % of the samples (glibc's expf is NOT correctly rounded: it misrounds ~0.06 % of arguments)."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-3, 0.6, 2_000_000), rng.uniform(-110, 95, 1_000_000),
+                        np.array([0, -0.0, 1e-40, -1e-40, 88.7, -103.9, -87.5, -100.0])]).astype(np.float32)
+    v, n_differ = oracle.expf_det(x)
+    with np.errstate(all="ignore"):
+        ref = np.exp(x.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(v, ref)
+    assert n_differ < 0.002 * x.size                             # glibc's expf misrounds ~0.06 % of arguments; this one none of these
+    sp, _ = oracle.expf_det(np.array([np.nan, np.inf, -np.inf, 89.5, -104.5], np.float32))
+    assert np.isnan(sp[0]) and sp[1] == np.inf and sp[2] == 0 and sp[3] == np.inf and sp[4] == 0
