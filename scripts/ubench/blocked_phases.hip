@@ -7,9 +7,9 @@
 #include <cstdlib>
 namespace rtdd {
 int fail(rtdd_ctx *, int s, const char *, hipError_t) { return s; }
-int prepare_persistent_launch(rtdd_ctx *ctx) {
-    if (!ctx->sync_words) { hipMalloc((void **)&ctx->sync_words, kSyncWords * sizeof(int)); hipMemset(ctx->sync_words, 0, kSyncWords * sizeof(int)); }
-    hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, kSyncMaxTiles * sizeof(int), ctx->stream);
+int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
+    if (!ctx->sync_words) { (void)hipMalloc((void **)&ctx->sync_words, kSyncWords * sizeof(int)); (void)hipMemset(ctx->sync_words, 0, kSyncWords * sizeof(int)); }
+    *flag_base = ctx->flag_epoch; ctx->flag_epoch += nblocks + 1;
     return 0;
 }
 }
@@ -17,7 +17,7 @@ using namespace rtdd;
 int main(int argc, char **argv) {
     int rows = argc > 1 ? atoi(argv[1]) : 1080, cols = argc > 2 ? atoi(argv[2]) : 1920, tile = argc > 3 ? atoi(argv[3]) : 4, T = argc > 4 ? atoi(argv[4]) : 8;
     rtdd_ctx ctx; ctx.opt.tile = tile; ctx.opt.temporal_depth = T;
-    rtdd::prepare_persistent_launch(&ctx);
+    { int fb; rtdd::prepare_persistent_launch(&ctx, 0, &fb); for (auto &t : ctx.persist_fit) t[0] = t[1] = -1; }
     if (getenv("RTDD_STREAM")) { hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking); printf("using a created stream\n"); }
     Level L; size_t ip = plane_pitch(cols); L.elems = plane_elems(rows, cols);
     std::vector<float> h(L.elems); for (auto &v : h) v = (float)(rand() % 25500) / 100.0f;
