@@ -1,5 +1,8 @@
-"""The N > 1 path on CPU: two gloo ranks shard a batch of independent images, 'solve' them with the
-oracle, and the aggregate matches a single-process run -- no data-path collective involved."""
+"""The N > 1 PLUMBING on CPU: two gloo ranks deal a batch of independent images round-robin, the SUM / MAX aggregation of
+bench.py and the barrier work, and nothing crosses ranks on the data path.  There is no GPU here and the product has no CPU
+fallback, so the per-image work is stood in for by the oracle -- this file checks the sharding code, not the solver.  The
+PRODUCT under two ranks is checked on the GPU box: tests/test_bench_launcher.py::test_two_ranks_results_equal_the_oracle
+(every rank's depth maps against the oracle, bit for bit)."""
 import os
 import socket
 
