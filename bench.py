@@ -305,13 +305,17 @@ def main():
         import torch.distributed as dist
         # The data path has NO collective (independent images); the process group only serves the timing barrier and
         # the MAX/SUM of two scalars.  RCCL ("nccl") is used when it comes up, gloo otherwise -- the result is the same.
-        # One backend for ALL ranks, decided before the rendezvous (RTDD_BENCH_BACKEND; default RCCL on GPUs, gloo for --dry-run and
-        # for ranks sharing a GPU): a per-rank fallback could leave the ranks on different backends, waiting at the first barrier.
-        # A rank that cannot bring the backend up fails loudly and the launcher ends the others.
+        # Every rank joins a gloo group first (it always comes up); whether the timing barrier then runs over RCCL is decided by ALL
+        # ranks together (shard.timing_group): a rank-by-rank fallback could leave the ranks on different backends, waiting at the
+        # first barrier.  RTDD_BENCH_BACKEND=gloo keeps everything on gloo (default for --dry-run and for ranks sharing a GPU).
         import datetime
-        backend = os.environ.get("RTDD_BENCH_BACKEND") or ("gloo" if (dry or share_gpu) else "nccl")
-        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
-        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=120), **kw)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+        want_rccl = (os.environ.get("RTDD_BENCH_BACKEND") or ("gloo" if (dry or share_gpu) else "nccl")) == "nccl"
+        tgroup, tbackend = shard.timing_group(dist, f"cuda:{local}", want_rccl)
+        if want_rccl and tbackend != "nccl" and rank == 0:
+            print("[bench] RCCL did not come up on every rank: the timing barrier runs over gloo (the data path has no collective either way)", file=sys.stderr)
+    else:
+        tgroup, tbackend = None, "none"
 
     if args.workload not in WORKLOADS:          # ROWSxCOLSxITERS, or batchB_ROWSxCOLSxITERS (a fixed batch of B images dealt round-robin)
         spec = args.workload
@@ -336,7 +340,7 @@ def main():
             time.sleep(0.001 * len(my_images))
 
         def fence():
-            shard.fence(dist, None)
+            shard.fence(dist, None, tgroup)
         ctx = None
     else:
         problems = [make_problem(rows, cols, seed=1234 + i) for i in my_images]
@@ -367,7 +371,7 @@ def main():
                     ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, iters, 1e-5, 0)
 
         def fence():
-            shard.fence(dist, torch.cuda.synchronize)
+            shard.fence(dist, torch.cuda.synchronize, tgroup)
 
     for i in range(args.warmup):
         step(i)
@@ -390,8 +394,8 @@ def main():
     else:
         px_iter_per_image = rows * cols * iters
     algo_bytes = ALGO_BYTES[method]
-    agg_dev = "cpu" if (dry or dist is None or dist.get_backend() != "nccl") else dev
-    units, elapsed, thr = shard.aggregate(args.steps * len(my_images) * px_iter_per_image, elapsed, dist, agg_dev)   # SUM of units, MAX of time
+    agg_dev = dev if tbackend == "nccl" else "cpu"
+    units, elapsed, thr = shard.aggregate(args.steps * len(my_images) * px_iter_per_image, elapsed, dist, agg_dev, tgroup)   # SUM of units, MAX of time
     n_images = batch if batch else world
     value = thr / 1e6
     launch_us = sweep_ms * 1e3 / max(launches, 1)
@@ -407,7 +411,8 @@ def main():
         "config": {"workload": (f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps (BASELINE configs[1])" if default_line else
                                 f"{args.workload}: {batch} independent {cols}x{rows} images x {iters} Chebyshev-Jacobi sweeps, image i on rank i % {world}, one stream per GPU" + (" (BASELINE configs[3])" if args.workload == "batch64_1080p" else "") if batch else
                                 f"{args.workload} ({method})"),
-                   "images_per_step": n_images, "images_this_rank": len(my_images), "sweeps_per_launch": sweeps_per_launch},
+                   "images_per_step": n_images, "images_this_rank": len(my_images), "sweeps_per_launch": sweeps_per_launch,
+                   "timing_barrier_backend": tbackend},
     }
     if info is not None:
         out["config"].update({"kernel": info.kernel, "tile": info.tile, "temporal_depth": info.temporal_depth, "persistent": info.persistent, "fp_contract": info.fp_contract})
@@ -466,7 +471,7 @@ def main():
             shas.append(hashlib.sha256(got.tobytes()).hexdigest()[:16])
         flag = torch.tensor([len(bad)], dtype=torch.float64, device=agg_dev)
         if dist is not None:
-            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=tgroup)
         out["verified"] = {"against": "oracle.solve, bit for bit" if method == "jacobi" else "(hash only: no fixed-count oracle for this method)", "images_differing_all_ranks": int(flag.item()),
                            "rank0_images": [my_images[k] for k in range(len(problems))], "rank0_sha256_16": shas}
     if executed:

@@ -11,23 +11,46 @@ def images_for_rank(n_images, world, rank):
     return list(range(rank, n_images, world))
 
 
-def fence(dist=None, device_sync=None):
-    """Barrier bracketed by device syncs, as the bench contract asks."""
+def fence(dist=None, device_sync=None, group=None):
+    """Barrier bracketed by device syncs, as the bench contract asks.  `group`: the process group to use (None = the default one)."""
     if device_sync is not None:
         device_sync()
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        dist.barrier(group=group)
         if device_sync is not None:
             device_sync()
 
 
-def aggregate(units_local, elapsed_local, dist=None, device="cpu"):
+def aggregate(units_local, elapsed_local, dist=None, device="cpu", group=None):
     """Whole-job throughput = units processed by ALL ranks / MAX over ranks of the elapsed time."""
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(units_local), float(elapsed_local), float(units_local) / float(elapsed_local)
     t = torch.tensor([float(elapsed_local)], dtype=torch.float64, device=device)
     u = torch.tensor([float(units_local)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)
     return float(u.item()), float(t.item()), float(u.item()) / float(t.item())
+
+
+def timing_group(dist, device, want_rccl, timeout_s=120):
+    """The process group for the timing barrier and the two scalar reductions (nothing else crosses ranks).  Every rank is already
+    in a gloo default group (it always comes up).  If RCCL is wanted, all ranks create an RCCL group and try one all-reduce on it;
+    whether that worked is agreed over gloo (MIN of a flag), so either ALL ranks use RCCL or ALL stay on gloo -- a rank-by-rank
+    fallback could leave the ranks on different backends, waiting at the first barrier.  Returns (group or None, "nccl" | "gloo")."""
+    import datetime
+    import torch
+    if not want_rccl:
+        return None, "gloo"
+    ok, g = 1, None
+    try:
+        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe, group=g)
+        torch.cuda.synchronize()
+        ok = int(abs(float(probe.item()) - dist.get_world_size()) < 0.5)
+    except Exception:                                               # noqa: BLE001
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)                     # the default (gloo) group
+    return (g, "nccl") if int(flag.item()) == 1 else (None, "gloo")

@@ -67,6 +67,16 @@ def test_two_ranks_results_equal_the_oracle():
 
 
 @pytest.mark.gpu
+def test_rccl_that_cannot_come_up_falls_back_to_gloo_on_all_ranks():
+    """Two ranks on ONE device cannot form an RCCL communicator (duplicate GPU).  Asked for RCCL anyway, every rank must end up on gloo
+    -- decided collectively (shard.timing_group), never rank by rank -- and the run must complete with verified results."""
+    d = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--workload", "batch4_270x480x60", "--verify"],
+             env={"RTDD_BENCH_SHARE_GPU": "1", "RTDD_BENCH_BACKEND": "nccl"}, timeout=600)
+    assert d["n_gpus"] == 2 and d["config"]["timing_barrier_backend"] == "gloo"
+    assert d["verified"]["images_differing_all_ranks"] == 0
+
+
+@pytest.mark.gpu
 def test_config4_batch64_on_one_gpu_verified():
     """BASELINE configs[3] at N = 1 (the base of the scaling curve): 64 independent 1080p images x 1000 sweeps on one GPU, one
     stream, every one of the 64 depth maps equal to the oracle's (--verify)."""
