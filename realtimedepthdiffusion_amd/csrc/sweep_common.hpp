@@ -1,0 +1,87 @@
+// sweep_common.hpp -- device helpers shared by the register-resident sweep kernels (sweep_blocked.hip, sweep_pk.hip): DPP lane
+// shifts, the write-through store / sc1 load of the inter-workgroup hand-off, the 3-operation divide and the rounded reciprocal.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rtdd {
+
+// bound_ctrl: the lane without a source (lane 0 / lane 63) reads 0 -- its value is never used (the weight towards it is 0
+// or the lane lies in the discarded halo) -- and the builtin needs no copy of `v` for the unwritten lane.
+__device__ __forceinline__ float lane_from_prev(float v) {   // lane l <- lane l-1  (DPP wave_shr:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_from_next(float v) {   // lane l <- lane l+1  (DPP wave_shl:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
+}
+
+// The same two shifts through the LDS crossbar (ds_bpermute_b32: no LDS memory, no VALU slot).  Why: ONE DPP instruction of any kind
+// in a loop slows the VALU instructions of the OTHER waves of its SIMD -- the sweep's instruction mix replayed on the GPU issues at
+// 3.26 cycles per wave-instruction and SIMD with its two v_mov_b32_dpp per row, at 2.24 with plain moves in their place and at 2.27
+// with ds_bpermute_b32 issued ahead (scripts/ubench/gen_block_bench.py, profiles/r03_block_replay.txt; one wave per SIMD sees no
+// difference, row_shr / quad_perm cost the same as wave_shr).  `prev4` = 4 * ((lane - 1) & 63), held in a register by the caller;
+// lane l + 1 is prev4 + 8 (the unit takes address bits 7:2).  Lane 0 reads lane 63 and lane 63 lane 0 where DPP's bound_ctrl gave
+// 0: both only ever meet a zero weight (sweep_tile_setup.inc: the right weight of a tile row's last pixel is 0, and lane 63 ends a
+// tile row for every LX), and the values are finite.  The result arrives like an LDS read: the compiler waits on lgkmcnt before
+// its first use, so the callers issue these well ahead.
+__device__ __forceinline__ float lds_from_prev(int prev4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(prev4, __float_as_int(v))); }
+__device__ __forceinline__ float lds_from_next(int prev4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(prev4 + 8, __float_as_int(v))); }
+
+// write-through (sc1) 16-byte store for inter-workgroup hand-offs (no release fence needed; the storing wave drains vmcnt itself)
+__device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+
+// 16-byte sc1 load to registers (bypasses this CU's L1, served by L2 / memory): with EVERY load of handed-off bytes of this form, every
+// store of them sc1 and drained, and the flag protocol of persist_sync.hpp, the consumer needs no agent-scope acquire
+// (MI355X_MICROARCH.md, "Valid forms", table row 1).  The value is NOT there when the statement returns: wait_loads() below.
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_sc1(f4v_t &dst, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+
+// Result stores.  RTDD_STORE_MODE (diagnostic knob): 0 plain, 1 non-temporal, 2 write-through (sc1).
+#ifndef RTDD_STORE_MODE
+#define RTDD_STORE_MODE 0
+#endif
+__device__ __forceinline__ void store_result(float4 *p, float4 v) {
+#if RTDD_STORE_MODE == 1
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+#elif RTDD_STORE_MODE == 2
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#else
+    *p = v;
+#endif
+}
+
+// ---- IEEE f32 division with a loop-invariant divisor ---------------------------------------------
+// `sum / cnt` must be the correctly rounded quotient (the reference relies on nvcc's default
+// -prec-div=true).  hipcc expands an IEEE divide into 11 VALU ops (v_div_scale x2, v_rcp, 5 fma,
+// v_mul, v_div_fmas, v_div_fixup): measured 46 cycles per wave-instruction group, 60 % of a sweep.
+// The divisor cnt is constant for a pixel, so its correctly rounded reciprocal y = RN(1/cnt) is
+// computed once per launch (one full divide) and each sweep does Markstein's correction step
+//      q0 = n*y;  r = fma(-d, q0, n);  q = fma(r, y, q0)
+// which IS RN(n/d): verified EXHAUSTIVELY on gfx950 against hipcc's divide for all 2^23 divisor x 2^24
+// numerator significands (scripts/ubench/div_exhaustive.hip, 1.4e14 pairs, 0 mismatches, 71 s; log in
+// profiles/).  Powers of two scale every intermediate exactly, so that covers all operands for which no
+// intermediate under/overflows: d normal (<= 4 here), n == 0 or |n| >= 2^-100 (then q0 is normal and the
+// remainder, a multiple of 2^(e_n - 47), is exactly representable), n/d bounded (a weighted mean).
+// Anything else takes the full divide under a wave-uniform branch.
+__device__ __forceinline__ float div_tail(float n, float d, float y) {
+    const float q0 = n * y;
+    const float r = __builtin_fmaf(-d, q0, n);
+    return __builtin_fmaf(r, y, q0);
+}
+
+// RN(1/d) for a normal d with a normal reciprocal: v_rcp_f32 (1 ulp) + one Newton step.  Equal to the IEEE quotient 1.0f/d for
+// EVERY such f32 (all 4 227 858 434 of them checked on the GPU, scripts/ubench/rcp_exhaustive.hip, profiles/r01_rcp_exhaustive.log):
+// 3 VALU ops instead of the 11 of the full divide, in the per-launch setup of every pixel.
+__device__ __forceinline__ float rcp_rn(float d) {
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
+}
+
+}  // namespace rtdd
