@@ -25,7 +25,7 @@ METHOD_RED_BLACK_GS = 1
 METHOD_MULTIGRID = 2
 METHOD_AUTO = 3
 RELAXATION_AUTO = -1.0                     # rtdd_solve_params.relaxation: SOR cycles (include/rtdd.h)
-OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, _OPT_RESERVED_3, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
+OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, OPT_DEFOCUS_PATH, OPT_ROWS_PER_WAVE, OPT_TILE, OPT_PERSISTENT = 0, 1, 2, 3, 4, 5, 6
 OPT_DEBUG_WITHHOLD_TILE, OPT_DEBUG_POLL_LIMIT_US = 7, 8
 OPT_AUTO_CYCLE_FIXED_NS, OPT_AUTO_CYCLE_FS_PER_PX, OPT_AUTO_SWEEP_FS_PER_PX, OPT_AUTO_SWEEP_FLOOR_NS = 9, 10, 11, 12
 OPT_DEBUG_FORCE_STATUS = 13

@@ -450,6 +450,196 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
     }
 }
 
+// ---- defocus without a global table: images up to ~1080p (kernelSize / 2 <= kDtHM) ------------------------------------------------
+// The four launches above are each a load -> compute -> store round on the whole image: 5.4 + 6.3 + 11.9 + 12.2 us at 1080p, mostly
+// kernel boundaries and memory round trips (the table is written and read back: 16.6 MB each way).  When the largest nominal window
+// is small -- half-width hm = kernelSize / 2 <= 28, i.e. images up to a 2280-pixel diagonal: 1080p, and every pair of the bundled
+// dataset -- ONE launch does it: a workgroup takes a 64 x 24 tile of output pixels, builds the summed-area table of the region its
+// windows can reach ((24 + 2 hm) rows x (64 + 2 hm) columns, <= 80 x 124 packed 64-bit entries = 78 KB) in LDS and reads its four
+// corners from there.  Packed fields of a LOCAL prefix overflow (the region holds more than 8224 pixels), but a window of
+// <= 56 x 56 pixels never does, and the four-corner combination is exact mod 2^64 (the carries of the prefixes cancel, as above).
+//   * build: the region is cut into 8 horizontal chunks, one per half-wave ("worker"): lane = four consecutive columns, the worker
+//     walks its <= 10 rows top to bottom with running column sums in registers and a 32-lane prefix scan per row (every load of the
+//     tile is issued before the first is used); the chunks' last rows go through LDS, each worker adds what lies above its chunk and
+//     writes its rows once.
+//   * lookup: as k_defocus, the corners from LDS.
+//   * a pixel whose window is larger than the region allows (depth > 255, or not a depth at all) is summed by its wave directly from
+//     the image, exactly and in bounded time (sums in u32: the whole image is < 2^32 / 255 pixels here); the results are what the
+//     table path gives (integer sums, then the same quotient code).
+// Tile height TH: 24 rows (region <= 80 rows = 78 KB: the most LDS lets two workgroups per CU have) or, for images whose 16-row tiles
+// all run at once (<= 512: up to ~700 x 700), 16 rows -- there a tile's latency is the launch's, and a shorter tile is done sooner.
+constexpr int kDtW = 64, kDtHM = 28, kDtRW = 124, kDtWorkers = 8;
+static_assert(kDtW + 2 * kDtHM + 3 <= kDtRW && kDtRW % 4 == 0 && kDtRW / 4 <= 32, "the region: tile + both margins + the alignment of its first column, one group of four per lane of a half-wave");
+
+// inclusive prefix sum over the 32 lanes of each half of a wave (the wave scan without its last step)
+__device__ __forceinline__ u64 half_incl_scan64(u64 v) {
+    u64 t = v + RTDD_DPP64(v, 0x111, 0xF, 0xF);
+    t += RTDD_DPP64(v, 0x112, 0xF, 0xF);
+    t += RTDD_DPP64(v, 0x113, 0xF, 0xF);
+    t += RTDD_DPP64(t, 0x114, 0xF, 0xE);
+    t += RTDD_DPP64(t, 0x118, 0xF, 0xC);
+    t += RTDD_DPP64(t, 0x142, 0xA, 0xF);                // row_bcast:15 into rows 1 and 3
+    return t;
+}
+
+template <bool VEC, int kDtH>
+__global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restrict__ orig, size_t op, const float *__restrict__ depth, size_t dp,
+                                                         uint8_t *__restrict__ art, size_t ap, int rows, int cols, int kernelSize, int hm,
+                                                         int gx, int ntiles, int xcd_tiles) {
+    constexpr int kDtRH = kDtH + 2 * kDtHM, kDtRowsPer = (kDtRH + kDtWorkers - 1) / kDtWorkers;
+    __shared__ u64 S[kDtRH][kDtRW];                                 // the region's summed-area table, S[r - R0][c - C0]: <= 79 360 B, two workgroups per CU
+    const int p = blockIdx.x;
+    const int tile = xcd_tiles > 0 ? (p & 7) * xcd_tiles + (p >> 3) : p;
+    if (tile >= ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx0 = (tile % gx) * kDtW, ty0 = (tile / gx) * kDtH;
+    const int R0 = ty0 - hm, C0 = (tx0 - hm) & ~3;                  // (a multiple of four, also when negative: groups of four never straddle column 0)
+    const int rh = kDtH + 2 * hm, rpw = (rh + kDtWorkers - 1) / kDtWorkers;      // region rows, rows per worker
+
+    // ---- every load of the tile first: the region's pixels (this thread: 4 columns x <= 9 rows) and the output pixels' depth / colour ----
+    const int worker = tid >> 5, wl = tid & 31, gcol = C0 + 4 * wl;
+    const bool group_ok = wl < kDtRW / 4 && gcol >= 0 && gcol < cols;
+    raw12 raw[kDtRowsPer];
+    if (VEC && C0 >= 0 && C0 + kDtRW <= cols) {
+        // the region lies between the image's left and right borders (workgroup-uniform; all but the outermost tile columns): three dword
+        // loads per row from a clamped, always valid address, rows outside the image or the chunk zeroed afterwards -- no branches
+        const int gc = wl < kDtRW / 4 ? gcol : C0;
+#pragma unroll
+        for (int i = 0; i < kDtRowsPer; i++) {
+            const int r = R0 + worker * rpw + i, rc = min(max(r, 0), rows - 1);
+            const uint32_t *q = (const uint32_t *)(orig + (size_t)rc * op + 3 * (size_t)gc);
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+            const bool ok = wl < kDtRW / 4 && i < rpw && r == rc;
+            raw[i] = raw12{ok ? w0 : 0u, ok ? w1 : 0u, ok ? w2 : 0u};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kDtRowsPer; i++) {
+            const int r = R0 + worker * rpw + i;
+            raw[i] = raw12{0, 0, 0};
+            if (group_ok && i < rpw && r >= 0 && r < rows) raw[i] = load_raw<VEC>(orig + (size_t)r * op, gcol, cols);
+        }
+    }
+    const int x = tx0 + lane, xc = min(x, cols - 1);
+    const bool whole = VEC && tx0 + kDtW <= cols;                   // wave-uniform: the dword path for orig / art
+    const int j = lane & 3;
+    constexpr int NR = kDtH / 4;                                    // output rows per wave
+    float d[NR];
+    uint32_t opx[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const int y = min(ty0 + wv * NR + i, rows - 1);
+        d[i] = ((const float *)((const char *)depth + (size_t)y * dp))[xc];
+        const uint8_t *orow = orig + (size_t)y * op;
+        if (whole) {
+            const uint32_t L = j < 3 ? ((const uint32_t *)(orow + 3 * (size_t)tx0))[3 * (lane >> 2) + j] : 0u;
+            const uint32_t prv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x90, 0xF, 0xF, true);   // quad_perm:[0,0,1,2]
+            opx[i] = __builtin_amdgcn_alignbit(L, prv, (32 - 8 * j) & 31) & 0xFFFFFFu;
+        } else {
+            const uint8_t *o = orow + 3 * (size_t)xc;
+            opx[i] = o[0] | (o[1] << 8) | (o[2] << 16);
+        }
+    }
+
+    // ---- the chunk's rows: running column sums, row prefix; kept in registers until the chunks above are known ----
+    u64 col[4] = {0, 0, 0, 0}, v[kDtRowsPer][4];
+#pragma unroll
+    for (int i = 0; i < kDtRowsPer; i++) {
+        u64 px[4];
+        unpack4(raw[i].w0, raw[i].w1, raw[i].w2, px);               // (zeros where nothing was loaded: outside the image or the region)
+#pragma unroll
+        for (int k = 0; k < 4; k++) col[k] += px[k];
+        const u64 s0 = col[0], s1 = s0 + col[1], s2 = s1 + col[2], s3 = s2 + col[3];
+        const u64 excl = half_incl_scan64(s3) - s3;
+        v[i][0] = s0 + excl; v[i][1] = s1 + excl; v[i][2] = s2 + excl; v[i][3] = s3 + excl;
+    }
+    // each chunk's last row (its column totals, row-prefixed) goes through the table's own row `worker` -- LDS has no room for a
+    // second array -- and is read back by the chunks below before any final row is written
+    if (wl < kDtRW / 4) {
+        u64x2 *q = (u64x2 *)&S[worker][4 * wl];
+        q[0] = u64x2{v[kDtRowsPer - 1][0], v[kDtRowsPer - 1][1]}; q[1] = u64x2{v[kDtRowsPer - 1][2], v[kDtRowsPer - 1][3]};
+    }
+    __syncthreads();
+    u64 base[4] = {0, 0, 0, 0};
+    if (wl < kDtRW / 4) {
+        for (int k = 0; k < worker; k++) {
+            const u64x2 *q = (const u64x2 *)&S[k][4 * wl];
+            const u64x2 a = q[0], b = q[1];
+            base[0] += a.a; base[1] += a.b; base[2] += b.a; base[3] += b.b;
+        }
+    }
+    __syncthreads();
+    if (wl < kDtRW / 4) {
+#pragma unroll
+        for (int i = 0; i < kDtRowsPer; i++) {
+            const int rr = worker * rpw + i;
+            if (i < rpw && rr < rh) {
+                u64x2 *q = (u64x2 *)&S[rr][4 * wl];
+                q[0] = u64x2{v[i][0] + base[0], v[i][1] + base[1]}; q[1] = u64x2{v[i][2] + base[2], v[i][3] + base[3]};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- lookups (k_defocus with the corners in LDS) ----
+    auto corner = [&](int r, int c) -> u64 {                        // T(r, c) of the region's table; rows / columns before the region sum to nothing
+        const u64 t = S[max(r - R0, 0)][max(c - C0, 0)];
+        return (r < R0 || c < C0) ? 0ull : t;
+    };
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const int y = ty0 + wv * NR + i, yc = min(y, rows - 1);
+        const int h = half_window(kernelSize, d[i]);
+        const int ya = max(yc - h, 0), yb = (int)min((long long)yc + h, (long long)rows);
+        const int xa = max(xc - h, 0), xb = (int)min((long long)xc + h, (long long)cols);
+        const int wd = xb - xa, ht = yb - ya;
+        uint32_t res = opx[i];                                      // count == 0 (:62-66): the pixel itself
+        uint32_t sb = 0, sg = 0, sr = 0;
+        const bool has = wd > 0 && ht > 0, local = h <= hm;
+        if (has && local) {
+            const u64 X = corner(yb - 1, xb - 1) - corner(yb - 1, xa - 1) - corner(ya - 1, xb - 1) + corner(ya - 1, xa - 1);
+            sb = (uint32_t)(X & kSatFieldMask); sg = (uint32_t)((X >> 21) & kSatFieldMask); sr = (uint32_t)(X >> 42);
+        }
+        // windows beyond the region: the wave sums them from the image, one pixel at a time (never taken for a depth map)
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(has && !local);
+        while (todo) {
+            const int L = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int wya = __builtin_amdgcn_readlane(ya, L), wyb = __builtin_amdgcn_readlane(yb, L);
+            const int wxa = __builtin_amdgcn_readlane(xa, L), wxb = __builtin_amdgcn_readlane(xb, L);
+            uint32_t tb = 0, tg = 0, tr = 0;
+            for (int r = wya; r < wyb; r++) {
+                const uint8_t *row = orig + (size_t)r * op;
+                for (int c = wxa + lane; c < wxb; c += 64) { tb += row[3 * (size_t)c]; tg += row[3 * (size_t)c + 1]; tr += row[3 * (size_t)c + 2]; }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { tb += __shfl_xor(tb, m); tg += __shfl_xor(tg, m); tr += __shfl_xor(tr, m); }
+            if (lane == L) { sb = tb; sg = tg; sr = tr; }
+        }
+        if (has) {
+            const uint32_t cnt = (uint32_t)ht * (uint32_t)wd;
+            if (cnt < 65536u && (sb | sg | sr) < (1u << 24)) {      // nominal: exact sums, exact integer quotients (quot_u8)
+                const float rc = __builtin_amdgcn_rcpf((float)cnt);
+                res = quot_u8(sb, cnt, rc) | (quot_u8(sg, cnt, rc) << 8) | (quot_u8(sr, cnt, rc) << 16);
+            } else {
+                const float count = (float)cnt;
+                res = store_u8((float)sb / count) | (store_u8((float)sg / count) << 8) | (store_u8((float)sr / count) << 16);
+            }
+        }
+        if (y < rows) {                                             // wave-uniform
+            uint8_t *arow = art + (size_t)y * ap;
+            if (whole) {
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)res, 0xF9, 0xF, 0xF, true);   // quad_perm:[1,2,3,3]
+                const uint32_t out = (res >> (8 * j)) | (nxt << ((24 - 8 * j) & 31));
+                if (j < 3) ((uint32_t *)(arow + 3 * (size_t)tx0))[3 * (lane >> 2) + j] = out;
+            } else if (x < cols) {
+                uint8_t *a = arow + 3 * (size_t)x;
+                a[0] = (uint8_t)res; a[1] = (uint8_t)(res >> 8); a[2] = (uint8_t)(res >> 16);
+            }
+        }
+    }
+}
+
 static inline dim3 grid64x4(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
 
 template <int MODE>
@@ -480,6 +670,23 @@ int launch_haze(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *dept
 }
 
 int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *depth, size_t dp, uint8_t *art, size_t ap, int rows, int cols) {
+    const int kernelSize = 0.025 * sqrtf(rows * rows + cols * cols);    // :42, evaluated once on the host (sqrtf is correctly rounded on both)
+    // small nominal windows (up to ~1080p): one launch, per-tile tables in LDS (k_defocus_tile).  RTDD_OPT_DEFOCUS_PATH: 0 automatic, 1 the
+    // global table always, 2 the tile kernel wherever its region fits.
+    if (ctx->opt.defocus_path != 1 && kernelSize / 2 <= kDtHM && (size_t)rows * cols < (1ull << 32) / 255) {
+        const bool vio = (uintptr_t)orig % 4 == 0 && op % 4 == 0 && (uintptr_t)art % 4 == 0 && ap % 4 == 0;
+        const int gx = (cols + kDtW - 1) / kDtW;
+        const bool low = gx * ((rows + 15) / 16) <= 2 * ctx->num_cus;    // every 16-row tile resident at once
+        const int th = low ? 16 : 24, gy = (rows + th - 1) / th, ntiles = gx * gy;
+        const int xcd_tiles = ntiles >= 64 ? (ntiles + 7) / 8 : 0;
+        const dim3 g(xcd_tiles > 0 ? 8 * xcd_tiles : ntiles);
+#define RTDD_DT_LAUNCH(V, H) hipLaunchKernelGGL((k_defocus_tile<V, H>), g, dim3(256), 0, ctx->stream, orig, op, depth, dp, art, ap, rows, cols, kernelSize, kernelSize / 2, gx, ntiles, xcd_tiles)
+        if (vio) { if (low) RTDD_DT_LAUNCH(true, 16); else RTDD_DT_LAUNCH(true, 24); }
+        else { if (low) RTDD_DT_LAUNCH(false, 16); else RTDD_DT_LAUNCH(false, 24); }
+#undef RTDD_DT_LAUNCH
+        RTDD_LAUNCH_CHECK(ctx, "k_defocus_tile");
+        return RTDD_OK;
+    }
     const int tp = (cols + 3) / 4 * 4;                                  // table row pitch in entries: 32-byte aligned groups of four
     // band height: one workgroup per band builds the table, so enough bands to occupy the chip (270 / 135 / 135 workgroups of 8 / 16 / 16
     // waves at 1080p / 4K / 8K); a band costs 8 B per column three times over (colsum, its scan, the build's read)
@@ -493,7 +700,6 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
         ctx->sat_elems = need;
     }
     u64 *T = (u64 *)ctx->sat, *base = T + (size_t)rows * tp;
-    const int kernelSize = 0.025 * sqrtf(rows * rows + cols * cols);    // :42, evaluated once on the host (sqrtf is correctly rounded on both)
     const bool vin = (uintptr_t)orig % 4 == 0 && op % 4 == 0, vout = vin && (uintptr_t)art % 4 == 0 && ap % 4 == 0;
     const dim3 g1((tp / 4 + 255) / 256, nbands);
     if (vin) hipLaunchKernelGGL(k_sat_colsum<true>, g1, dim3(256), 0, ctx->stream, orig, op, base, tp, rows, cols, RB);

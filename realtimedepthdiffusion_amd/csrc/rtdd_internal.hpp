@@ -48,6 +48,7 @@ struct Options {
     int rows_per_wave = 0;
     int tile = 0;
     int persistent = 1;
+    int defocus_path = 0;                // RTDD_OPT_DEFOCUS_PATH: 0 automatic, 1 global summed-area table, 2 per-tile tables in LDS where they fit
     // RTDD_METHOD_AUTO's cost model (constants, not clocks: a solve is reproducible).  Readable and settable as options so that
     // what decided a solve can be restated from outside (tests/test_gpu_multigrid.py).
     int auto_cycle_fixed_ns = 270000;    // a V-cycle with its residual check: launch-bound part ...

@@ -108,47 +108,91 @@ def test_haze_transmission_every_depth_pattern(ctx, oracle):
     assert np.array_equal(down(art), oracle.haze(orig, depth, 1))
 
 
+# RTDD_OPT_DEFOCUS_PATH: 1 = the global summed-area table (four launches), 2 = per-tile tables in LDS (one launch; what images up to
+# ~1080p take by default).  Every defocus test runs both.
+DEFOCUS_PATHS = [1, 2]
+
+
+def _defocus(ctx, path, orig_dev, depth_dev, art_dev, rows, cols):
+    ctx.set_option(rt.OPT_DEFOCUS_PATH, path)
+    try:
+        ctx.GPUSimulateDefocus(orig_dev, depth_dev, art_dev, rows, cols)
+        ctx.synchronize()
+    finally:
+        ctx.set_option(rt.OPT_DEFOCUS_PATH, 0)
+
+
+@pytest.mark.parametrize("path", DEFOCUS_PATHS)
 @pytest.mark.parametrize("shape", [(6, 8), (80, 80), (67, 120), (270, 480), (700, 560)])
-def test_defocus_bit_exact(ctx, oracle, shape):
+def test_defocus_bit_exact(ctx, oracle, shape, path):
     rows, cols = shape
     depth, _ = _depth(rows, cols, 41)
     orig = _rgb(rows, cols, 17)
     art = up(np.zeros_like(orig))
-    ctx.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+    _defocus(ctx, path, up(orig), up(depth), art, rows, cols)
     assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=min(8, oracle.max_threads())))
 
 
-@pytest.mark.parametrize("shape,align", [((67, 121), 1), ((131, 259), 1), ((40, 4099), 4), ((9, 70), 1), ((300, 66), 2)])
-def test_defocus_unaligned_rows_and_ragged_tiles(ctx, oracle, shape, align):
+@pytest.mark.parametrize("path", DEFOCUS_PATHS)
+@pytest.mark.parametrize("shape,align", [((67, 121), 1), ((131, 259), 1), ((40, 4099), 4), ((9, 70), 1), ((300, 66), 2), ((17, 64), 1), ((16, 128), 4), ((33, 63), 4)])
+def test_defocus_unaligned_rows_and_ragged_tiles(ctx, oracle, shape, align, path):
     """Caller pitches that are no multiple of 4 bytes (the byte paths of the table build and of the lookup), widths that leave a
     ragged last 64-pixel tile and a ragged last group of four, and a row wider than one sweep of the build's workgroup (4096 px:
-    the per-row carry between column ranges)."""
+    the per-row carry between column ranges; too large a window for the tile kernel, which hands that one to the table)."""
     rows, cols = shape
     depth, _ = _depth(rows, cols, 43)
     orig = _rgb(rows, cols, 18)
     art = up(np.zeros_like(orig), align)
-    ctx.GPUSimulateDefocus(up(orig, align), up(depth), art, rows, cols)
+    _defocus(ctx, path, up(orig, align), up(depth), art, rows, cols)
     assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=min(8, oracle.max_threads())))
 
 
-def test_defocus_windows_beyond_one_lookup(ctx, oracle):
+@pytest.mark.parametrize("path", DEFOCUS_PATHS)
+def test_defocus_windows_beyond_one_lookup(ctx, oracle, path):
     """Windows of more than 8224 pixels (the packed table's 21-bit fields) are summed in strips: a small image with a depth far
-    above 255 makes every window the whole (clipped) image -- 160 x 120 = 19 200 pixels, three strips."""
+    above 255 makes every window the whole (clipped) image -- 160 x 120 = 19 200 pixels, three strips.  In the tile kernel every one
+    of these pixels is beyond its region: the wave sums the window from the image."""
     rows, cols = 120, 160
     orig = _rgb(rows, cols, 20)
     depth = np.full((rows, cols), 4000.0, np.float32); depth[::7, ::5] = 900.0; depth[3::11, 1::3] = 255.0
     art = up(np.zeros_like(orig))
-    ctx.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+    _defocus(ctx, path, up(orig), up(depth), art, rows, cols)
     assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=min(8, oracle.max_threads())))
 
 
-def test_defocus_out_of_range_depth_is_defined(ctx, oracle):
+@pytest.mark.parametrize("path", DEFOCUS_PATHS)
+def test_defocus_out_of_range_depth_is_defined(ctx, oracle, path):
     rows, cols = 120, 160
     orig = _rgb(rows, cols, 19)
     depth = np.random.default_rng(5).uniform(-300, 600, (rows, cols)).astype(np.float32)
     art = up(np.zeros_like(orig))
-    ctx.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+    _defocus(ctx, path, up(orig), up(depth), art, rows, cols)
     assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=min(8, oracle.max_threads())))
+
+
+@pytest.mark.parametrize("shape", [(1080, 1920), (853, 1280), (1440, 1754)])
+def test_defocus_tile_kernel_equals_table_at_size(ctx, oracle, shape):
+    """The largest sizes the tile kernel takes (1440 x 1754: kernelSize 56, half-width 28 = its limit): every pixel equal to the table
+    path's, a depth map with a patch of out-of-range values (windows beyond the region) and special values, and 400 sampled pixels
+    against the oracle's literal gather."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows)
+    depth, _ = _depth(rows, cols, 47)
+    depth[100:140, 200:260] = rng.uniform(255, 700, (40, 60)).astype(np.float32)
+    depth[0, :8] = [0.0, -0.0, 255.0, 1e-30, np.float32(np.inf), np.float32(-np.inf), np.float32(np.nan), 3e38]
+    orig = _rgb(rows, cols, 21)
+    o, dd = up(orig), up(depth)
+    a1, a2 = up(np.zeros_like(orig)), up(np.zeros_like(orig))
+    _defocus(ctx, 1, o, dd, a1, rows, cols)
+    _defocus(ctx, 2, o, dd, a2, rows, cols)
+    got = down(a2)
+    assert np.array_equal(got, down(a1))
+    ys = rng.integers(0, rows, 400); xs = rng.integers(0, cols, 400)
+    ys[:60] = rng.integers(95, 145, 60); xs[:60] = rng.integers(195, 265, 60)
+    keep = ~((ys == 0) & (xs < 8))       # (the infinite depths' windows are the whole image: sums beyond 2^24, where the reference's own f32 accumulation rounds)
+    ys, xs = ys[keep], xs[keep]
+    want = oracle.defocus_at(orig, depth, ys, xs)
+    assert np.array_equal(got[ys, xs], want)
 
 
 def test_effects_1080p_properties(ctx):
