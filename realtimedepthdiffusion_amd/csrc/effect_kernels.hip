@@ -471,6 +471,9 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
 constexpr int kDtW = 64, kDtHM = 28, kDtRW = 124, kDtWorkers = 8;
 static_assert(kDtW + 2 * kDtHM + 3 <= kDtRW && kDtRW % 4 == 0 && kDtRW / 4 <= 32, "the region: tile + both margins + the alignment of its first column, one group of four per lane of a half-wave");
 
+#ifndef RTDD_DT_DIAG
+#define RTDD_DT_DIAG 0       // timing-only ablations of k_defocus_tile (results wrong): 1 no row scan, 2 no lookups, 4 no unpack
+#endif
 // inclusive prefix sum over the 32 lanes of each half of a wave (the wave scan without its last step)
 __device__ __forceinline__ u64 half_incl_scan64(u64 v) {
     u64 t = v + RTDD_DPP64(v, 0x111, 0xF, 0xF);
@@ -546,11 +549,12 @@ __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restri
 #pragma unroll
     for (int i = 0; i < kDtRowsPer; i++) {
         u64 px[4];
-        unpack4(raw[i].w0, raw[i].w1, raw[i].w2, px);               // (zeros where nothing was loaded: outside the image or the region)
+        if (RTDD_DT_DIAG & 4) { px[0] = raw[i].w0; px[1] = raw[i].w1; px[2] = raw[i].w2; px[3] = raw[i].w0 ^ raw[i].w1; }
+        else unpack4(raw[i].w0, raw[i].w1, raw[i].w2, px);          // (zeros where nothing was loaded: outside the image or the region)
 #pragma unroll
         for (int k = 0; k < 4; k++) col[k] += px[k];
         const u64 s0 = col[0], s1 = s0 + col[1], s2 = s1 + col[2], s3 = s2 + col[3];
-        const u64 excl = half_incl_scan64(s3) - s3;
+        const u64 excl = (RTDD_DT_DIAG & 1) ? s3 : half_incl_scan64(s3) - s3;
         v[i][0] = s0 + excl; v[i][1] = s1 + excl; v[i][2] = s2 + excl; v[i][3] = s3 + excl;
     }
     // each chunk's last row (its column totals, row-prefixed) goes through the table's own row `worker` -- LDS has no room for a
@@ -582,48 +586,61 @@ __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restri
     __syncthreads();
 
     // ---- lookups (k_defocus with the corners in LDS) ----
-    auto corner = [&](int r, int c) -> u64 {                        // T(r, c) of the region's table; rows / columns before the region sum to nothing
-        const u64 t = S[max(r - R0, 0)][max(c - C0, 0)];
-        return (r < R0 || c < C0) ? 0ull : t;
-    };
+    // The common case -- the window lies inside the region -- is straight-line code for the whole wave: clamped LDS addresses, selects
+    // instead of branches, 24-bit multiplies (quotient <= 256, count <= 56 x 56); what it computes for a lane whose window does not
+    // fit is discarded.  Such lanes (a depth above 255 * (2 hm + 1) / kernelSize, never a depth map's) are summed from the image by
+    // their wave under ONE wave-uniform branch per row of output.
+    const int rh1 = rh - 1;
 #pragma unroll
     for (int i = 0; i < NR; i++) {
         const int y = ty0 + wv * NR + i, yc = min(y, rows - 1);
-        const int h = half_window(kernelSize, d[i]);
-        const int ya = max(yc - h, 0), yb = (int)min((long long)yc + h, (long long)rows);
-        const int xa = max(xc - h, 0), xb = (int)min((long long)xc + h, (long long)cols);
+        const int h = half_window(kernelSize, d[i]);                // <= 2^21: the sums below stay in int
+        const int ya = max(yc - h, 0), yb = min(yc + h, rows);
+        const int xa = max(xc - h, 0), xb = min(xc + h, cols);
         const int wd = xb - xa, ht = yb - ya;
-        uint32_t res = opx[i];                                      // count == 0 (:62-66): the pixel itself
-        uint32_t sb = 0, sg = 0, sr = 0;
-        const bool has = wd > 0 && ht > 0, local = h <= hm;
-        if (has && local) {
-            const u64 X = corner(yb - 1, xb - 1) - corner(yb - 1, xa - 1) - corner(ya - 1, xb - 1) + corner(ya - 1, xa - 1);
-            sb = (uint32_t)(X & kSatFieldMask); sg = (uint32_t)((X >> 21) & kSatFieldMask); sr = (uint32_t)(X >> 42);
-        }
-        // windows beyond the region: the wave sums them from the image, one pixel at a time (never taken for a depth map)
+        const bool has = !(RTDD_DT_DIAG & 2) && wd > 0 && ht > 0, local = h <= hm;
+        // T(r, c) of the region's table at the four corners; a row / column before the region sums to nothing
+        const int r1 = min(max(yb - 1 - R0, 0), rh1), r0 = min(ya - 1 - R0, rh1), c1 = min(max(xb - 1 - C0, 0), kDtRW - 1), c0 = min(xa - 1 - C0, kDtRW - 1);
+        const int r0c = max(r0, 0), c0c = max(c0, 0);
+        const u64 t11 = S[r1][c1], t10 = S[r1][c0c], t01 = S[r0c][c1], t00 = S[r0c][c0c];
+        const u64 X = t11 - (c0 < 0 ? 0ull : t10) - (r0 < 0 ? 0ull : t01) + ((r0 < 0 || c0 < 0) ? 0ull : t00);
+        const uint32_t fb = (uint32_t)(X & kSatFieldMask), fg = (uint32_t)((X >> 21) & kSatFieldMask), fr = (uint32_t)(X >> 42);
+        const uint32_t cnt = (uint32_t)__mul24(ht, wd);             // (exact for a window inside the region; recomputed below otherwise)
+        const float rc = __builtin_amdgcn_rcpf((float)cnt);
+        auto quot_small = [&](uint32_t s) {                         // quot_u8 with 24-bit multiplies: s < 2^24, quotient <= 256, count < 2^12
+            int n = (int)((float)s * rc);
+            const int rem = (int)s - __mul24(n, (int)cnt);
+            n += rem < 0 ? -1 : (rem >= (int)cnt ? 1 : 0);
+            return (uint32_t)min(n, 255);
+        };
+        const uint32_t fast = quot_small(fb) | (quot_small(fg) << 8) | (quot_small(fr) << 16);
+        uint32_t res = (has && local) ? fast : opx[i];              // count == 0 (:62-66): the pixel itself
         unsigned long long todo = __builtin_amdgcn_ballot_w64(has && !local);
-        while (todo) {
-            const int L = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int wya = __builtin_amdgcn_readlane(ya, L), wyb = __builtin_amdgcn_readlane(yb, L);
-            const int wxa = __builtin_amdgcn_readlane(xa, L), wxb = __builtin_amdgcn_readlane(xb, L);
-            uint32_t tb = 0, tg = 0, tr = 0;
-            for (int r = wya; r < wyb; r++) {
-                const uint8_t *row = orig + (size_t)r * op;
-                for (int c = wxa + lane; c < wxb; c += 64) { tb += row[3 * (size_t)c]; tg += row[3 * (size_t)c + 1]; tr += row[3 * (size_t)c + 2]; }
-            }
+        if (__builtin_expect(todo != 0, 0)) {                       // windows beyond the region: the wave sums them from the image, one pixel at a time
+            uint32_t sb = 0, sg = 0, sr = 0;
+            while (todo) {
+                const int L = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int wya = __builtin_amdgcn_readlane(ya, L), wyb = __builtin_amdgcn_readlane(yb, L);
+                const int wxa = __builtin_amdgcn_readlane(xa, L), wxb = __builtin_amdgcn_readlane(xb, L);
+                uint32_t tb = 0, tg = 0, tr = 0;
+                for (int r = wya; r < wyb; r++) {
+                    const uint8_t *row = orig + (size_t)r * op;
+                    for (int c = wxa + lane; c < wxb; c += 64) { tb += row[3 * (size_t)c]; tg += row[3 * (size_t)c + 1]; tr += row[3 * (size_t)c + 2]; }
+                }
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) { tb += __shfl_xor(tb, m); tg += __shfl_xor(tg, m); tr += __shfl_xor(tr, m); }
-            if (lane == L) { sb = tb; sg = tg; sr = tr; }
-        }
-        if (has) {
-            const uint32_t cnt = (uint32_t)ht * (uint32_t)wd;
-            if (cnt < 65536u && (sb | sg | sr) < (1u << 24)) {      // nominal: exact sums, exact integer quotients (quot_u8)
-                const float rc = __builtin_amdgcn_rcpf((float)cnt);
-                res = quot_u8(sb, cnt, rc) | (quot_u8(sg, cnt, rc) << 8) | (quot_u8(sr, cnt, rc) << 16);
-            } else {
-                const float count = (float)cnt;
-                res = store_u8((float)sb / count) | (store_u8((float)sg / count) << 8) | (store_u8((float)sr / count) << 16);
+                for (int m = 32; m >= 1; m >>= 1) { tb += __shfl_xor(tb, m); tg += __shfl_xor(tg, m); tr += __shfl_xor(tr, m); }
+                if (lane == L) { sb = tb; sg = tg; sr = tr; }
+            }
+            if (has && !local) {
+                const uint32_t n = (uint32_t)ht * (uint32_t)wd;
+                if (n < 65536u && (sb | sg | sr) < (1u << 24)) {    // exact sums, exact integer quotients (quot_u8)
+                    const float rn = __builtin_amdgcn_rcpf((float)n);
+                    res = quot_u8(sb, n, rn) | (quot_u8(sg, n, rn) << 8) | (quot_u8(sr, n, rn) << 16);
+                } else {                                            // (as the table path: the reference's own f32 sums round here)
+                    const float count = (float)n;
+                    res = store_u8((float)sb / count) | (store_u8((float)sg / count) << 8) | (store_u8((float)sr / count) << 16);
+                }
             }
         }
         if (y < rows) {                                             // wave-uniform
