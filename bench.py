@@ -56,13 +56,15 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # VALU roof: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md chip table) = 78.6 T lane-operations/s (= 157.3 TFLOP/s / 2).
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 # Algorithmic VALU operations per pixel-sweep, counted in the ISA of the sweep body (k_sweep_blocked<32,1024,3,true,true>, fast
-# path: 392 VALU instructions per 2 sweeps x 12 pixels; 4 fma for the sum, 3 for the divide, 1.5 for the tiny-numerator test, 6
-# for clamp + update + Dirichlet select, 0.5 DPP, ~1.3 bookkeeping).  Halo redundancy is NOT counted: `achieved` is useful work.
-VALU_OPS = {"jacobi": 16.3, "rbgs": 15.0, "sor_cycles": 15.0}
-# What the sweep's instruction MIX can issue at: scripts/ubench/valu_mix.hip (profiles/r03_valu_mix.txt) measures 3.77 cycles per
-# wave-instruction and SIMD for one pixel's forms in their proportions at 4 waves per SIMD -- clamp, compare, DPP and select forms run at
-# the SIMD-16 rate, plain fma at 3.2 -- against the 2 cycles `peak` assumes.  Reported beside `frac`, never instead of it.
-VALU_MIX_CYCLES = 3.77
+# path: 362 VALU instructions per 2 sweeps x 12 pixels = 15.1; 4 fma for the sum, 3 for the divide, 1.5 for the tiny-numerator test, 6
+# for clamp + update + Dirichlet select, ~0.6 bookkeeping; the lane shifts are LDS-crossbar permutes since round 3 and no longer VALU
+# work: 16.3 before).  Halo redundancy is NOT counted: `achieved` is useful work.
+VALU_OPS = {"jacobi": 15.1, "rbgs": 15.0, "sor_cycles": 15.0}
+# What the sweep's instruction MIX can issue at: the kernel's own hot block replayed as a micro-benchmark (scripts/ubench/gen_block_bench.py,
+# profiles/r03_block_replay.txt) issues at 2.66 cycles per wave-instruction and SIMD with every CU busy at 4 waves per SIMD (2.27 with one
+# CU busy: the chip clocks down under load) -- clamp, compare and select forms run at half rate -- against the 2 cycles `peak` assumes.
+# Reported beside `frac`, never instead of it.
+VALU_MIX_CYCLES = 2.66
 
 
 def free_port():

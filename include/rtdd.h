@@ -74,9 +74,7 @@ enum rtdd_option {
     RTDD_OPT_ROWS_PER_WAVE = 4,     /* one-sweep kernel: rows each wave walks (0 = auto) */
     RTDD_OPT_PERSISTENT = 6,        /* 1 (default): levels whose tiles all fit on the chip at once run ALL sweeps in one launch,
                                        neighbouring workgroups trading halo strips in memory (no kernel boundaries); larger levels (4K, 8K) run
-                                       one launch per block of sweeps.  0: one launch per block of sweeps everywhere.  2 (experimental, slower):
-                                       every multi-tile level runs all its blocks in one DATAFLOW launch (workgroups claim (block, tile) items
-                                       and wait only for the tiles around theirs) */
+                                       one launch per block of sweeps.  0: one launch per block of sweeps everywhere */
     /* RTDD_METHOD_AUTO prices the V-cycles still needed against finishing with SOR cycles.  The prices are these four CONSTANTS
      * (never a clock: a solve is reproducible); they are options so that the decision can be restated from outside and re-tuned
      * without touching bits by accident.  cycle = FIXED_NS + pixels * CYCLE_FS_PER_PX; sweep = max(FLOOR_NS, pixels * SWEEP_FS_PER_PX). */
@@ -160,7 +158,7 @@ typedef struct rtdd_solve_info {
                                      * 3 one red-black colour per launch, 4 register-blocked red-black; 0 = no sweep launch */
     int tile;                       /* blocked kernels: tile id (RTDD_OPT_TILE numbering; red-black: 1 = 128x64, 2 = 128x128) */
     int temporal_depth;             /* blocked kernels: sweeps per launch (persistent: per exchange) */
-    int persistent;                 /* 1: that launch was persistent (all its sweeps in one launch, tiles resident); 2: one dataflow launch */
+    int persistent;                 /* 1: that launch was persistent (all its sweeps in one launch) */
     int fp_contract;                /* RTDD_OPT_FP_CONTRACT in force */
     int launches;                   /* kernel launches of the solve, k_prepare / k_finish excluded */
 } rtdd_solve_info;

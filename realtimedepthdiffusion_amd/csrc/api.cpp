@@ -57,36 +57,6 @@ int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
     return RTDD_OK;
 }
 
-// k_sweep_flow (sweep_blocked.hip): `ntiles` flags (monotonic over the life of the context: launch values flag_base + 1 .. + nblocks) behind
-// the eight queue counters, which are zeroed for every launch (one 512-byte fill per solve of a 4K / 8K image).
-int prepare_flow_launch(rtdd_ctx *ctx, size_t ntiles, int nblocks, int grid, int *flag_base, int *item_base) {
-    (void)grid;
-    const size_t slots = ntiles + 8;                                  // 8 counters + one flag per tile, kFlowFlagStride = 16 ints each
-    if (ctx->flow_flags_cap < slots) {
-        RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->flow_flags) { RTDD_HIP(ctx, hipFree(ctx->flow_flags)); ctx->flow_flags = nullptr; ctx->flow_flags_cap = 0; }
-        const size_t cap = slots < 4096 ? 4096 : slots;
-        RTDD_HIP(ctx, hipMalloc((void **)&ctx->flow_flags, cap * 16 * sizeof(int)));
-        RTDD_HIP(ctx, hipMemset(ctx->flow_flags, 0, cap * 16 * sizeof(int)));
-        ctx->flow_flags_cap = cap; ctx->flow_epoch = 0;
-    }
-    if (ctx->flow_epoch > (1 << 30) - nblocks - 2) {                  // start over (rare)
-        RTDD_HIP(ctx, hipMemsetAsync(ctx->flow_flags, 0, ctx->flow_flags_cap * 16 * sizeof(int), ctx->stream));
-        ctx->flow_epoch = 0;
-    }
-    RTDD_HIP(ctx, hipMemsetAsync(ctx->flow_flags, 0, 8 * 16 * sizeof(int), ctx->stream));      // the queues' counters
-    *flag_base = ctx->flow_epoch; ctx->flow_epoch += nblocks + 1;
-    *item_base = 0;
-    const int limit = ctx->opt.debug_poll_limit_us > 0 ? ctx->opt.debug_poll_limit_us * 100 : 0;        // 10 ns ticks
-    if (ctx->sync_header[0] != ctx->opt.debug_withhold_tile || ctx->sync_header[1] != limit) {
-        RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncWithhold), ctx->opt.debug_withhold_tile, 1, ctx->stream));
-        RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncLimit), limit, 1, ctx->stream));
-        ctx->sync_header[0] = ctx->opt.debug_withhold_tile; ctx->sync_header[1] = limit;
-    }
-    ctx->persistent_used = true;
-    return RTDD_OK;
-}
-
 // The stream has just been synchronised by the caller.  A blocked-sweep launch since the last check may have given up (persist_sync.hpp).
 int check_persistent_status(rtdd_ctx *ctx) {
     if (!ctx->persistent_used || !ctx->sync_words) return RTDD_OK;
@@ -95,9 +65,6 @@ int check_persistent_status(rtdd_ctx *ctx) {
     ctx->persistent_used = false;
     if (status == 0) return RTDD_OK;
     RTDD_HIP(ctx, hipMemset(ctx->sync_words + kSyncStatus, 0, sizeof(int)));
-    // a dataflow launch that gave up leaves its flags anywhere: they start over
-    if (ctx->flow_flags) RTDD_HIP(ctx, hipMemset(ctx->flow_flags, 0, ctx->flow_flags_cap * 16 * sizeof(int)));
-    ctx->flow_epoch = 0; ctx->work_epoch = 0;
     return fail(ctx, RTDD_ERR_TIMEOUT, status == 1 ? "persistent sweep kernel: a workgroup timed out waiting for a neighbouring tile (its workgroups were not all "
                                                      "co-resident: is the GPU shared?); the results since the last synchronisation are invalid; "
                                                      "set RTDD_OPT_PERSISTENT to 0 when the GPU is shared"
@@ -152,7 +119,6 @@ int rtdd_ctx_create(int device, rtdd_ctx **out) {
     if (!ctx) return RTDD_ERR_NOMEM;
     ctx->device = device;
     for (auto &t : ctx->persist_fit) t[0] = t[1] = -1;
-    for (auto &t : ctx->flow_occ) t[0] = t[1] = -1;
     DeviceGuard g(device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -177,7 +143,6 @@ int rtdd_ctx_destroy(rtdd_ctx *ctx) {
     if (ctx->omega_dev) (void)hipFree(ctx->omega_dev);
     if (ctx->residual_dev) (void)hipFree(ctx->residual_dev);
     if (ctx->sync_words) (void)hipFree(ctx->sync_words);
-    if (ctx->flow_flags) (void)hipFree(ctx->flow_flags);
     if (ctx->sat) (void)hipFree(ctx->sat);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -206,8 +171,8 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 28, "temporal depth must be 0..28"); ctx->opt.temporal_depth = value; break;
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
         case RTDD_OPT_DEFOCUS_PATH: REQUIRE(ctx, value >= 0 && value <= 2, "defocus path must be 0..2"); ctx->opt.defocus_path = value; break;
-        case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 19, "tile must be 0..19"); ctx->opt.tile = value; break;
-        case RTDD_OPT_PERSISTENT: REQUIRE(ctx, value >= 0 && value <= 2, "persistent must be 0..2"); ctx->opt.persistent = value; break;
+        case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 16, "tile must be 0..16"); ctx->opt.tile = value; break;
+        case RTDD_OPT_PERSISTENT: ctx->opt.persistent = value ? 1 : 0; break;
         case RTDD_OPT_AUTO_CYCLE_FIXED_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fixed_ns = value; break;
         case RTDD_OPT_AUTO_CYCLE_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fs_per_px = value; break;
         case RTDD_OPT_AUTO_SWEEP_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_sweep_fs_per_px = value; break;

@@ -85,17 +85,11 @@ struct rtdd_ctx {
     int deferred_plane = -1;
     uint8_t *finish_u8 = nullptr;
     size_t finish_u8_pitch = 0;
-    // dataflow mode of the blocked kernel (k_sweep_flow): one flag per tile (as many as the largest image so far needs), both the flags and
-    // the item counter (sync_words[kSyncWork]) monotonic over the life of the context like flag_epoch below; reset together after a failed launch
-    int *flow_flags = nullptr;
-    size_t flow_flags_cap = 0;      // tiles
-    int flow_epoch = 0, work_epoch = 0;
-    signed char flow_occ[20][2];    // per (tile id, contraction): workgroups of k_sweep_flow per CU on THIS device (-1 = not asked yet, 0 = no)
     int flag_epoch = 0;             // the per-tile flags of the persistent kernels only ever grow: base value of the next persistent launch (api.cpp)
     int sync_header[2] = {0, 0};    // what sync_words[kSyncWithhold], [kSyncLimit] currently hold on the device
     rtdd_solve_info last_info{};    // of the most recent solve; kernel/tile/temporal_depth/persistent are filled in by the sweep launchers
     bool persistent_used = false;   // a launch that can set the status word (sync_words[kSyncStatus]) happened since the last status check
-    signed char persist_fit[20][2];  // per (tile id, contraction): does one workgroup of the persistent kernel fit a CU of THIS device (-1 = not asked yet)
+    signed char persist_fit[17][2];  // per (tile id, contraction): does one workgroup of the persistent kernel fit a CU of THIS device (-1 = not asked yet)
     uint32_t *sat = nullptr;        // defocus summed-area table scratch
     size_t sat_elems = 0;
     int num_cus = 256;
@@ -190,13 +184,7 @@ void pyramid_free(rtdd_ctx *ctx);
 // persistent kernels (persist_sync.hpp): reserve the launch's flag values and refresh the debug words before a persistent launch;
 // read the status word where the stream has just been synchronised (-> RTDD_ERR_TIMEOUT, status cleared)
 int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base);
-int prepare_flow_launch(rtdd_ctx *ctx, size_t ntiles, int nblocks, int grid, int *flag_base, int *item_base);
 int check_persistent_status(rtdd_ctx *ctx);
-
-// sweep_pk.hip: the packed tiles (ids 17..19) of sweep_blocked.hip's table
-bool pk_persistent_possible(rtdd_ctx *ctx, int tile, int nthreads);
-void launch_sweep_pk(rtdd_ctx *ctx, int tile, dim3 grid, int xcd_tiles, int nthreads, float *Xk, float *Xm, float *Yk, float *Ym, const uint32_t *M,
-                     const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma, int block_sweeps, int flag_base);
 
 // the reference's host-side omega recurrence (src/GPUSolver.cu:282-299)
 void omega_schedule(int n, std::vector<float> &out);

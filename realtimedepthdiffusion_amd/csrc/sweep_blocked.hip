@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     __syncthreads();
     if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
 
-#include "sweep_tile_setup.inc"       // vxr / vpr / mr / mup -> a, b, weights, divisors, reciprocals (shared with k_sweep_flow)
+#include "sweep_tile_setup.inc"       // vxr / vpr / mr / mup -> a, b, weights, divisors, reciprocals
 
     RTDD_STAMP(1);
     // ---- n sweeps in registers -------------------------------------------------------------------
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     // before their counter is known, fetching counter and rows in one go, s_setprio feedback for lagging waves, a half-sweep
     // stagger between groups of four waves, a wave-level (barrier-free) hand-off between workgroups, and a "zebra" row order (even
     // waves top-down, odd waves bottom-up, every edge row published as soon as it is computed and fetched a step ahead).
-#include "sweep_tile_sweeps.inc"      // publish / await / sweep lambdas (shared with k_sweep_flow)
+#include "sweep_tile_sweeps.inc"      // publish / await / sweep lambdas
     // (the divide variant is chosen per wave; the neighbour handshake above does not care which one a wave runs)
     const int tile_id = by * gx + bx, ntiles = gx * gy;
     int s = 0, blk = 0;
@@ -324,179 +324,6 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 #endif
 }
 
-// ---- DATAFLOW mode (images whose tiles do not all fit the chip at once: 4K, 8K) --------------------------------------------------
-// One launch per block of T sweeps ends in a kernel boundary (~3 us) and in a tail -- the last workgroups of a launch run on a
-// half-empty chip (2160 tiles on 512 slots at 4K: 4.2 rounds) -- together ~12 % of a 4K block.  Here ONE launch runs every block:
-// workgroups claim (block, tile) items in order from a global counter; item (b, t) waits until the nine tiles around t have finished
-// block b - 1 (one monotonic flag per tile, as in persistent mode), loads its extended tile with sc1 loads (the neighbours stored it
-// write-through), sweeps it T times with the same code as k_sweep_blocked (sweep_tile_*.inc), stores its centre sc1, drains, and
-// raises its flag.  The tail of block b overlaps the head of block b + 1; there is no grid-wide barrier anywhere.
-//   * Progress: ids are claimed in increasing order and an item waits only for items with smaller ids (block b - 1), each of which
-//     has been claimed by a workgroup that is running: the smallest unfinished item never waits -- no co-residency assumption.
-//   * Write-after-read: block b writes the plane pair block b - 1 read.  Item (b, t) overwrites the centre of t there only after
-//     (b - 1, t') has finished for every neighbour t' -- the only items that read it.  And (b + 1, t') overwrites what (b, t) reads as
-//     halo only after (b, t) has finished, t being a neighbour of t'.
-//   * Every wait is bounded (persist_sync.hpp): a workgroup that gives up sets the status word, everyone who sees it leaves, the host
-//     reports RTDD_ERR_TIMEOUT at the next synchronisation and resets the counter and the flags.
-// Bit-identical to the other schedules: the arithmetic is the shared include, only the order of tiles in time differs.
-constexpr int kFlowFlagStride = 16;                                 // ints between two tiles' flags (64 bytes)
-#ifndef RTDD_FLOW_DIAG
-#define RTDD_FLOW_DIAG 0      // timing-only ablations (results wrong): 1 no drain before the flag, 2 plain tile loads, 4 no poll, 8 plain stores, 16 claim at the end, 32 no sweeps, 64 no tile loads / stores
-#endif
-template <int LX, int NT, int G, bool CONTRACT>
-__global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) void k_sweep_flow(float *P0k, float *P0m, float *P1k, float *P1m,
-                                                      const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
-                                                      const float *__restrict__ omegas, int ip, int rows, int cols,
-                                                      int hx, int hy, int nsweeps, float gamma, int T, int *sync_words, int *flags,
-                                                      int gx, int gy, int flag_base, int item_base) {
-    constexpr bool PERSIST = false;
-    constexpr int EW = 4 * LX, NTR = NT / LX;
-    __shared__ float lut[257];
-    __shared__ float4 edge[2][NTR][2][LX];
-    __shared__ int published[NT / 64 + 1];
-    __shared__ int dead_s, item_s;
-    // EIGHT queues, one per band of tiles (queue q owns tiles [q * per, (q + 1) * per) of EVERY block, in block-major order), workgroup w
-    // claims from queue w % 8 -- where the dispatcher usually puts it on XCD w % 8, so a band's tiles tend to stay in one L2 (speed only)
-    // -- and kFlowChunk items per claim: ONE counter for all workgroups cost ~55 ns per item, serialised at the memory side (270 K items
-    // per 1000 sweeps at 4K: the whole solve), measured.  Progress as before: a queue hands out its block-b items only after all its
-    // block-(b-1) items, a claimed item of block 0 needs nothing, and every queue has workgroups by construction (w % 8, not the hardware id).
-    constexpr int kFlowChunk = 4;
-    const int queue = (int)blockIdx.x & 7;
-    const int tid = threadIdx.x;
-    const int lx = tid % LX, tr = tid / LX;
-    const int ntr = (int)blockDim.x / LX;
-    const int eh = ntr * G;
-    const int TW = EW - 2 * hx, TH = eh - 2 * hy;
-    const int ntiles = gx * gy, nblocks = (nsweeps + T - 1) / T;
-    const int per = (ntiles + 7) / 8, t_lo = ((int)blockIdx.x & 7) * per;
-    const int nt_q = max(0, min(per, ntiles - t_lo)), total = nt_q * nblocks;         // this queue's tiles and items
-    int *counter = flags + (size_t)((int)blockIdx.x & 7) * kFlowFlagStride;             // (the first 8 flag slots are the queues' counters)
-    flags += 8 * kFlowFlagStride;
-    for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
-    if (tid == 0) {
-        dead_s = __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        item_s = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * kFlowChunk;
-    }
-    __syncthreads();
-    if (dead_s) return;                          // an earlier launch of this context gave up: drain at once
-    int item = item_s, next_chunk = 0;
-    (void)queue; (void)item_base;
-    typedef float f4r __attribute__((ext_vector_type(4)));
-    while (item < total) {
-        const int blk = item / nt_q, t = t_lo + (item - blk * nt_q);
-        const int bx = t % gx, by = t / gx;
-        // the NEXT chunk is claimed at the first item of this one, its number is needed only after the chunk: the atomic's round trip
-        // hides behind the sweeps
-        int next_item = item + 1;
-        const bool last_of_chunk = (item + 1) % kFlowChunk == 0;
-        if (item % kFlowChunk == 0 && tid == 0) next_chunk = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * kFlowChunk;
-        if (last_of_chunk) next_item = next_chunk;
-        if (!(RTDD_FLOW_DIAG & 4) && blk > 0 && tid < 9) {                // lane i waits for tile (bx + i%3 - 1, by + i/3 - 1) of block blk - 1 (the tile itself included)
-            const int nx = bx + tid % 3 - 1, ny = by + tid / 3 - 1;
-            if (nx >= 0 && ny >= 0 && nx < gx && ny < gy) {
-                const int *f = flags + (size_t)(ny * gx + nx) * kFlowFlagStride;
-                const int want = flag_base + blk;
-                unsigned long long t0 = 0, limit = 0;
-                unsigned spins = 0;
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if ((++spins & 63u) == 0) {
-                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                        if (t0 == 0) {
-                            t0 = now;
-                            const int l = __hip_atomic_load(&sync_words[kSyncLimit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            limit = l > 0 ? (unsigned long long)l : kDefaultPollLimit;
-                        }
-                        const bool failed = __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                        if (failed || now - t0 > limit) {
-                            if (!failed) __hip_atomic_store(&sync_words[kSyncStatus], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(&dead_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            break;
-                        }
-                    }
-                }
-            }
-        }
-        if (tid <= NT / 64) published[tid] = 0;  // (the previous item's counters: its sweeps may have had the same numbers)
-        if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the polls have returned
-        __syncthreads();                         // the polling wave has seen the flags; nobody still reads the previous item's LDS rows
-        if (__hip_atomic_load(&dead_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
-        float *Xk = (blk & 1) ? P1k : P0k, *Xm = (blk & 1) ? P1m : P0m;     // block blk reads this pair ...
-        float *Yk = (blk & 1) ? P0k : P1k, *Ym = (blk & 1) ? P0m : P1m;     // ... and writes that one
-        const int x0 = bx * TW - hx + 4 * lx;
-        const int y0 = by * TH - hy + tr * G;
-        const bool colok = x0 >= 0 && x0 < cols;
-        f4r a[G], b[G];
-        float wr[G][4], wd[G][4], wl0[G], wu0[4], cnt[G][4], rcp[G][4];
-        bool unsafe = false;
-        uint32_t dirichlet = 0;
-        // the extended tile: 16-byte sc1 loads (every byte of it was stored sc1 and drained before its owner's flag; the polling wave
-        // loads after its poll, the others behind the barrier above -- MI355X_MICROARCH.md "Valid forms", row 1), ONE wait
-        f4r vxr[G], vpr[G];
-        uint4 mr[G], mup = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int y = y0 + g;
-            vxr[g] = f4r{0, 0, 0, 0}; vpr[g] = vxr[g]; mr[g] = make_uint4(0, 0, 0, 0);
-            if (!(RTDD_FLOW_DIAG & 64) && colok && y >= 0 && y < rows) {
-                const size_t off = (size_t)y * ip + x0;
-                if (RTDD_FLOW_DIAG & 2) { const float4 t0_ = *(const float4 *)(Xk + off), t1_ = *(const float4 *)(Xm + off); vxr[g] = f4r{t0_.x, t0_.y, t0_.z, t0_.w}; vpr[g] = f4r{t1_.x, t1_.y, t1_.z, t1_.w}; }
-                else { load_sc1(vxr[g], Xk + off); load_sc1(vpr[g], Xm + off); }
-                mr[g] = *(const uint4 *)(M + off);
-            }
-        }
-        if (colok && y0 - 1 >= 0 && y0 < rows) mup = *(const uint4 *)(M + (size_t)(y0 - 1) * ip + x0);
-        if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(vxr[0]), "+v"(vpr[0]) :: "memory");
-        else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(vxr[0]), "+v"(vpr[0]), "+v"(vxr[1]), "+v"(vpr[1]) :: "memory");
-        else {
-            static_assert(G == 3, "add a wait for this G");
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vxr[0]), "+v"(vpr[0]), "+v"(vxr[1]), "+v"(vpr[1]), "+v"(vxr[2]), "+v"(vpr[2]) :: "memory");
-        }
-#include "sweep_tile_setup.inc"
-#include "sweep_tile_sweeps.inc"
-        int s = blk * T;                          // (T is even: every block starts at an even sweep, as the parity constants below assume)
-        const int s_end = (RTDD_FLOW_DIAG & 32) ? s : min(s + T, nsweeps);
-        bool odd = false;
-        publish(a[0], a[G - 1], s, 0);
-        using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
-        if (!wave_unsafe) {
-            for (; s + 1 < s_end; s += 2) {
-                sweep(a, b, s, std::true_type{}, false, P0{});
-                sweep(b, a, s + 1, std::true_type{}, s + 2 >= s_end, P1{});
-            }
-            if (s < s_end) { sweep(a, b, s, std::true_type{}, true, P0{}); s++; odd = true; }
-        } else {
-            for (; s + 1 < s_end; s += 2) {
-                sweep(a, b, s, std::false_type{}, false, P0{});
-                sweep(b, a, s + 1, std::false_type{}, s + 2 >= s_end, P1{});
-            }
-            if (s < s_end) { sweep(a, b, s, std::false_type{}, true, P0{}); s++; odd = true; }
-        }
-        // the centre -> the other pair, write-through; drained by every storing wave before the flag
-        const bool xin = colok && 4 * lx >= hx && 4 * lx < EW - hx;
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int y = y0 + g, ty = tr * G + g;
-            if (!(RTDD_FLOW_DIAG & 64) && xin && ty >= hy && ty < eh - hy && y < rows) {
-                const size_t off = (size_t)y * ip + x0;
-                const float4 vk = make_float4(odd ? b[g][0] : a[g][0], odd ? b[g][1] : a[g][1], odd ? b[g][2] : a[g][2], odd ? b[g][3] : a[g][3]);
-                const float4 vm = make_float4(odd ? a[g][0] : b[g][0], odd ? a[g][1] : b[g][1], odd ? a[g][2] : b[g][2], odd ? a[g][3] : b[g][3]);
-                if (RTDD_FLOW_DIAG & 8) { *(float4 *)(Yk + off) = vk; *(float4 *)(Ym + off) = vm; }
-                else { store_sc1((float4 *)(Yk + off), vk); store_sc1((float4 *)(Ym + off), vm); }
-            }
-        }
-        if (!(RTDD_FLOW_DIAG & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            if (__hip_atomic_load(&sync_words[kSyncWithhold], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != t + 1)      // (testing aid: RTDD_OPT_DEBUG_WITHHOLD_TILE)
-                __hip_atomic_store(flags + (size_t)t * kFlowFlagStride, flag_base + blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            item_s = next_item;                  // (a chunk's fetch-add has long returned when its last item ends)
-        }
-        __syncthreads();
-        item = item_s;
-    }
-}
-
 // ---- the same sweeps in a COLUMN layout (tile 14): a thread owns 1 pixel x 4 rows --------------------------------------------
 // For the small pyramid levels every sweep is a chain -- counter poll, row reads, arithmetic, publish -- and with one row of 4
 // pixels per thread (tile 9) EVERY row is an edge row: all of a wave's arithmetic sits between its wait and its publish, and each
@@ -591,14 +418,6 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
         constexpr int buf = decltype(parity)::value;
         float up, dn;
         RTDD_TL(0, s);
-#if RTDD_COL_SHIFT_LDS
-        float xls[R], xrs[R];                    // the neighbouring lanes' x_k: requested now, in flight during the wait for the neighbouring waves
-        {
-            const int prev4 = ((lane + 63) & 63) * 4;
-#pragma unroll
-            for (int g = 0; g < R; g++) { xls[g] = lds_from_prev(prev4, cur[g]); xrs[g] = lds_from_next(prev4, cur[g]); }
-        }
-#endif
         {
             const long long *pu = (const long long *)&edge[buf][up_w][lane] + up_half, *pd = (const long long *)&edge[buf][dn_w][lane] + dn_half;
             auto read_both = [&]() {                 // (value, tag) of either neighbour in one 8-byte read each; true when both tags are there
@@ -628,24 +447,15 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
 #endif
         RTDD_TL(1, s);
         const float omega = omegas[s], gamma_v = gamma;     // (scalar operands: the vector form measured no faster, see k_sweep_blocked)
-#ifndef RTDD_COL_SHIFT_LDS
-#define RTDD_COL_SHIFT_LDS 0       // 1: the lane shifts through the LDS crossbar (sweep_common.hpp) instead of DPP; measured: scripts/r3_bperm_col.sh
-#endif
+        // (the lane shifts stay DPP here: through the LDS crossbar -- 8 ds_bpermute_b32 per thread and sweep, as k_sweep_blocked does with
+        // its 2 per row -- the coarse levels measured 20 % SLOWER, and with no shifts at all (timing only) no faster: EXPERIMENTS.md)
         auto wsum = [&](int g) {
-#if RTDD_COL_SHIFT_LDS
-            const float xl = xls[g];
-#else
             const float xl = lane_from_prev(cur[g]);
-#endif
             const float xu = g == 0 ? up : cur[g - 1], xd = g == R - 1 ? dn : cur[g + 1];
             const float wu = g == 0 ? wu0 : wd[g - 1];
             float sum = 0.0f;
             sum = CONTRACT ? __builtin_fmaf(wl[g], xl, sum) : sum + wl[g] * xl;
-            if (RTDD_COL_SHIFT_LDS) {
-#if RTDD_COL_SHIFT_LDS
-                sum = CONTRACT ? __builtin_fmaf(wr[g], xrs[g], sum) : sum + wr[g] * xrs[g];
-#endif
-            } else if (CONTRACT) {
+            if (CONTRACT) {
                 // sum = fma(wr, x of the NEXT lane, sum) with the lane shift as the instruction's own DPP operand (lane 63 reads 0, as
                 // lane_from_next gives it): one instruction instead of v_mov_b32_dpp + v_fmac -- hipcc does not fold wave shifts itself
                 // (a DPP read needs two wait states after a VALU write of its SOURCE register and five after a VALU write of EXEC; the hazard
@@ -729,18 +539,15 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-struct TileCfg { int lx, nt, g, pk; };        // pk: 1 = plain tile; 2 = packed tile (sweep_pk.hip): two halves stacked, a thread holds its rows in both
+struct TileCfg { int lx, nt, g; };
 // id -> (lanes per tile row, threads, rows per thread); extended tile = 4*lx wide, nt/lx*g tall
 static const TileCfg kTiles[] = {{0, 0, 0}, {16, 256, 4}, {32, 512, 4}, {32, 1024, 4}, {32, 1024, 3}, {32, 512, 3}, {16, 512, 3}, {16, 256, 3}, {32, 1024, 2},
                                  {16, 1024, 1}, {16, 512, 2}, {32, 1024, 1}, {32, 768, 4}, {32, 512, 6},
                                  {16, 1024, 1} /* 14: tile 9's geometry in the column layout (k_sweep_col) */,
-                                 {16, 512, 1} /* 15: the column layout on 64 x 32 (8 waves) */, {16, 768, 1} /* 16: ... on 64 x 48 (12 waves) */,
-                                 {32, 768, 2, 2} /* 17: packed (k_sweep_pk), 128 x 96 */, {32, 512, 3, 2} /* 18: packed, 128 x 96, 3 rows per thread and half */,
-                                 {16, 384, 2, 2} /* 19: packed, 64 x 96 */};
-constexpr int kNumTiles = 19;
-static inline bool is_col_tile(int tile) { return tile >= 14 && tile <= 16; }
-static inline bool is_pk_tile(int tile) { return tile >= 17 && tile <= 19; }
-static inline int tile_rows(int tile, int nthreads) { return nthreads / kTiles[tile].lx * kTiles[tile].g * (is_pk_tile(tile) ? 2 : 1); }
+                                 {16, 512, 1} /* 15: the column layout on 64 x 32 (8 waves) */, {16, 768, 1} /* 16: ... on 64 x 48 (12 waves) */};
+constexpr int kNumTiles = 16;
+static inline bool is_col_tile(int tile) { return tile >= 14; }
+static inline int tile_rows(int tile, int nthreads) { return nthreads / kTiles[tile].lx * kTiles[tile].g; }
 
 // Can every workgroup of a persistent launch be resident at once?  Asked of the runtime once per kernel (the answer depends on the
 // kernel's registers and LDS): at least one workgroup of `nthreads` threads per CU, and no more workgroups than CUs.  A launch that
@@ -786,7 +593,7 @@ static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, fl
 //   persistent                 T sweeps + ~8 us halo exchange (6 us for the small tiles); needs nWG <= #CUs, T even,
 //                              halo no wider than a neighbour's centre
 // It only has to rank candidates; it reproduces the measured launch times within ~15 %.
-static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1, 2, 4, 2, 1, 1, 2};
+static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1, 2, 4, 2};
 
 static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int tile, int T, bool persist) {
     const int G = kTiles[tile].g;
@@ -859,42 +666,6 @@ static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fi
     RTDD_TILE_CASE(11, 32, 1024, 1) RTDD_TILE_CASE(12, 32, 768, 4) RTDD_TILE_CASE(13, 32, 512, 6)
 #endif
 
-// ---- dataflow launch (k_sweep_flow): the tiles large images use ------------------------------------------------------------------
-#define RTDD_FLOW_TILES RTDD_TILE_CASE(4, 32, 1024, 3) RTDD_TILE_CASE(5, 32, 512, 3) RTDD_TILE_CASE(6, 16, 512, 3) RTDD_TILE_CASE(7, 16, 256, 3)
-
-// how many workgroups of k_sweep_flow the chip holds (0: this tile has no dataflow instantiation, or the runtime says none fits).  More
-// workgroups than that would only queue; correctness does not depend on the number (see the kernel).
-static int flow_workgroups(rtdd_ctx *ctx, int tile, int nthreads) {
-    if (tile < 0 || tile > 16) return 0;
-    signed char &c = ctx->flow_occ[tile][ctx->opt.fp_contract ? 1 : 0];
-    if (c < 0) {
-        int nb = 0;
-        hipError_t e = hipErrorInvalidValue;
-        switch (tile) {
-#define RTDD_TILE_CASE(id, LX_, NT_, G_) case id: e = ctx->opt.fp_contract ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sweep_flow<LX_, NT_, G_, true>, nthreads, 0) \
-                                                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sweep_flow<LX_, NT_, G_, false>, nthreads, 0); break;
-            RTDD_FLOW_TILES
-#undef RTDD_TILE_CASE
-            default: break;
-        }
-        c = (e == hipSuccess && nb > 0) ? (signed char)(nb > 16 ? 16 : nb) : 0;
-    }
-    return (int)c * ctx->num_cus;
-}
-
-static void launch_flow(rtdd_ctx *ctx, int tile, int wgs, int nthreads, float *P0k, float *P0m, float *P1k, float *P1m, const uint32_t *M, const float *omegas,
-                        int ip, int rows, int cols, int hx, int hy, int n, float gamma, int T, int gx, int gy, int flag_base, int item_base) {
-    switch (tile) {
-#define RTDD_TILE_CASE(id, LX_, NT_, G_) case id: \
-        if (ctx->opt.fp_contract) hipLaunchKernelGGL((k_sweep_flow<LX_, NT_, G_, true>), dim3(wgs), dim3(nthreads), 0, ctx->stream, P0k, P0m, P1k, P1m, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma, T, ctx->sync_words, ctx->flow_flags, gx, gy, flag_base, item_base); \
-        else hipLaunchKernelGGL((k_sweep_flow<LX_, NT_, G_, false>), dim3(wgs), dim3(nthreads), 0, ctx->stream, P0k, P0m, P1k, P1m, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma, T, ctx->sync_words, ctx->flow_flags, gx, gy, flag_base, item_base); \
-        break;
-        RTDD_FLOW_TILES
-#undef RTDD_TILE_CASE
-        default: break;
-    }
-}
-
 // Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
 // holding x_{k+n} / x_{k+n-1}.  omegas_dev[0..n) must already be on the device.
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
@@ -927,8 +698,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         // a single tile launches only the thread rows the image needs (whole waves), e.g. 120x67 -> 23 of 32 rows
         int nthreads = kTiles[tile].nt;
         if (single) {
-            const int rpt = kTiles[tile].g * (is_pk_tile(tile) ? 2 : 1);       // image rows one thread row covers
-            const int need = (rows + rpt - 1) / rpt * kTiles[tile].lx;
+            const int need = (rows + kTiles[tile].g - 1) / kTiles[tile].g * kTiles[tile].lx;
             nthreads = (need + 63) / 64 * 64;
             if (nthreads > kTiles[tile].nt) nthreads = kTiles[tile].nt;
         }
@@ -938,12 +708,11 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         // PERSISTENT mode: all remaining sweeps in ONE launch, neighbouring workgroups trade halo strips every T sweeps.
         // Only when every workgroup is certainly co-resident (grid <= #CUs), T is even, and there is more than one block.
         int block_sweeps = m;
-        bool persistent = !single && want_persistent && ctx->opt.persistent != 2 && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= (unsigned)kSyncMaxTiles &&
+        bool persistent = !single && want_persistent && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= (unsigned)kSyncMaxTiles &&
                                 (T % 2 == 0) && n - done > T && hy == T &&
                                 hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
         if (is_col_tile(tile)) persistent = false;          // (the column-layout kernel has no persistent mode)
-        if (persistent && is_pk_tile(tile)) persistent = pk_persistent_possible(ctx, tile, kTiles[tile].nt);
-        else if (persistent) {
+        if (persistent) {
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) case id: persistent = persistent_possible<LX_, NT_, G_>(ctx, tile, kTiles[tile].nt); break;
             switch (tile) { RTDD_ALL_TILES }
 #undef RTDD_TILE_CASE
@@ -954,37 +723,6 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             m = n - done;
             { const int rc_ = prepare_persistent_launch(ctx, (m + T - 1) / T, &flag_base); if (rc_ != RTDD_OK) return rc_; }   // this launch's flag values, debug words
             ctx->persistent_used = true;
-        }
-        // DATAFLOW mode (k_sweep_flow), RTDD_OPT_PERSISTENT = 2 only: ONE launch runs every block of sweeps, workgroups claiming (block,
-        // tile) items in order and waiting only for the nine tiles around theirs (no kernel boundary, no tail per block).  Bit-exact and
-        // tested, but measured at HALF the rate of one launch per block at 4K / 8K (570 against 1100 Gpx-it/s: every item pays a poll,
-        // write-through loads of its whole extended tile, a drain and a flag, in series): never chosen automatically.  EXPERIMENTS.md.
-        int flow_wgs = 0;
-        if (!single && !persistent && ctx->opt.persistent == 2 && !is_col_tile(tile) && !is_pk_tile(tile) && (T % 2 == 0) && n - done > T && hy == T && hx <= TW && hy <= TH)
-            flow_wgs = flow_workgroups(ctx, tile, nthreads);
-        if (flow_wgs > 0) {
-            const int mm = n - done, nblocks = (mm + T - 1) / T, ntiles = (int)(grid.x * grid.y);
-            const long long total = (long long)ntiles * nblocks;
-            static const int wgs_env = getenv("RTDD_FLOW_WGS") ? atoi(getenv("RTDD_FLOW_WGS")) : 0;       // (developer knob: workgroups per CU)
-            if (wgs_env > 0) flow_wgs = wgs_env * ctx->num_cus;
-            const int launch_wgs = (int)(total < flow_wgs ? total : flow_wgs);
-            if (getenv("RTDD_DEBUG_CONFIG")) fprintf(stderr, "[rtdd] dataflow: %d tiles x %d blocks, %d workgroups (%d per CU)\n", ntiles, nblocks, launch_wgs, flow_wgs / ctx->num_cus);
-            int item_base = 0;
-            { const int rc_ = prepare_flow_launch(ctx, (size_t)ntiles, nblocks, launch_wgs, &flag_base, &item_base); if (rc_ != RTDD_OK) return rc_; }
-            int f0 = -1, f1 = -1;
-            for (int i = 0; i < 4; i++) if (i != *pk && i != *pm) { if (f0 < 0) f0 = i; else f1 = i; }
-            launch_flow(ctx, tile, launch_wgs, nthreads, L.P(*pk, ip), L.P(*pm, ip), L.P(f0, ip), L.P(f1, ip), L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, mm, gamma, T,
-                        (int)grid.x, (int)grid.y, flag_base, item_base);
-            ctx->persistent_used = true;
-            if (ctx->opt.debug_force_status) {
-                RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncStatus), ctx->opt.debug_force_status, 1, ctx->stream));
-                ctx->opt.debug_force_status = 0;
-            }
-            ctx->last_info.kernel = 2; ctx->last_info.tile = tile; ctx->last_info.temporal_depth = T; ctx->last_info.persistent = 2;
-            if (nblocks & 1) { *pk = f0; *pm = f1; }            // block b reads pair b & 1 and writes the other: the last block's output
-            done += mm;
-            (*launches)++;
-            continue;
         }
         // XCD-aware tile placement (RTDD_XCD_REMAP=0 turns it off): +1.5-4 % persistent (strips traded inside one L2), +8 % at 4K
         // launch-per-block (a tile's halo is its neighbours' centre: the same XCD reads both)
@@ -1001,8 +739,6 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
             if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
             else hipLaunchKernelGGL(k_sweep_col<false>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
-        } else if (is_pk_tile(tile)) {
-            launch_sweep_pk(ctx, tile, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps, flag_base);
         } else
         switch (tile) { RTDD_ALL_TILES }
 #undef RTDD_TILE_CASE

@@ -14,15 +14,16 @@ __device__ __forceinline__ float lane_from_next(float v) {   // lane l <- lane l
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 
-// The same two shifts through the LDS crossbar (ds_bpermute_b32: no LDS memory, no VALU slot).  Why: ONE DPP instruction of any kind
-// in a loop slows the VALU instructions of the OTHER waves of its SIMD -- the sweep's instruction mix replayed on the GPU issues at
-// 3.26 cycles per wave-instruction and SIMD with its two v_mov_b32_dpp per row, at 2.24 with plain moves in their place and at 2.27
-// with ds_bpermute_b32 issued ahead (scripts/ubench/gen_block_bench.py, profiles/r03_block_replay.txt; one wave per SIMD sees no
-// difference, row_shr / quad_perm cost the same as wave_shr).  `prev4` = 4 * ((lane - 1) & 63), held in a register by the caller;
-// lane l + 1 is prev4 + 8 (the unit takes address bits 7:2).  Lane 0 reads lane 63 and lane 63 lane 0 where DPP's bound_ctrl gave
-// 0: both only ever meet a zero weight (sweep_tile_setup.inc: the right weight of a tile row's last pixel is 0, and lane 63 ends a
-// tile row for every LX), and the values are finite.  The result arrives like an LDS read: the compiler waits on lgkmcnt before
-// its first use, so the callers issue these well ahead.
+// The same two shifts through the LDS crossbar (ds_bpermute_b32: no LDS memory, no VALU slot), issued a group of rows ahead so that
+// their latency hides behind the wait for the neighbouring waves' rows: k_sweep_blocked measured +3-5 % with them (1080p 1.17 -> 1.21
+// Tpx-it/s, one tile alone 0.996 -> 0.945 us per sweep, same call).  What pointed here: the sweep's instruction mix replayed as a
+// micro-benchmark issues at 3.26 cycles per wave-instruction and SIMD with its two v_mov_b32_dpp per row and at 2.27 with two
+// ds_bpermute_b32 in their place (scripts/ubench/gen_block_bench.py, profiles/r03_block_replay.txt) -- in the kernel most of that
+// difference does not show, and the column-layout kernel (8 shifts per thread and sweep) is SLOWER this way (EXPERIMENTS.md).
+// `prev4` = 4 * ((lane - 1) & 63), held in a register by the caller; lane l + 1 is prev4 + 8 (the unit takes address bits 7:2).  Lane 0
+// reads lane 63 and lane 63 lane 0 where DPP's bound_ctrl gave 0: both only ever meet a zero weight (sweep_tile_setup.inc: the right
+// weight of a tile row's last pixel is 0, and lane 63 ends a tile row for every LX), and the values are finite.  The result arrives
+// like an LDS read: the compiler waits on lgkmcnt before its first use.
 __device__ __forceinline__ float lds_from_prev(int prev4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(prev4, __float_as_int(v))); }
 __device__ __forceinline__ float lds_from_next(int prev4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(prev4 + 8, __float_as_int(v))); }
 

@@ -93,14 +93,6 @@ def test_north_star_4k_1000_jacobi_sweeps_bit_exact(ctx, oracle, lut, problem_4k
     assert info.persistent == 0 and info.launches == -(-1000 // info.temporal_depth), info.describe()   # too many tiles to be resident: launch per block
 
 
-def test_4k_1000_jacobi_sweeps_one_dataflow_launch(ctx, oracle, lut, problem_4k):
-    """The same with RTDD_OPT_PERSISTENT = 2: every block of sweeps in ONE dataflow launch (k_sweep_flow; experimental, not the default)."""
-    ctx.set_option(rt.OPT_PERSISTENT, 2)
-    info = _jacobi_at_size(ctx, oracle, lut, problem_4k, 1000, 1, "4K x 1000 Jacobi, dataflow")
-    ctx.set_option(rt.OPT_PERSISTENT, 1)
-    assert info.persistent == 2 and info.launches == 1, info.describe()
-
-
 def test_north_star_4k_odd_sweep_count_and_second_seed(ctx, oracle, lut):
     """Another image and a sweep count that is no multiple of the temporal depth (a short last block)."""
     p = make_problem(2160, 3840, seed=77)
@@ -115,16 +107,12 @@ def test_4k_jacobi_every_large_tile_bit_exact(ctx, oracle, lut, problem_4k, tile
     ctx.GPUAllocateDeviceMemory(rows, cols, 1)
     want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 64, 0, 0, lut, 1, threads=oracle.max_threads())
     ctx.set_option(rt.OPT_SWEEP_KERNEL, 2); ctx.set_option(rt.OPT_TILE, tile); ctx.set_option(rt.OPT_TEMPORAL_DEPTH, depth)
-    for persistent in (2, 0):                                   # dataflow (tiles 4-7) / one launch per block
-        ctx.set_option(rt.OPT_PERSISTENT, persistent)
-        d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
-        ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 64, 1e-5, 0)
-        info = ctx.last_solve_info()
-        ctx.synchronize()
-        assert info.tile == tile, info.describe()      # (temporal_depth reports the LAST launch: the short tail block, or the tile's cap)
-        assert info.persistent == (2 if persistent and tile in (4, 5, 6, 7) else 0), info.describe()
-        assert_bit_equal(down(d), want, f"4K x 64, tile {tile} depth {depth}, persistent option {persistent}")
-    ctx.set_option(rt.OPT_PERSISTENT, 1)
+    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+    ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 64, 1e-5, 0)
+    info = ctx.last_solve_info()
+    ctx.synchronize()
+    assert info.tile == tile, info.describe()      # (temporal_depth reports the LAST launch: the short tail block, or the tile's cap)
+    assert_bit_equal(down(d), want, f"4K x 64, tile {tile} depth {depth}")
 
 
 def test_north_star_8k_200_jacobi_sweeps_bit_exact(ctx, oracle, lut, problem_8k):

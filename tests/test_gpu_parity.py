@@ -72,9 +72,7 @@ def test_solver_bit_exact(ctx, oracle, lut, shape, level, levels, iters, contrac
 
 
 @pytest.mark.parametrize("tile,depth", [(1, 1), (1, 4), (1, 7), (1, 8), (1, 16), (2, 4), (2, 8), (2, 5), (3, 4), (3, 12), (3, 16), (12, 8), (13, 8), (13, 5), (9, 28), (9, 24), (11, 8), (4, 28), (14, 8), (14, 28), (14, 5), (14, 1),
-                                        (5, 8), (5, 12), (6, 8), (6, 12), (7, 8), (7, 12), (8, 8), (8, 12), (10, 8), (10, 12), (4, 8), (4, 12),
-                                        # the packed tiles (sweep_pk.hip: two pixels per vector instruction)
-                                        (17, 8), (17, 12), (17, 5), (17, 1), (17, 28), (18, 8), (18, 12), (18, 3), (19, 8), (19, 12), (19, 7), (19, 16)])
+                                        (5, 8), (5, 12), (6, 8), (6, 12), (7, 8), (7, 12), (8, 8), (8, 12), (10, 8), (10, 12), (4, 8), (4, 12)])
 @pytest.mark.parametrize("shape,iters,level,levels", [((200, 333), 37, 0, 1), ((67, 120), 64, 1, 2), ((300, 130), 24, 0, 2), ((129, 129), 19, 0, 1)])
 def test_blocked_kernel_bit_exact(ctx, oracle, lut, tile, depth, shape, iters, level, levels):
     """Temporal blocking is only a re-schedule: any tile shape / depth must reproduce the oracle bit for bit."""
@@ -101,12 +99,6 @@ def test_blocked_kernel_bit_exact(ctx, oracle, lut, tile, depth, shape, iters, l
     ((1080, 1920), 120, 13, 8),    # ... and by 8 waves of 24 pixels per thread
     ((270, 480), 50, 13, 8),
     ((300, 130), 64, 7, 16),
-    ((1080, 1920), 200, 17, 8),    # the headline tile in packed form (12 waves, 16 pixels per thread in 8 register pairs per row)
-    ((1080, 1920), 120, 18, 8),    # ... 8 waves, 24 pixels per thread
-    ((540, 960), 125, 17, 8),
-    ((270, 480), 250, 19, 8),      # 64 x 96 packed tiles
-    ((200, 333), 100, 19, 12),
-    ((300, 130), 64, 17, 16),
 ])
 def test_persistent_mode_bit_exact(ctx, oracle, lut, shape, iters, tile, depth):
     """Persistent mode: one launch, tiles stay in registers, neighbouring workgroups trade halo strips through
@@ -124,108 +116,6 @@ def test_persistent_mode_bit_exact(ctx, oracle, lut, shape, iters, tile, depth):
         ctx.set_option(k, 0)
 
 
-@pytest.mark.parametrize("shape,iters,tile,depth", [
-    ((200, 333), 100, 6, 8),       # 7 x 3 tiles of 48 x 80, 12.5 blocks: a short last block
-    ((270, 480), 64, 7, 8),        # 10 x 9 tiles of 48 x 32
-    ((540, 960), 40, 4, 8),        # 9 x 7 tiles of 112 x 80
-    ((540, 960), 37, 5, 8),        # 128 x 48 tiles, an odd sweep count
-    ((300, 130), 64, 6, 12),       # depth 12: 40 x 72 centres
-    ((129, 129), 19, 7, 4),
-    ((1080, 1920), 120, 6, 8),     # 40 x 14 = 560 tiles: more than the chip holds at once even without the option
-])
-def test_dataflow_mode_bit_exact(ctx, oracle, lut, shape, iters, tile, depth):
-    """k_sweep_flow: ONE launch, workgroups claim (block, tile) items in order and wait only for the tiles around theirs.  Forced here on
-    images small enough for the persistent mode (RTDD_OPT_PERSISTENT = 2); three runs each: the flags and the item counter are
-    monotonic across launches, caches are warm on the later ones."""
-    p = make_problem(shape[0], shape[1], seed=shape[0] + 5 * shape[1])
-    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, 0, 0, lut, 1, threads=oracle.max_threads())
-    opts = {rt.OPT_SWEEP_KERNEL: 2, rt.OPT_TILE: tile, rt.OPT_TEMPORAL_DEPTH: depth, rt.OPT_PERSISTENT: 2}
-    ctx.profile_enable(True)
-    for rep in range(3):
-        got = _solve_gpu(ctx, p, iters, 0, 1, 1, opts=opts)
-        info = ctx.last_solve_info()
-        assert info.persistent == 2 and ctx.profile().launches == 1, info.describe()
-        assert_bit_equal(got, want, f"dataflow {shape} tile {tile} depth {depth} rep {rep}")
-    ctx.profile_enable(False)
-    for k in opts:
-        ctx.set_option(k, 0)
-    ctx.set_option(rt.OPT_PERSISTENT, 1)
-
-
-def test_dataflow_timeout_is_reported_and_recoverable(ctx, oracle, lut):
-    """A tile whose flag never appears (RTDD_OPT_DEBUG_WITHHOLD_TILE) stops its neighbours' next block: bounded polls, the launch drains,
-    RTDD_ERR_TIMEOUT at the next synchronisation, counter and flags start over, the context solves bit-exactly again."""
-    import time
-    rows, cols = 540, 960
-    p = make_problem(rows, cols, seed=15)
-    ctx.GPUAllocateDeviceMemory(rows, cols, 1)
-    opts = {rt.OPT_SWEEP_KERNEL: 2, rt.OPT_TILE: 6, rt.OPT_TEMPORAL_DEPTH: 8, rt.OPT_PERSISTENT: 2}
-    for k, v in opts.items():
-        ctx.set_option(k, v)
-    d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
-    ctx.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); ctx.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 30 + 1)
-    try:
-        t0 = time.perf_counter()
-        ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 80, 0.0, 0)
-        with pytest.raises(rt.RtddError) as e:
-            ctx.synchronize()
-        assert e.value.status == rt.RTDD_ERR_TIMEOUT and time.perf_counter() - t0 < 0.5
-    finally:
-        ctx.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 0); ctx.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 0)
-    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 80, 0, 0, lut, 1, threads=oracle.max_threads())
-    d2 = up(p["depth"])
-    ctx.GPUMatrixFreeSolver(d2, m, g, rows, cols, 0.4, 80, 0.0, 0); ctx.synchronize()
-    assert ctx.last_solve_info().persistent == 2
-    assert_bit_equal(down(d2), want, "dataflow solve after a timed-out one")
-    for k in opts:
-        ctx.set_option(k, 0)
-    ctx.set_option(rt.OPT_PERSISTENT, 1)
-
-
-def test_packed_tiles_randomised(ctx, oracle, lut):
-    """40 random (shape, sweeps, level rule, packed tile, depth, persistence, contraction) draws for k_sweep_pk: single tiles launched
-    with fewer thread rows, ragged grids, the seam between the two halves of a tile at every offset, both contraction variants."""
-    rng = np.random.default_rng(20261004)
-    for trial in range(40):
-        rows = int(rng.integers(1, 330)); cols = int(rng.integers(1, 420))
-        iters = int(rng.integers(1, 70))
-        levels = int(rng.integers(1, 4)); level = int(rng.integers(0, levels))
-        contract = int(rng.integers(0, 2))
-        opts = {rt.OPT_SWEEP_KERNEL: 2, rt.OPT_PERSISTENT: int(rng.integers(0, 2)), rt.OPT_TILE: int(rng.integers(17, 20)),
-                rt.OPT_TEMPORAL_DEPTH: int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 24]))}
-        p = make_problem(rows, cols, seed=3000 + trial)
-        if level != levels - 1:
-            free = p["mask"] != 255
-            p["depth"][free] = rng.uniform(0, 255, free.sum()).astype(np.float32)
-        want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, level, levels - 1, lut, contract, threads=min(8, oracle.max_threads()))
-        got = _solve_gpu(ctx, p, iters, level, levels, contract, opts=opts)
-        info = ctx.last_solve_info()
-        for k in opts:
-            ctx.set_option(k, 0)
-        ctx.set_option(rt.OPT_PERSISTENT, 1)
-        assert info.tile == opts[rt.OPT_TILE], info.describe()
-        assert_bit_equal(got, want, f"packed trial {trial}: {rows}x{cols} iters {iters} level {level}/{levels} contract {contract} opts {opts}")
-
-
-def test_packed_tile_denormal_weights_and_tiny_numerators(ctx, oracle, lut):
-    """beta = 0.4 makes LUT entries 219..255 denormal: divisors below 2^-126 take the full divide per wave, numerators below 2^-100 the
-    wave-uniform redo of a row -- both paths of k_sweep_pk on an image built to reach them (hard edges everywhere, a decaying front)."""
-    rng = np.random.default_rng(7)
-    rows, cols = 150, 260
-    gray = (rng.integers(0, 2, (rows, cols)) * 255).astype(np.uint8)           # neighbours differ by 0 or 255: weights 1 or exp(-102) (denormal)
-    mask = np.zeros((rows, cols), np.uint8); depth = np.zeros((rows, cols), np.float32)
-    mask[::37, ::41] = 255; depth[::37, ::41] = rng.uniform(1, 255, depth[::37, ::41].shape).astype(np.float32)
-    p = {"depth": depth, "mask": mask, "gray": gray}
-    for contract in (1, 0):
-        want = oracle.solve(depth.copy(), mask, gray, 60, 0, 0, lut, contract, threads=min(8, oracle.max_threads()))
-        for tile in (17, 18, 19):
-            opts = {rt.OPT_SWEEP_KERNEL: 2, rt.OPT_TILE: tile, rt.OPT_TEMPORAL_DEPTH: 8}
-            got = _solve_gpu(ctx, p, 60, 0, 1, contract, opts=opts)
-            for k in opts:
-                ctx.set_option(k, 0)
-            assert_bit_equal(got, want, f"packed tile {tile} contract {contract}, denormal weights")
-
-
 def test_randomised_shapes_and_options(ctx, oracle, lut):
     """60 random (shape, sweeps, level rule, kernel, tile, depth, persistence, contraction) draws, fixed seed: every
     one bit-exact.  Catches geometry corner cases the hand-picked lists miss (ragged tiles, tiny centres, 1-pixel strips)."""
@@ -238,7 +128,7 @@ def test_randomised_shapes_and_options(ctx, oracle, lut):
         levels = int(rng.integers(1, 4)); level = int(rng.integers(0, levels))
         contract = int(rng.integers(0, 2))
         kernel = int(rng.choice([0, 0, 1, 2]))
-        opts = {rt.OPT_SWEEP_KERNEL: kernel, rt.OPT_PERSISTENT: int(rng.integers(0, 3))}            # 2: the dataflow launch where a tile has one
+        opts = {rt.OPT_SWEEP_KERNEL: kernel, rt.OPT_PERSISTENT: int(rng.integers(0, 2))}
         if kernel != 1 and rng.random() < 0.6:
             opts[rt.OPT_TILE] = int(rng.integers(1, 14)); opts[rt.OPT_TEMPORAL_DEPTH] = int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 24]))
         p = make_problem(rows, cols, seed=1000 + trial)
