@@ -60,9 +60,14 @@ int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
 // The stream has just been synchronised by the caller.  A blocked-sweep launch since the last check may have given up (persist_sync.hpp).
 int check_persistent_status(rtdd_ctx *ctx) {
     if (!ctx->persistent_used || !ctx->sync_words) return RTDD_OK;
-    int status = 0;
-    RTDD_HIP(ctx, hipMemcpy(&status, ctx->sync_words + kSyncStatus, sizeof(int), hipMemcpyDeviceToHost));
+    int words[4] = {0, 0, 0, 0};
+    RTDD_HIP(ctx, hipMemcpy(words, ctx->sync_words, sizeof(words), hipMemcpyDeviceToHost));
     ctx->persistent_used = false;
+    const int status = words[kSyncStatus];
+    if (words[kSyncNonLocal] != 0) {               // the tile defocus kernel summed windows by hand: not a depth map -- the table path from now on
+        ctx->defocus_table_sticky = true;
+        RTDD_HIP(ctx, hipMemset(ctx->sync_words + kSyncNonLocal, 0, sizeof(int)));
+    }
     if (status == 0) return RTDD_OK;
     RTDD_HIP(ctx, hipMemset(ctx->sync_words + kSyncStatus, 0, sizeof(int)));
     return fail(ctx, RTDD_ERR_TIMEOUT, status == 1 ? "persistent sweep kernel: a workgroup timed out waiting for a neighbouring tile (its workgroups were not all "

@@ -9,6 +9,7 @@
 // Defocus in the reference is a per-pixel O(k^2) gather (up to 48 400 taps at 8K, src/GPUDepthEffect.cu:47-60); here it is an
 // exact O(1) lookup in a packed 64-bit summed-area table written once -- see "defocus" below.
 #include "rtdd_internal.hpp"
+#include "persist_sync.hpp"
 
 namespace rtdd {
 
@@ -488,7 +489,7 @@ __device__ __forceinline__ u64 half_incl_scan64(u64 v) {
 template <bool VEC, int kDtH>
 __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restrict__ orig, size_t op, const float *__restrict__ depth, size_t dp,
                                                          uint8_t *__restrict__ art, size_t ap, int rows, int cols, int kernelSize, int hm,
-                                                         int gx, int ntiles, int xcd_tiles) {
+                                                         int gx, int ntiles, int xcd_tiles, int *__restrict__ nonlocal_word) {
     constexpr int kDtRH = kDtH + 2 * kDtHM, kDtRowsPer = (kDtRH + kDtWorkers - 1) / kDtWorkers;
     __shared__ u64 S[kDtRH][kDtRW];                                 // the region's summed-area table, S[r - R0][c - C0]: <= 79 360 B, two workgroups per CU
     const int p = blockIdx.x;
@@ -591,6 +592,8 @@ __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restri
     // fit is discarded.  Such lanes (a depth above 255 * (2 hm + 1) / kernelSize, never a depth map's) are summed from the image by
     // their wave under ONE wave-uniform branch per row of output.
     const int rh1 = rh - 1;
+    bool have_whole = false;                                        // this wave has summed the WHOLE image once (what an infinite or garbage depth asks for)
+    uint32_t whole_b = 0, whole_g = 0, whole_r = 0;
 #pragma unroll
     for (int i = 0; i < NR; i++) {
         const int y = ty0 + wv * NR + i, yc = min(y, rows - 1);
@@ -617,19 +620,27 @@ __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restri
         uint32_t res = (has && local) ? fast : opx[i];              // count == 0 (:62-66): the pixel itself
         unsigned long long todo = __builtin_amdgcn_ballot_w64(has && !local);
         if (__builtin_expect(todo != 0, 0)) {                       // windows beyond the region: the wave sums them from the image, one pixel at a time
+            // (the host hears of it at its next synchronisation and sends this context's later calls to the table: rtdd_internal.hpp
+            // defocus_table_sticky -- a window costs its area here, the table a constant)
+            if (lane == 0) __hip_atomic_store(nonlocal_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t sb = 0, sg = 0, sr = 0;
             while (todo) {
                 const int L = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int wya = __builtin_amdgcn_readlane(ya, L), wyb = __builtin_amdgcn_readlane(yb, L);
                 const int wxa = __builtin_amdgcn_readlane(xa, L), wxb = __builtin_amdgcn_readlane(xb, L);
-                uint32_t tb = 0, tg = 0, tr = 0;
-                for (int r = wya; r < wyb; r++) {
-                    const uint8_t *row = orig + (size_t)r * op;
-                    for (int c = wxa + lane; c < wxb; c += 64) { tb += row[3 * (size_t)c]; tg += row[3 * (size_t)c + 1]; tr += row[3 * (size_t)c + 2]; }
-                }
+                const bool whole_image = wya == 0 && wxa == 0 && wyb == rows && wxb == cols;
+                uint32_t tb = whole_b, tg = whole_g, tr = whole_r;
+                if (!(whole_image && have_whole)) {
+                    tb = tg = tr = 0;
+                    for (int r = wya; r < wyb; r++) {
+                        const uint8_t *row = orig + (size_t)r * op;
+                        for (int c = wxa + lane; c < wxb; c += 64) { tb += row[3 * (size_t)c]; tg += row[3 * (size_t)c + 1]; tr += row[3 * (size_t)c + 2]; }
+                    }
 #pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) { tb += __shfl_xor(tb, m); tg += __shfl_xor(tg, m); tr += __shfl_xor(tr, m); }
+                    for (int m = 32; m >= 1; m >>= 1) { tb += __shfl_xor(tb, m); tg += __shfl_xor(tg, m); tr += __shfl_xor(tr, m); }
+                    if (whole_image) { have_whole = true; whole_b = tb; whole_g = tg; whole_r = tr; }
+                }
                 if (lane == L) { sb = tb; sg = tg; sr = tr; }
             }
             if (has && !local) {
@@ -690,18 +701,19 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
     const int kernelSize = 0.025 * sqrtf(rows * rows + cols * cols);    // :42, evaluated once on the host (sqrtf is correctly rounded on both)
     // small nominal windows (up to ~1080p): one launch, per-tile tables in LDS (k_defocus_tile).  RTDD_OPT_DEFOCUS_PATH: 0 automatic, 1 the
     // global table always, 2 the tile kernel wherever its region fits.
-    if (ctx->opt.defocus_path != 1 && kernelSize / 2 <= kDtHM && (size_t)rows * cols < (1ull << 32) / 255) {
+    if (ctx->opt.defocus_path != 1 && !(ctx->opt.defocus_path == 0 && ctx->defocus_table_sticky) && kernelSize / 2 <= kDtHM && (size_t)rows * cols < (1ull << 32) / 255) {
         const bool vio = (uintptr_t)orig % 4 == 0 && op % 4 == 0 && (uintptr_t)art % 4 == 0 && ap % 4 == 0;
         const int gx = (cols + kDtW - 1) / kDtW;
         const bool low = gx * ((rows + 15) / 16) <= 2 * ctx->num_cus;    // every 16-row tile resident at once
         const int th = low ? 16 : 24, gy = (rows + th - 1) / th, ntiles = gx * gy;
         const int xcd_tiles = ntiles >= 64 ? (ntiles + 7) / 8 : 0;
         const dim3 g(xcd_tiles > 0 ? 8 * xcd_tiles : ntiles);
-#define RTDD_DT_LAUNCH(V, H) hipLaunchKernelGGL((k_defocus_tile<V, H>), g, dim3(256), 0, ctx->stream, orig, op, depth, dp, art, ap, rows, cols, kernelSize, kernelSize / 2, gx, ntiles, xcd_tiles)
+#define RTDD_DT_LAUNCH(V, H) hipLaunchKernelGGL((k_defocus_tile<V, H>), g, dim3(256), 0, ctx->stream, orig, op, depth, dp, art, ap, rows, cols, kernelSize, kernelSize / 2, gx, ntiles, xcd_tiles, ctx->sync_words + kSyncNonLocal)
         if (vio) { if (low) RTDD_DT_LAUNCH(true, 16); else RTDD_DT_LAUNCH(true, 24); }
         else { if (low) RTDD_DT_LAUNCH(false, 16); else RTDD_DT_LAUNCH(false, 24); }
 #undef RTDD_DT_LAUNCH
         RTDD_LAUNCH_CHECK(ctx, "k_defocus_tile");
+        ctx->persistent_used = true;                 // (the next synchronising call reads the control words: check_persistent_status)
         return RTDD_OK;
     }
     const int tp = (cols + 3) / 4 * 4;                                  // table row pitch in entries: 32-byte aligned groups of four

@@ -24,7 +24,7 @@ namespace rtdd {
 #endif
 // kSyncFlagStride: ints between the flags of consecutive tiles.  64 = one flag per 256 bytes (its own line, and neighbouring tiles on different memory channels): a tile's flag is stored once and polled
 // by up to 8 neighbours, all through memory (sc1); packed 32 to a line (round 2) every store and poll of 32 tiles met on one line: 1080p 1.17 -> 1.24 Tpx-it/s with one line each, +1.5 % more at 256 bytes.
-constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncFlags = 32, kSyncMaxTiles = 1024, kSyncFlagStride = RTDD_FLAG_STRIDE;
+constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncNonLocal = 3 /* k_defocus_tile met windows beyond its region (effect_kernels.hip) */, kSyncFlags = 32, kSyncMaxTiles = 1024, kSyncFlagStride = RTDD_FLAG_STRIDE;
 constexpr int kSyncWords = kSyncFlags + kSyncMaxTiles * kSyncFlagStride;              // size of sync_words in ints
 constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: legitimate waits are microseconds
 

@@ -170,6 +170,25 @@ def test_defocus_out_of_range_depth_is_defined(ctx, oracle, path):
     assert np.array_equal(down(art), oracle.defocus(orig, depth, threads=min(8, oracle.max_threads())))
 
 
+def test_defocus_automatic_path_survives_a_depth_that_is_no_depth(oracle):
+    """Automatic path, a fresh context: the tile kernel meets windows beyond its region (summed by hand, flagged), the context hears of
+    it at its next synchronisation and uses the table from then on -- same bits before and after, also for a sane depth map."""
+    rows, cols = 96, 140
+    orig = _rgb(rows, cols, 31)
+    crazy = np.full((rows, cols), 3.0e5, np.float32); crazy[::3, ::2] = 2000.0
+    sane, _ = _depth(rows, cols, 59)
+    want = {id(d): oracle.defocus(orig, d, threads=min(8, oracle.max_threads())) for d in (crazy, sane)}
+    c = rt.Context(0)
+    try:
+        for depth in (crazy, crazy, sane):
+            art = up(np.zeros_like(orig))
+            c.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+            c.synchronize()
+            assert np.array_equal(down(art), want[id(depth)])
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("shape", [(1080, 1920), (853, 1280), (1440, 1754)])
 def test_defocus_tile_kernel_equals_table_at_size(ctx, oracle, shape):
     """The largest sizes the tile kernel takes (1440 x 1754: kernelSize 56, half-width 28 = its limit): every pixel equal to the table
