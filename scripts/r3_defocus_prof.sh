@@ -7,4 +7,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o df -- python3 $R/scripts/prof_defocus.py > $OUT/trace.log 2>&1 || { tail -20 $OUT/trace.log; exit 1; }
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- python3 $R/scripts/prof_defocus.py > $OUT/fetch.log 2>&1 || { tail -20 $OUT/fetch.log; exit 1; }
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- python3 $R/scripts/prof_defocus.py > $OUT/write.log 2>&1 || { tail -20 $OUT/write.log; exit 1; }
-cd $R && python3 scripts/prof_defocus_summary.py $OUT && python3 scripts/prof_defocus_counters.py $OUT
+cd $R && python3 scripts/prof_defocus_report.py $OUT
