@@ -40,6 +40,7 @@ for i in range(n):
 print("soak ok:", n, "solves (every Jacobi result == the oracle's bits),", {k: v[:12] for k, v in ref.items()}, flush=True)
 c.close(); torch.cuda.synchronize()
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from cascade_ref import Cascade                           # tests/cascade_ref.py
 bgr = np.repeat(p["gray"][..., None], 3, 2)
 ann = np.where(p["mask"] == 255, p["edited"][..., 0], 32).astype(np.uint8)
