@@ -212,8 +212,18 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
                 }
             }
         };
+        // (first / last rows at a raised wave priority, as k_sweep_blocked: sweep_tile_sweeps.inc)
+#ifndef RTDD_RB_PRIO
+#define RTDD_RB_PRIO 1
+#endif
+#if RTDD_RB_PRIO
+        __builtin_amdgcn_s_setprio(RTDD_RB_PRIO);
+#endif
         group([](int g) { return g == 0 || g == G - 1; });
         if (!last_of_block) publish(h + 1, C ^ 1);
+#if RTDD_RB_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         group([](int g) { return g != 0 && g != G - 1; });
     };
 
