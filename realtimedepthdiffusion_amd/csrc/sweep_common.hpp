@@ -1,4 +1,4 @@
-// sweep_common.hpp -- device helpers shared by the register-resident sweep kernels (sweep_blocked.hip, sweep_pk.hip): DPP lane
+// sweep_common.hpp -- device helpers of the register-resident sweep kernels (sweep_blocked.hip): DPP lane
 // shifts, the write-through store / sc1 load of the inter-workgroup hand-off, the 3-operation divide and the rounded reciprocal.
 #pragma once
 #include <hip/hip_runtime.h>
