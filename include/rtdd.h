@@ -70,7 +70,9 @@ enum rtdd_option {
     RTDD_OPT_TEMPORAL_DEPTH = 2,    /* sweeps fused per launch by the blocked kernel (0 = auto) */
     RTDD_OPT_DEFOCUS_PATH = 3,      /* rtdd_simulate_defocus: 0 (default) automatic -- one launch with per-tile summed-area tables in LDS when the largest
                                        nominal window is <= 56 pixels wide (images up to a 2280-pixel diagonal: 1080p), a global table otherwise;
-                                       1 the global table always; 2 the same as 0 (the tile kernel wherever its region fits).  Same bits either way */
+                                       1 the global table always; 2 the tile kernel wherever its region fits (0 falls back to the table for the rest of
+                                       the context's life once a call has met depths far outside [0, 255]: windows beyond a tile's region are
+                                       summed directly there, exactly but at a cost that grows with their area).  Same bits either way */
     RTDD_OPT_ROWS_PER_WAVE = 4,     /* one-sweep kernel: rows each wave walks (0 = auto) */
     RTDD_OPT_PERSISTENT = 6,        /* 1 (default): levels whose tiles all fit on the chip at once run ALL sweeps in one launch,
                                        neighbouring workgroups trading halo strips in memory (no kernel boundaries); larger levels (4K, 8K) run
