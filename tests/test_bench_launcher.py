@@ -39,6 +39,15 @@ def test_plain_launch_default_workload_is_weak():
     assert d1["n_gpus"] == 1 and d1["config"]["images_per_step"] == 1
 
 
+def test_eight_ranks_dry_run_both_scalings():
+    """What the driver's scaling run launches, minus the GPUs: eight ranks, the default (one image per rank: weak) and BASELINE
+    configs[3] (64 images dealt to 8 ranks: strong); SUM of units / MAX of time on rank 0, one JSON line."""
+    d = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"], timeout=600)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["images_per_step"] == 8 and d["config"]["images_this_rank"] == 1
+    d = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--workload", "batch64_1080p"], timeout=600)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["images_per_step"] == 64 and d["config"]["images_this_rank"] == 8
+
+
 def test_gpus_flag_must_match_world_size():
     e = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run"], env=e, capture_output=True, text=True, timeout=120)
