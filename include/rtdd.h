@@ -41,10 +41,16 @@ enum rtdd_status {
     RTDD_ERR_NOMEM = 4,
     RTDD_ERR_NO_DEVICE = 5,         /* no usable gfx950 device: there is NO CPU fallback */
     RTDD_ERR_TIMEOUT = 6            /* a persistent sweep launch gave up waiting for a neighbouring workgroup (the GPU was shared, so
-                                       its workgroups were not all resident at once).  Reported by the next call that synchronises the
-                                       stream anyway: rtdd_ctx_synchronize, rtdd_download, a residual-stopped rtdd_solve_ex.  Everything
-                                       computed since the previous synchronisation is invalid; the failed launch and the launches queued
-                                       behind it drain at once instead of spinning */
+                                       its workgroups were not all resident at once) AND running the affected calls again failed too, or a
+                                       wave gave up waiting for a wave of its own workgroup (an internal error).  A first time-out is NOT
+                                       an error (the reference's solver always leaves a valid depth map, src/GPUSolver.cu:311-314): the
+                                       failed launch and everything queued behind it drain at once, the copy-back kernels behind them store
+                                       nothing (every affected call keeps its input), and the next call that synchronises the stream anyway
+                                       -- rtdd_ctx_synchronize, rtdd_download, a residual-stopped rtdd_solve_ex -- sets RTDD_OPT_PERSISTENT
+                                       to 0 for the rest of the context's life, prints one warning on stderr, runs the solves / estimates made
+                                       since the previous synchronisation again from the failed one on (up to 4096 of them are remembered)
+                                       and returns RTDD_OK: see RTDD_OPT_TIMEOUT_HEALS.  Other work queued behind a failed solve (an effect
+                                       reading its depth map) has seen the solve's INPUT and is not run again */
 };
 
 /* Solver variants.  RTDD_METHOD_CHEBYSHEV_JACOBI is the reference's only scheme
@@ -89,6 +95,7 @@ enum rtdd_option {
     RTDD_OPT_DEBUG_POLL_LIMIT_US = 8, /* testing aid: that poll limit in microseconds (0 = the default, 200 ms) */
     RTDD_OPT_DEBUG_FORCE_STATUS = 13, /* testing aid: value (0..2) stored into the kernels' status word right behind the next temporally blocked
                                        Jacobi launch, persistent or not, as if a wave of it had given up (one shot: resets to 0) */
+    RTDD_OPT_TIMEOUT_HEALS = 14,    /* read only: how many times this context has healed a timed-out persistent launch (see RTDD_ERR_TIMEOUT) */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),
@@ -108,8 +115,9 @@ const char *rtdd_last_error(rtdd_ctx *ctx);              /* message of the last 
 const char *rtdd_status_string(int status);
 int rtdd_version(void);                                  /* major * 100 + minor.  200: rtdd_solve_info grew from 12 to 36 bytes (kernel .. launches);
                                                           * rtdd_solve_ex / rtdd_refine_depth / rtdd_last_solve_info write the whole struct, so a
-                                                          * caller compiled against a 1xx header must be rebuilt (#define RTDD_VERSION below) */
-#define RTDD_VERSION 200
+                                                          * caller compiled against a 1xx header must be rebuilt (#define RTDD_VERSION below).  210 adds
+                                                          * rtdd_pyramid_annotation_changed, RTDD_OPT_TIMEOUT_HEALS and the self-healing time-out */
+#define RTDD_VERSION 210
 
 /* ---- solver (include/GPUSolver.h:6-10) ------------------------------------------------------ */
 
@@ -243,6 +251,13 @@ int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch);
 /* annotation: DEVICE pointer to a 1-channel u8 map; decode rule of src/main.cpp:160-168 (value != 32 -> label, mask 255) */
 int rtdd_pyramid_set_annotation(rtdd_ctx *ctx, const uint8_t *annotation, size_t pitch);
 int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *pitch, int *rows, int *cols);
+/* The coarse annotation levels (GPUPyrDownAnnotation, src/main.cpp:249-253) and the coarsest level's injection (:257-259) are brought up
+ * to date by the first rtdd_estimate_depth after the annotation changed, not by every estimate (they depend on nothing else, the
+ * down-sampling only ever adds and the solver never moves a Dirichlet pixel: same images, same bits).  Every entry point of this
+ * library that writes RTDD_IMG_SCRIBBLE / RTDD_IMG_EDITED (set_image, set_annotation, rtdd_paint_image, rtdd_pyrdown_annotation,
+ * rtdd_upload) notes the change itself; a caller that writes those images, or the coarsest RTDD_IMG_DEPTH, through the raw
+ * pointers by other means says so with this call. */
+int rtdd_pyramid_annotation_changed(rtdd_ctx *ctx);
 /* src/main.cpp:239-291; asynchronous; results in RTDD_IMG_DEPTH (all levels) and RTDD_IMG_DEPTH_U8 */
 int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations);
 /* Extension: one more solve of the finest level, in place on RTDD_IMG_DEPTH level 0, by rtdd_solve_ex with `params`

@@ -35,3 +35,10 @@ void GPUSimulateDesaturation(unsigned char *originalImage, size_t originalPitch,
                              int cols);
 void GPUSimulateHaze(unsigned char *originalImage, size_t originalPitch, float *depthImage, size_t depthPitch,
                      unsigned char *artisticImage, size_t artisticPitch, int rows, int cols);
+
+// Not part of the reference: the process-global context the ten functions above run on (created on first use), for a host that
+// wants to set an option (rtdd_set_option: RTDD_OPT_FP_CONTRACT ...) or read a counter (RTDD_OPT_TIMEOUT_HEALS) on it.  The
+// unchanged main.cpp never needs it: a persistent launch that times out on a shared GPU is healed inside GPUMatrixFreeSolver
+// (include/rtdd.h, RTDD_ERR_TIMEOUT), which -- like the reference's (src/GPUSolver.cu:311-314) -- always returns with a valid depth map.
+struct rtdd_ctx;
+extern "C" rtdd_ctx *rtdd_dropin_context(void);

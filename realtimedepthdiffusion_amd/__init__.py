@@ -29,6 +29,7 @@ OPT_FP_CONTRACT, OPT_SWEEP_KERNEL, OPT_TEMPORAL_DEPTH, OPT_DEFOCUS_PATH, OPT_ROW
 OPT_DEBUG_WITHHOLD_TILE, OPT_DEBUG_POLL_LIMIT_US = 7, 8
 OPT_AUTO_CYCLE_FIXED_NS, OPT_AUTO_CYCLE_FS_PER_PX, OPT_AUTO_SWEEP_FS_PER_PX, OPT_AUTO_SWEEP_FLOOR_NS = 9, 10, 11, 12
 OPT_DEBUG_FORCE_STATUS = 13
+OPT_TIMEOUT_HEALS = 14                     # read only
 RTDD_ERR_TIMEOUT = 6
 
 # every symbol include/rtdd.h declares (checked by tests/test_abi.py against the header)
@@ -39,7 +40,7 @@ C_ABI_SYMBOLS = [
     "rtdd_pyrdown_annotation", "rtdd_paint_image", "rtdd_simulate_defocus", "rtdd_simulate_desaturation",
     "rtdd_simulate_haze", "rtdd_profile_enable", "rtdd_profile_get",
     "rtdd_pyramid_levels", "rtdd_pyramid_create", "rtdd_pyramid_destroy", "rtdd_pyramid_set_image",
-    "rtdd_pyramid_set_annotation", "rtdd_pyramid_image", "rtdd_estimate_depth", "rtdd_refine_depth", "rtdd_bgr2gray", "rtdd_pyrdown_gray",
+    "rtdd_pyramid_set_annotation", "rtdd_pyramid_image", "rtdd_pyramid_annotation_changed", "rtdd_estimate_depth", "rtdd_refine_depth", "rtdd_bgr2gray", "rtdd_pyrdown_gray",
     "rtdd_pyrup_depth", "rtdd_depth_to_u8", "rtdd_upload", "rtdd_download",
 ]
 IMG_ORIGINAL, IMG_GRAY, IMG_SCRIBBLE, IMG_EDITED, IMG_DEPTH, IMG_DEPTH_U8, IMG_ARTISTIC = range(7)
@@ -279,6 +280,9 @@ class Context:
     def pyramid_set_annotation(self, annotation):
         p, pitch = _img(annotation)
         self._check(lib().rtdd_pyramid_set_annotation(self._h, p, pitch))
+
+    def pyramid_annotation_changed(self):
+        self._check(lib().rtdd_pyramid_annotation_changed(self._h))
 
     def pyramid_image(self, kind, level=0):
         """(ptr, pitch_bytes, rows, cols) of a context-owned pyramid image."""

@@ -57,24 +57,95 @@ int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
     return RTDD_OK;
 }
 
+// ---- self-healing ---------------------------------------------------------------------------------------------------------------
+// The reference's GPUMatrixFreeSolver always leaves a valid depth map behind (src/GPUSolver.cu:311-314), and an unchanged main.cpp can
+// neither set options nor upload its input again.  A persistent launch that is not fully co-resident (a shared GPU) gives up after its
+// poll limit and sets the status word; from then on k_finish / k_pyrup_inject store nothing (persist_sync.hpp solve_is_dead), so every
+// call made since keeps its INPUT, and the first of them has left its sequence number in sync_words[kSyncFailedSeq].  The next call that
+// synchronises finds the word, switches persistence off for the rest of the context's life (one warning on stderr), runs the logged
+// calls again from the failed one on, one launch per block of sweeps, and only then returns -- RTDD_OK, with the results the calls
+// would have produced.  Status 2 (a wave waiting for a wave of its own workgroup: a protocol bug, not a scheduling accident) and a
+// second failure during the replay are reported as RTDD_ERR_TIMEOUT as before.
+static int replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
+    const Options now = ctx->opt;
+    ctx->opt = op.opt;
+    ctx->opt.persistent = 0; ctx->opt.debug_force_status = 0;
+    int rc = RTDD_OK;
+    if (op.kind == PendingOp::kSolve) {
+        uint8_t *u8 = ctx->finish_u8; const size_t u8p = ctx->finish_u8_pitch;
+        ctx->finish_u8 = op.finish_u8; ctx->finish_u8_pitch = op.finish_u8_pitch;
+        rc = rtdd_solve_ex(ctx, op.depth, op.depthPitch, op.scribble, op.scribblePitch, op.gray, op.grayPitch, op.rows, op.cols, op.level, &op.params, nullptr);
+        ctx->finish_u8 = u8; ctx->finish_u8_pitch = u8p;
+    } else {
+        int from = -1;                                  // the level whose solve gave up; an estimate queued behind the failed call: every level
+        for (int l = 0; l < 32; l++) if (op.level_seq[l] != 0 && op.level_seq[l] == failed_seq) from = l;
+        if (from < 0) for (int l = 31; l >= 0 && from < 0; l--) if (op.level_seq[l] != 0) from = l;
+        if (from >= 0) rc = estimate_levels(ctx, op.maxIterations, from, nullptr);
+    }
+    ctx->opt = now;
+    return rc;
+}
+
+static bool op_holds(const PendingOp &op, int seq) {
+    if (op.kind == PendingOp::kSolve) return op.seq == seq;
+    for (int l = 0; l < 32; l++) if (op.level_seq[l] != 0 && op.level_seq[l] == seq) return true;
+    return false;
+}
+
+static const char *kTimeoutText = "persistent sweep kernel: a workgroup timed out waiting for a neighbouring tile (its workgroups were not all "
+                                  "co-resident: is the GPU shared?)";
+
 // The stream has just been synchronised by the caller.  A blocked-sweep launch since the last check may have given up (persist_sync.hpp).
-int check_persistent_status(rtdd_ctx *ctx) {
-    if (!ctx->persistent_used || !ctx->sync_words) return RTDD_OK;
-    int words[4] = {0, 0, 0, 0};
+int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
+    if (!ctx->persistent_used || !ctx->sync_words) { if (!ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } return RTDD_OK; }
+    int words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RTDD_HIP(ctx, hipMemcpy(words, ctx->sync_words, sizeof(words), hipMemcpyDeviceToHost));
     ctx->persistent_used = false;
-    const int status = words[kSyncStatus];
+    const int status = words[kSyncStatus], failed_seq = words[kSyncFailedSeq];
     if (words[kSyncNonLocal] != 0) {               // the tile defocus kernel summed windows by hand: not a depth map -- the table path from now on
         ctx->defocus_table_sticky = true;
         RTDD_HIP(ctx, hipMemset(ctx->sync_words + kSyncNonLocal, 0, sizeof(int)));
     }
-    if (status == 0) return RTDD_OK;
+    if (status == 0) { if (!ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } return RTDD_OK; }
     RTDD_HIP(ctx, hipMemset(ctx->sync_words + kSyncStatus, 0, sizeof(int)));
-    return fail(ctx, RTDD_ERR_TIMEOUT, status == 1 ? "persistent sweep kernel: a workgroup timed out waiting for a neighbouring tile (its workgroups were not all "
-                                                     "co-resident: is the GPU shared?); the results since the last synchronisation are invalid; "
-                                                     "set RTDD_OPT_PERSISTENT to 0 when the GPU is shared"
-                                                   : "blocked sweep kernel: a wave timed out waiting for a neighbouring wave of its own workgroup (internal error); "
-                                                     "the results since the last synchronisation are invalid");
+    RTDD_HIP(ctx, hipMemset(ctx->sync_words + kSyncFailedSeq, 0, sizeof(int)));
+    if (status != 1) {
+        ctx->pending.clear(); ctx->pending_overflow = false;
+        return fail(ctx, RTDD_ERR_TIMEOUT, "blocked sweep kernel: a wave timed out waiting for a neighbouring wave of its own workgroup (internal error); "
+                                           "the results since the last synchronisation are invalid");
+    }
+    if (ctx->healing || ctx->pending_overflow) {
+        std::string msg = kTimeoutText;
+        msg += ctx->healing ? "; it happened again while the calls were being run again without persistence" : "; too many calls were queued without a synchronisation to run them again";
+        msg += "; the results since the last synchronisation are invalid";
+        ctx->pending.clear(); ctx->pending_overflow = false;
+        return fail(ctx, RTDD_ERR_TIMEOUT, msg.c_str());
+    }
+    // heal: persistence off from now on, the logged calls again from the first failed one
+    ctx->opt.persistent = 0;
+    ctx->heals++;
+    if (!ctx->heal_warned) {
+        ctx->heal_warned = true;
+        std::fprintf(stderr, "rtdd: %s; running the affected calls again one launch per block of sweeps -- RTDD_OPT_PERSISTENT is 0 for this context from now on\n", kTimeoutText);
+    }
+    std::vector<PendingOp> ops;
+    ops.swap(ctx->pending);
+    size_t first = ops.size();                      // failed_seq == 0: every logged call had published its result before the word was set
+    if (failed_seq != 0) {
+        for (size_t i = 0; i < ops.size(); i++) if (op_holds(ops[i], failed_seq)) { first = i; break; }
+        if (first == ops.size()) return fail(ctx, RTDD_ERR_TIMEOUT, "persistent sweep kernel timed out and the failed call is not among the logged ones; the results since the last synchronisation are invalid");
+    }
+    ctx->healing = true;
+    int rc = RTDD_OK;
+    for (size_t i = first; i < ops.size() && rc == RTDD_OK; i++) rc = replay(ctx, ops[i], i == first ? failed_seq : 0);
+    if (rc == RTDD_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, RTDD_ERR_HIP, "hipStreamSynchronize (replay)", e);
+        else { ctx->persistent_used = true; rc = check_persistent_status(ctx); }
+    }
+    ctx->healing = false;
+    if (rc != RTDD_OK) return rc;
+    return in_solve ? kRestartSolve : RTDD_OK;
 }
 
 static void free_levels(rtdd_ctx *ctx) {
@@ -164,8 +235,7 @@ int rtdd_ctx_synchronize(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     DeviceGuard g(ctx->device);
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    { const int rc = check_persistent_status(ctx); if (rc != RTDD_OK) return rc; }
-    return RTDD_OK;
+    return check_persistent_status(ctx);           // (a timed-out persistent launch is healed here: the affected calls run again, api.cpp above)
 }
 
 int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
@@ -207,6 +277,7 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_DEBUG_WITHHOLD_TILE: *value = ctx->opt.debug_withhold_tile; break;
         case RTDD_OPT_DEBUG_POLL_LIMIT_US: *value = ctx->opt.debug_poll_limit_us; break;
         case RTDD_OPT_DEBUG_FORCE_STATUS: *value = ctx->opt.debug_force_status; break;
+        case RTDD_OPT_TIMEOUT_HEALS: *value = ctx->heals; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;
@@ -451,27 +522,16 @@ struct Solve {
 
 }  // namespace
 
-int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
-                  const uint8_t *gray, size_t grayPitch, int rows, int cols, int level,
-                  const rtdd_solve_params *params, rtdd_solve_info *info) {
-    if (!ctx) return RTDD_ERR_INVALID;
-    REQUIRE(ctx, params != nullptr, "null params");
-    REQUIRE(ctx, params->maxIterations >= 0, "maxIterations must be >= 0");
-    REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS || params->method == RTDD_METHOD_MULTIGRID ||
-                 params->method == RTDD_METHOD_AUTO, "unknown method");
-    REQUIRE(ctx, params->method != RTDD_METHOD_AUTO || params->tolerance > 0.0f, "RTDD_METHOD_AUTO needs a tolerance");
-    REQUIRE(ctx, params->method != RTDD_METHOD_RED_BLACK_GS || params->relaxation == RTDD_RELAXATION_AUTO || (params->relaxation >= 0.0f && params->relaxation < 2.0f),
-            "relaxation must be in [0,2) or RTDD_RELAXATION_AUTO");
-    int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
-    if (rc != RTDD_OK) return rc;
-    DeviceGuard g(ctx->device);
+// one attempt: stage + edge weights, the sweeps, the (guarded) copy-back
+static int solve_once(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
+                      const uint8_t *gray, size_t grayPitch, int rows, int cols, int level, const rtdd_solve_params *params, int seq) {
     const Level &L = ctx->levels[level];
     const size_t ip = plane_pitch(cols);
     const bool prof = ctx->profile_on;
     hipEvent_t *ev = ctx->ev + 4 * (ctx->prof_pending % rtdd_ctx::kProfSlots);
 
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
-    rc = launch_prepare(ctx, L, ip, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
+    int rc = launch_prepare(ctx, L, ip, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
     if (rc != RTDD_OK) return rc;
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
 
@@ -491,6 +551,7 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
 
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
     ctx->deferred_plane = s.pk;
+    ctx->guard_seq = seq;                           // (a deferred copy-back is k_pyrup_inject's: cascade_api.cpp hands it the same number)
     if (!ctx->defer_finish) {
         rc = launch_finish(ctx, L, ip, s.pk, depth, depthPitch, rows, cols, ctx->finish_u8, ctx->finish_u8_pitch);
         if (rc != RTDD_OK) return rc;
@@ -503,6 +564,42 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     }
     ctx->last_info.iterations = s.done; ctx->last_info.residual = s.residual; ctx->last_info.cycles = s.cycles;
     ctx->last_info.fp_contract = ctx->opt.fp_contract; ctx->last_info.launches = s.launches;
+    return RTDD_OK;
+}
+
+int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
+                  const uint8_t *gray, size_t grayPitch, int rows, int cols, int level,
+                  const rtdd_solve_params *params, rtdd_solve_info *info) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    REQUIRE(ctx, params != nullptr, "null params");
+    REQUIRE(ctx, params->maxIterations >= 0, "maxIterations must be >= 0");
+    REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS || params->method == RTDD_METHOD_MULTIGRID ||
+                 params->method == RTDD_METHOD_AUTO, "unknown method");
+    REQUIRE(ctx, params->method != RTDD_METHOD_AUTO || params->tolerance > 0.0f, "RTDD_METHOD_AUTO needs a tolerance");
+    REQUIRE(ctx, params->method != RTDD_METHOD_RED_BLACK_GS || params->relaxation == RTDD_RELAXATION_AUTO || (params->relaxation >= 0.0f && params->relaxation < 2.0f),
+            "relaxation must be in [0,2) or RTDD_RELAXATION_AUTO");
+    int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
+    if (rc != RTDD_OK) return rc;
+    DeviceGuard g(ctx->device);
+    ctx->solve_seq = ctx->solve_seq >= (1 << 30) ? 1 : ctx->solve_seq + 1;
+    const int seq = ctx->solve_seq;
+    const Options asked = ctx->opt;
+    rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq);
+    // A residual check inside the solve found the status word set, and the calls before this one have been healed (check_persistent_status):
+    // nothing of this solve has reached the caller's buffers (its copy-back is the last thing it does), so it simply starts over --
+    // persistence is off by now.
+    if (rc == kRestartSolve) rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq);
+    if (rc == kRestartSolve) rc = fail(ctx, RTDD_ERR_TIMEOUT, "the solve was restarted after a timed-out persistent launch and failed again");
+    if (rc != RTDD_OK) return rc;
+    if (!ctx->healing && !ctx->in_estimate) {       // remembered until the next synchronising call has seen the status word clear
+        if (ctx->pending.size() >= kMaxPendingOps) { ctx->pending.clear(); ctx->pending_overflow = true; }
+        PendingOp op;
+        op.kind = PendingOp::kSolve; op.opt = asked; op.seq = seq;
+        op.depth = depth; op.depthPitch = depthPitch; op.scribble = scribble; op.scribblePitch = scribblePitch; op.gray = gray; op.grayPitch = grayPitch;
+        op.rows = rows; op.cols = cols; op.level = level; op.params = *params;
+        op.finish_u8 = ctx->finish_u8; op.finish_u8_pitch = ctx->finish_u8_pitch;
+        ctx->pending.push_back(op);
+    }
     if (info) *info = ctx->last_info;
     return RTDD_OK;
 }
@@ -566,6 +663,7 @@ int rtdd_pyrdown_annotation(rtdd_ctx *ctx, const uint8_t *prevScribble, size_t p
     REQUIRE(ctx, prevScribblePitch >= (size_t)previousCols && prevEditedPitch >= (size_t)previousCols * 3 &&
                  currScribblePitch >= (size_t)currentCols && currEditedPitch >= (size_t)currentCols * 3, "pitch smaller than a row");
     DeviceGuard g(ctx->device);
+    pyramid_note_write(ctx, currScribble, currEdited);
     return launch_pyrdown_annotation(ctx, prevScribble, prevScribblePitch, prevEdited, prevEditedPitch, previousRows, previousCols,
                                      currScribble, currScribblePitch, currEdited, currEditedPitch, currentRows, currentCols);
 }
@@ -578,6 +676,7 @@ int rtdd_paint_image(rtdd_ctx *ctx, int x, int y, int scribbleColor, int scribbl
     if (rows == 0 || cols == 0) return RTDD_OK;
     REQUIRE(ctx, editedPitch >= (size_t)cols * 3 && scribblePitch >= (size_t)cols, "pitch smaller than a row");
     DeviceGuard g(ctx->device);
+    pyramid_note_write(ctx, scribble, edited);
     return launch_paint(ctx, x, y, scribbleColor, scribbleRadius, edited, editedPitch, scribble, scribblePitch, rows, cols);
 }
 

@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include "rtdd_internal.hpp"
+#include "persist_sync.hpp"
 
 namespace rtdd {
 
@@ -89,8 +90,9 @@ __global__ __launch_bounds__(256) void k_pyrup_inject(const float *__restrict__ 
                                                       float *__restrict__ dst, size_t dp, int drows, int dcols,
                                                       const uint8_t *__restrict__ edited, size_t ep,
                                                       const uint8_t *__restrict__ mask, size_t mp,
-                                                      float *__restrict__ coarse_out, size_t cp) {
+                                                      float *__restrict__ coarse_out, size_t cp, int *sync_words, int seq) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;    // (persist_sync.hpp: the coarse solve gave up)
     if (x >= dcols || y >= drows) return;
     // the estimate driver reads the coarse level straight from the solver's plane; the caller-visible coarse depth image (the
     // solver's copy-back, src/GPUSolver.cu:311-312) is written here on the side: fine pixel (2c, 2r) stores coarse pixel (c, r)
@@ -167,10 +169,12 @@ int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, in
     return RTDD_OK;
 }
 int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
-                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out, size_t cp) {
+                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out, size_t cp, bool guarded) {
+    int *sw = guarded ? ctx->sync_words : nullptr;
+    const int seq = ctx->guard_seq;
     if (coarse_out && (drows < 2 * rows || dcols < 2 * cols)) return fail(ctx, RTDD_ERR_INVALID, "pyrUp: the fine level must be at least twice the coarse one");
-    if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject<true>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp);
-    else hipLaunchKernelGGL(k_pyrup_inject<false>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp);
+    if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject<true>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
+    else hipLaunchKernelGGL(k_pyrup_inject<false>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
     RTDD_LAUNCH_CHECK(ctx, "k_pyrup_inject");
     return RTDD_OK;
 }

@@ -17,7 +17,23 @@ struct Pyramid {
     int levels = 0, rows = 0, cols = 0;
     Image original, depth_u8, artistic;
     std::vector<Image> gray, scribble, edited, depth;
+    // The coarse annotation levels and the coarsest level's injection depend on the annotation only (src/main.cpp:249-259;
+    // GPUPyrDownAnnotation only ever adds, SURVEY A.8, and the solver never moves a Dirichlet pixel): they are brought up to date
+    // by the first estimate after the annotation changed, not by every estimate.
+    bool annotation_dirty = true;
 };
+
+static bool inside(const Image &im, const void *p) {
+    return im.ptr && (const char *)p >= (const char *)im.ptr && (const char *)p < (const char *)im.ptr + im.pitch * (size_t)(im.rows > 0 ? im.rows : 1);
+}
+
+// called by the entry points that write an annotation image: is it one of this context's pyramid?
+void pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited) {
+    Pyramid *p = ctx->pyr;
+    if (!p) return;
+    for (int l = 0; l < p->levels; l++)
+        if (inside(p->scribble[l], scribble) || inside(p->edited[l], edited) || inside(p->scribble[l], edited) || inside(p->edited[l], scribble)) p->annotation_dirty = true;
+}
 
 static int alloc_image(rtdd_ctx *ctx, Image &im, int rows, int cols, int elem, int fill) {
     im.rows = rows; im.cols = cols; im.elem = elem;
@@ -106,6 +122,7 @@ int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch) {
     // A new image is a new problem (the reference loads one image per process, src/main.cpp:93): everything an estimate carries
     // over to the next one -- the depth pyramid it warm-starts from (:136) and the coarse annotation levels, which
     // GPUPyrDownAnnotation only ever adds to -- goes back to its initial state.
+    p->annotation_dirty = true;
     for (int l = 0; l < p->levels; l++) {
         if (p->scribble[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->scribble[l].ptr, 0, p->scribble[l].pitch * p->scribble[l].rows, ctx->stream));
         if (l > 0 && p->edited[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->edited[l].ptr, 0, p->edited[l].pitch * p->edited[l].rows, ctx->stream));
@@ -128,6 +145,7 @@ int rtdd_pyramid_set_annotation(rtdd_ctx *ctx, const uint8_t *annotation, size_t
     Pyramid *p = ctx->pyr;
     REQUIRE(ctx, annotation && pitch >= (size_t)p->cols, "bad annotation");
     DeviceGuard g(ctx->device);
+    p->annotation_dirty = true;
     return launch_decode_annotation(ctx, (const uint8_t *)p->original.ptr, p->original.pitch, annotation, pitch,
                                     (uint8_t *)p->edited[0].ptr, p->edited[0].pitch, (uint8_t *)p->scribble[0].ptr, p->scribble[0].pitch, p->rows, p->cols);
 }
@@ -156,6 +174,13 @@ int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *p
     return RTDD_OK;
 }
 
+int rtdd_pyramid_annotation_changed(rtdd_ctx *ctx) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
+    ctx->pyr->annotation_dirty = true;
+    return RTDD_OK;
+}
+
 int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
     if (!ctx) return RTDD_ERR_INVALID;
     if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
@@ -163,15 +188,42 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
     Pyramid *p = ctx->pyr;
     const int P = p->levels;
     int rc = RTDD_OK;
-    for (int l = 1; l < P && rc == RTDD_OK; l++)                               // src/main.cpp:249-253
-        rc = rtdd_pyrdown_annotation(ctx, (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch,
-                                     (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch, p->edited[l - 1].rows, p->edited[l - 1].cols,
-                                     (uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch, (uint8_t *)p->edited[l].ptr, p->edited[l].pitch,
-                                     p->edited[l].rows, p->edited[l].cols);
-    if (rc != RTDD_OK) return rc;
-    rc = rtdd_convert_to_float(ctx, (const uint8_t *)p->edited[P - 1].ptr, p->edited[P - 1].pitch, (float *)p->depth[P - 1].ptr, p->depth[P - 1].pitch,
-                               (const uint8_t *)p->scribble[P - 1].ptr, p->scribble[P - 1].pitch, p->edited[P - 1].rows, p->edited[P - 1].cols);   // :257-259
-    for (int l = P - 1; l >= 0 && rc == RTDD_OK; l--) {                        // :261-288
+    if (p->annotation_dirty) {
+        for (int l = 1; l < P && rc == RTDD_OK; l++)                           // src/main.cpp:249-253
+            rc = rtdd_pyrdown_annotation(ctx, (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch,
+                                         (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch, p->edited[l - 1].rows, p->edited[l - 1].cols,
+                                         (uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch, (uint8_t *)p->edited[l].ptr, p->edited[l].pitch,
+                                         p->edited[l].rows, p->edited[l].cols);
+        if (rc != RTDD_OK) return rc;
+        rc = rtdd_convert_to_float(ctx, (const uint8_t *)p->edited[P - 1].ptr, p->edited[P - 1].pitch, (float *)p->depth[P - 1].ptr, p->depth[P - 1].pitch,
+                                   (const uint8_t *)p->scribble[P - 1].ptr, p->scribble[P - 1].pitch, p->edited[P - 1].rows, p->edited[P - 1].cols);   // :257-259
+        if (rc != RTDD_OK) return rc;
+        p->annotation_dirty = false;                                           // (the two calls above marked it themselves: they write pyramid images)
+    }
+    PendingOp op;
+    op.kind = PendingOp::kEstimate; op.opt = ctx->opt; op.maxIterations = maxIterations;
+    rc = estimate_levels(ctx, maxIterations, P - 1, op.level_seq);
+    if (rc == RTDD_OK && !ctx->healing) {
+        if (ctx->pending.size() >= kMaxPendingOps) { ctx->pending.clear(); ctx->pending_overflow = true; }
+        ctx->pending.push_back(op);
+    }
+    return rc;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop
+
+namespace rtdd {
+
+int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq) {
+    Pyramid *p = ctx->pyr;
+    if (!p) return fail(ctx, RTDD_ERR_STATE, "the pyramid is gone");
+    const int P = p->levels;
+    if (from_level > P - 1) from_level = P - 1;
+    int rc = RTDD_OK;
+    const bool was_in = ctx->in_estimate;
+    ctx->in_estimate = true;
+    for (int l = from_level; l >= 0 && rc == RTDD_OK; l--) {                   // src/main.cpp:261-288
         const int iters = (int)(maxIterations / powf(2.0, (P - 1) - l));       // :263
         const bool solved = p->depth[l].rows > 0 && p->depth[l].cols > 0;
         // Two launches less per level than the calls spelt out: above the finest level the solver's copy-back is left to the pyrUp
@@ -179,9 +231,11 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
         // writes the u8 map (:290).  Same values in the same buffers (tests/test_gpu_cascade.py compares every level's image).
         ctx->defer_finish = solved && l > 0;
         ctx->finish_u8 = l == 0 ? (uint8_t *)p->depth_u8.ptr : nullptr; ctx->finish_u8_pitch = p->depth_u8.pitch;
-        if (solved)
+        if (solved) {
             rc = rtdd_matrix_free_solver(ctx, (float *)p->depth[l].ptr, p->depth[l].pitch, (const uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch,
                                          (const uint8_t *)p->gray[l].ptr, p->gray[l].pitch, p->depth[l].rows, p->depth[l].cols, 0.4f, iters, 1e-5f, l);
+            if (level_seq && l < 32) level_seq[l] = ctx->solve_seq;
+        }
         const bool deferred = ctx->defer_finish;
         ctx->defer_finish = false; ctx->finish_u8 = nullptr;
         if (rc == RTDD_OK && l > 0) {
@@ -193,27 +247,36 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
                 src = ctx->levels[l].P(ctx->deferred_plane, ip); sp = ip * sizeof(float);
                 coarse_out = (float *)p->depth[l].ptr;
             }
+            // guarded like k_finish: when level l's sweeps gave up it stores nothing, depth[l] keeps level l's input and the level can be run again
             rc = launch_pyrup_inject(ctx, src, sp, p->depth[l].rows, p->depth[l].cols,
                                      (float *)p->depth[l - 1].ptr, p->depth[l - 1].pitch, p->depth[l - 1].rows, p->depth[l - 1].cols,
                                      (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch,
-                                     (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch, coarse_out, p->depth[l].pitch);     // :272-283
+                                     (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch, coarse_out, p->depth[l].pitch, /*guarded=*/solved);     // :272-283
         }
     }
+    ctx->in_estimate = was_in;
     if (rc != RTDD_OK) return rc;
     if (p->depth[0].rows > 0 && p->depth[0].cols > 0) return RTDD_OK;         // the u8 map left the solver's copy-back (above)
     DeviceGuard g(ctx->device);
     return launch_depth_to_u8(ctx, (const float *)p->depth[0].ptr, p->depth[0].pitch, (uint8_t *)p->depth_u8.ptr, p->depth_u8.pitch, p->rows, p->cols);   // :290
 }
 
+}  // namespace rtdd
+
+#pragma GCC visibility push(default)
+extern "C" {
+
 int rtdd_refine_depth(rtdd_ctx *ctx, const rtdd_solve_params *params, rtdd_solve_info *info) {
     if (!ctx) return RTDD_ERR_INVALID;
     if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
     Pyramid *p = ctx->pyr;
-    int rc = rtdd_solve_ex(ctx, (float *)p->depth[0].ptr, p->depth[0].pitch, (const uint8_t *)p->scribble[0].ptr, p->scribble[0].pitch,
-                           (const uint8_t *)p->gray[0].ptr, p->gray[0].pitch, p->rows, p->cols, 0, params, info);
-    if (rc != RTDD_OK) return rc;
-    DeviceGuard g(ctx->device);
-    return launch_depth_to_u8(ctx, (const float *)p->depth[0].ptr, p->depth[0].pitch, (uint8_t *)p->depth_u8.ptr, p->depth_u8.pitch, p->rows, p->cols);
+    // the u8 map is written by the solve's own copy-back (k_finish: the same rounding as k_depth_to_u8), so that a solve that has to be
+    // run again after a timed-out persistent launch brings the map with it
+    ctx->finish_u8 = (uint8_t *)p->depth_u8.ptr; ctx->finish_u8_pitch = p->depth_u8.pitch;
+    const int rc = rtdd_solve_ex(ctx, (float *)p->depth[0].ptr, p->depth[0].pitch, (const uint8_t *)p->scribble[0].ptr, p->scribble[0].pitch,
+                                 (const uint8_t *)p->gray[0].ptr, p->gray[0].pitch, p->rows, p->cols, 0, params, info);
+    ctx->finish_u8 = nullptr;
+    return rc;
 }
 
 int rtdd_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bgrPitch, uint8_t *gray, size_t grayPitch, int rows, int cols) {
@@ -248,6 +311,7 @@ int rtdd_upload(rtdd_ctx *ctx, void *dev, size_t devPitch, const void *host, siz
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, dev && host && rows >= 0 && devPitch >= widthBytes && hostPitch >= widthBytes, "bad argument");
     DeviceGuard g(ctx->device);
+    pyramid_note_write(ctx, dev, dev);
     RTDD_HIP(ctx, hipMemcpy2DAsync(dev, devPitch, host, hostPitch, widthBytes, rows, hipMemcpyHostToDevice, ctx->stream));
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTDD_OK;
@@ -259,7 +323,12 @@ int rtdd_download(rtdd_ctx *ctx, void *host, size_t hostPitch, const void *dev, 
     DeviceGuard g(ctx->device);
     RTDD_HIP(ctx, hipMemcpy2DAsync(host, hostPitch, dev, devPitch, widthBytes, rows, hipMemcpyDeviceToHost, ctx->stream));
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return check_persistent_status(ctx);        // what was just downloaded may come from a persistent launch that gave up
+    const int heals = ctx->heals;
+    const int rc = check_persistent_status(ctx);  // what was just downloaded may come from a persistent launch that gave up ...
+    if (rc != RTDD_OK || ctx->heals == heals) return rc;
+    RTDD_HIP(ctx, hipMemcpy2DAsync(host, hostPitch, dev, devPitch, widthBytes, rows, hipMemcpyDeviceToHost, ctx->stream));   // ... and has been run again since
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTDD_OK;
 }
 
 }  // extern "C"

@@ -32,6 +32,8 @@ void sync(const char *who) { report(who, rtdd_ctx_synchronize(g_ctx)); }
 
 }  // namespace
 
+extern "C" RTDD_EXPORT rtdd_ctx *rtdd_dropin_context(void) { return ctx("rtdd_dropin_context"); }
+
 RTDD_EXPORT void GPUAllocateDeviceMemory(int rows, int cols, int levels) {
     if (!ctx("GPUAllocateDeviceMemory")) return;
     report("GPUAllocateDeviceMemory", rtdd_allocate(g_ctx, rows, cols, levels));
@@ -54,7 +56,9 @@ RTDD_EXPORT void GPUMatrixFreeSolver(float *depthImage, size_t depthPitch, unsig
     if (!ctx("GPUMatrixFreeSolver")) return;
     report("GPUMatrixFreeSolver", rtdd_matrix_free_solver(g_ctx, depthImage, depthPitch, scribbleImage, scribblePitch, grayImage,
                                                           grayPitch, rows, cols, beta, maxIterations, tolerance, level));
-    sync("GPUMatrixFreeSolver");                    // src/GPUSolver.cu:314
+    // src/GPUSolver.cu:314.  A persistent launch that timed out (shared GPU) is healed in here: the solve has run again, one launch per
+    // block of sweeps, by the time this returns (api.cpp check_persistent_status) -- the caller's depth map is valid either way
+    sync("GPUMatrixFreeSolver");
 }
 
 RTDD_EXPORT void GPUConvertToFloat(unsigned char *src, size_t srcPitch, float *dst, size_t dstPitch, unsigned char *mask,

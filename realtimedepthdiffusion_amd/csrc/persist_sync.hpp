@@ -12,6 +12,8 @@
 //   [kSyncWithhold]  debug (RTDD_OPT_DEBUG_WITHHOLD_TILE): tile number + 1 whose flag is never published (0 = off), to make the
 //                    timeout path testable.
 //   [kSyncLimit]     poll limit in 10 ns ticks of s_memrealtime (0 = kDefaultPollLimit).
+//   [kSyncFailedSeq] sequence number of the first solve whose copy-back kernel (k_finish / k_pyrup_inject) found the status word set and
+//                    therefore stored nothing: the host re-runs the pending calls from that one on (api.cpp heal_pending).  0 = none.
 //   [kSyncFlags ..]  one block counter per tile.  Monotonic over the life of the context: launch L's workgroups publish base_L + block
 //                    number, base_L handed in by the host (api.cpp prepare_persistent_launch), so nothing is zeroed between launches.
 #pragma once
@@ -24,11 +26,22 @@ namespace rtdd {
 #endif
 // kSyncFlagStride: ints between the flags of consecutive tiles.  64 = one flag per 256 bytes (its own line, and neighbouring tiles on different memory channels): a tile's flag is stored once and polled
 // by up to 8 neighbours, all through memory (sc1); packed 32 to a line (round 2) every store and poll of 32 tiles met on one line: 1080p 1.17 -> 1.24 Tpx-it/s with one line each, +1.5 % more at 256 bytes.
-constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncNonLocal = 3 /* k_defocus_tile met windows beyond its region (effect_kernels.hip) */, kSyncFlags = 32, kSyncMaxTiles = 1024, kSyncFlagStride = RTDD_FLAG_STRIDE;
+constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncNonLocal = 3 /* k_defocus_tile met windows beyond its region (effect_kernels.hip) */, kSyncFailedSeq = 4, kSyncFlags = 32, kSyncMaxTiles = 1024, kSyncFlagStride = RTDD_FLAG_STRIDE;
 constexpr int kSyncWords = kSyncFlags + kSyncMaxTiles * kSyncFlagStride;              // size of sync_words in ints
 constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: legitimate waits are microseconds
 
 #ifdef __HIPCC__
+// The kernels that publish a solve's result into the caller's buffers call this first (every thread; `first` = one thread of the
+// grid): true = a sweep launch in front of them gave up, store nothing.  The reference's solver always leaves a valid depth map
+// (src/GPUSolver.cu:311-314); here a failed solve leaves its INPUT in place so that the host can run it again.
+__device__ __forceinline__ bool solve_is_dead(int *sync_words, int seq, bool first) {
+    if (!sync_words) return false;
+    if (__hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return false;
+    if (first && __hip_atomic_load(&sync_words[kSyncFailedSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __hip_atomic_store(&sync_words[kSyncFailedSeq], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // Called by EVERY thread of the workgroup after its payload stores are drained (s_waitcnt vmcnt(0)) and a __syncthreads().
 // Publishes this tile's counter, waits for the up-to-8 neighbouring tiles' counters, makes their payload visible (one agent
 // acquire by wave 0) and ends with a __syncthreads().  Returns true when the launch is dead (see kSyncStatus): the caller

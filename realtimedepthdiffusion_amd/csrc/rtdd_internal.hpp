@@ -60,6 +60,26 @@ struct Options {
     int debug_force_status = 0;      // RTDD_OPT_DEBUG_FORCE_STATUS: one-shot value for the status word behind the next blocked launch
 };
 
+// One asynchronous call whose results the caller has not yet seen confirmed by a synchronising call: what check_persistent_status
+// needs to run it again when a persistent launch gave up (api.cpp, "self-healing").  A solve is one sequence number (handed to the
+// kernel that publishes its result: k_finish, or k_pyrup_inject inside an estimate); an estimate is one per pyramid level.
+struct PendingOp {
+    enum Kind { kSolve = 0, kEstimate = 1 } kind = kSolve;
+    Options opt;                          // the options in force when the call was made
+    // kSolve: the arguments of rtdd_solve_ex (+ the optional u8 copy of the result, rtdd_refine_depth)
+    float *depth = nullptr; size_t depthPitch = 0;
+    const uint8_t *scribble = nullptr; size_t scribblePitch = 0;
+    const uint8_t *gray = nullptr; size_t grayPitch = 0;
+    int rows = 0, cols = 0, level = 0, seq = 0;
+    rtdd_solve_params params{};
+    uint8_t *finish_u8 = nullptr; size_t finish_u8_pitch = 0;
+    // kEstimate
+    int maxIterations = 0;
+    int level_seq[32] = {};               // sequence number of level l's solve (0: the level is empty)
+};
+constexpr int kRestartSolve = -1000;      // internal status: the pending calls were healed inside a solve's residual check; that solve starts over
+constexpr size_t kMaxPendingOps = 4096;
+
 }  // namespace rtdd
 
 namespace rtdd { struct Pyramid; struct MgState; }
@@ -89,6 +109,15 @@ struct rtdd_ctx {
     int flag_epoch = 0;             // the per-tile flags of the persistent kernels only ever grow: base value of the next persistent launch (api.cpp)
     int sync_header[2] = {0, 0};    // what sync_words[kSyncWithhold], [kSyncLimit] currently hold on the device
     rtdd_solve_info last_info{};    // of the most recent solve; kernel/tile/temporal_depth/persistent are filled in by the sweep launchers
+    // Self-healing after RTDD_ERR_TIMEOUT (api.cpp heal_pending): every solve / estimate since the last status check, in call order
+    int solve_seq = 0;              // sequence number of the most recent rtdd_solve_ex (1 .. 2^30, never 0)
+    std::vector<rtdd::PendingOp> pending;
+    bool pending_overflow = false;  // more than kMaxPendingOps calls without a synchronisation: a timeout among them is reported, not healed
+    bool in_estimate = false;       // rtdd_estimate_depth logs itself; its per-level solves do not
+    bool healing = false;           // a replay is running: nothing is logged, a second timeout is final
+    bool heal_warned = false;
+    int heals = 0;                  // RTDD_OPT_TIMEOUT_HEALS
+    int guard_seq = 0;              // sequence number the next guarded copy-back kernel reports when it finds the status word set
     bool persistent_used = false;   // a launch that can set the status word (sync_words[kSyncStatus]) happened since the last status check
     signed char persist_fit[17][2];  // per (tile id, contraction): does one workgroup of the persistent kernel fit a CU of THIS device (-1 = not asked yet)
     uint32_t *sat = nullptr;        // defocus summed-area table scratch
@@ -144,6 +173,8 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
 // sweep_blocked.hip
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
                           int *pk, int *pm, int *launches);
+// (k_finish and k_pyrup_inject store NOTHING when the status word is set: a timed-out solve leaves the caller's buffers as they were;
+// the first of them to find it set records ctx->guard_seq in sync_words[kSyncFailedSeq])
 int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols, uint8_t *u8 = nullptr, size_t u8Pitch = 0);
 int launch_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch, const float *depth, size_t depthPitch,
                            int32_t *index2, int level, int rows, int cols);
@@ -175,17 +206,21 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
 int launch_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, uint8_t *gray, size_t gp, int rows, int cols);
 int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, int cols, uint8_t *dst, size_t dp);
 int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
-                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out = nullptr, size_t cp = 0);
+                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out = nullptr, size_t cp = 0, bool guarded = false);
 int launch_depth_to_u8(rtdd_ctx *ctx, const float *src, size_t sp, uint8_t *dst, size_t dp, int rows, int cols);
 int launch_decode_annotation(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, const uint8_t *ann, size_t ap, uint8_t *edited, size_t ep,
                              uint8_t *scribble, size_t sp, int rows, int cols);
 int launch_fill_f32(rtdd_ctx *ctx, float *dst, size_t dp, int rows, int cols, float v);
 void pyramid_free(rtdd_ctx *ctx);
+void pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited);   // an annotation image is about to be written: one of the pyramid's?
 
 // persistent kernels (persist_sync.hpp): reserve the launch's flag values and refresh the debug words before a persistent launch;
 // read the status word where the stream has just been synchronised (-> RTDD_ERR_TIMEOUT, status cleared)
 int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base);
-int check_persistent_status(rtdd_ctx *ctx);
+// in_solve: called from a residual check inside rtdd_solve_ex -- after a successful heal of the calls before it that solve starts over (kRestartSolve)
+int check_persistent_status(rtdd_ctx *ctx, bool in_solve = false);
+// cascade_api.cpp: levels from_level .. 0 of an estimate (src/main.cpp:261-291); level_seq (optional) receives each level's solve sequence number
+int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq);
 
 // the reference's host-side omega recurrence (src/GPUSolver.cu:282-299)
 void omega_schedule(int n, std::vector<float> &out);

@@ -19,6 +19,7 @@
 // fmaf only in the contracted variant; the file is compiled with -ffp-contract=off), which is
 // what makes GPU-vs-oracle parity bit-exact rather than merely within 1e-4.
 #include "rtdd_internal.hpp"
+#include "persist_sync.hpp"
 
 namespace rtdd {
 
@@ -270,9 +271,10 @@ __device__ __forceinline__ uint8_t round_u8(float v) {
 }
 
 __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
-                                                int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch) {
+                                                int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;
     if (x >= cols || y >= rows) return;
     const float v = X[(size_t)y * ip + x];
     ((float *)((char *)depth + (size_t)y * depthPitch))[x] = v;
@@ -281,9 +283,10 @@ __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int
 
 // four pixels per thread when the caller's rows are 16-byte aligned (a group past the end of the row: pixel by pixel)
 __global__ __launch_bounds__(256) void k_finish4(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
-                                                 int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch) {
+                                                 int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq) {
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;
     if (x0 >= cols || y >= rows) return;
     const float4 v = *(const float4 *)(X + (size_t)y * ip + x0);
     float *o = (float *)((char *)depth + (size_t)y * depthPitch) + x0;
@@ -446,9 +449,10 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
 
 int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols, uint8_t *u8, size_t u8Pitch) {
     if ((uintptr_t)depth % 16 == 0 && depthPitch % 16 == 0)
-        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch);
+        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq);
     else
-        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch);
+        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq);
+    ctx->persistent_used = true;                  // (the guard may have recorded a failed solve: the next synchronising call looks)
     RTDD_LAUNCH_CHECK(ctx, "k_finish");
     return RTDD_OK;
 }
@@ -464,7 +468,7 @@ int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int row
     RTDD_LAUNCH_CHECK(ctx, "k_residual");
     RTDD_HIP(ctx, hipMemcpyAsync(host_out, ctx->residual_dev, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return check_persistent_status(ctx);        // the sweeps this residual judges may have been a persistent launch that gave up
+    return check_persistent_status(ctx, true);  // the sweeps this residual judges may have been a persistent launch that gave up
 }
 
 int launch_rbgs(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, int nsweeps, float omega) {

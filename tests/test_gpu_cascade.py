@@ -1,4 +1,6 @@
 """Whole-estimate driver on the GPU against the oracle-composed cascade (-m gpu)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -136,6 +138,73 @@ def test_estimate_4k_and_8k_full_cascades(oracle, lut, rows, cols, levels, seed)
         ref.estimate(1000)                                              # --live: the warm-started second frame
         c.estimate_depth(1000); c.synchronize()
         assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, 0), ref.depth[0], f"{cols}x{rows} cascade, second (warm-started) estimate")
+
+
+def test_estimate_heals_a_timed_out_persistent_level(oracle, lut, capfd):
+    """rtdd_estimate_depth with one tile's hand-off flag withheld (RTDD_OPT_DEBUG_WITHHOLD_TILE): the first persistent level of the
+    cascade times out, every copy-back behind it stores nothing, and the synchronising call runs the cascade again from that level
+    on without persistence -- every level's depth image and the u8 map are the oracle's, as if nothing had happened; the second,
+    warm-started estimate too (src/GPUSolver.cu:311-314: the reference's solver always leaves a valid depth map)."""
+    rows, cols = 1080, 1920
+    bgr, ann = _bgr(rows, cols, 77)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads())
+    ref.estimate(1000)
+    capfd.readouterr()
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        levels = c.pyramid_create(rows, cols)
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann))
+        c.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 1)
+        c.estimate_depth(1000); c.synchronize()
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1 and c.get_option(rt.OPT_PERSISTENT) == 0
+        assert capfd.readouterr().err.count("rtdd: persistent sweep kernel") == 1
+        for l in range(levels - 1, -1, -1):
+            assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, l), ref.depth[l], f"healed cascade, level {l}")
+        assert np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), ref.depth_u8)
+        ref.estimate(1000)
+        c.estimate_depth(1000); c.synchronize()
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1
+        assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, 0), ref.depth[0], "estimate after a healed one (warm start)")
+
+
+def test_annotation_pyramid_follows_every_write(oracle, lut):
+    """The coarse annotation levels are rebuilt by the first estimate after the annotation changed, not by every estimate
+    (src/main.cpp:249-259 does it every time; K6 only ever adds, so the images are the same).  Every library call that writes the
+    annotation must be noticed: rtdd_paint_image on the pyramid's own level-0 images, rtdd_upload, set_annotation; and a caller
+    that writes through the raw pointers says so (rtdd_pyramid_annotation_changed)."""
+    rows, cols = 270, 480
+    bgr, ann = _bgr(rows, cols, 5)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=4)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        levels = c.pyramid_create(rows, cols)
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann))
+
+        def check(what):
+            ref.estimate(1000); c.estimate_depth(1000); c.synchronize()
+            for l in range(levels):
+                assert np.array_equal(c.pyramid_download(rt.IMG_SCRIBBLE, l), ref.scribble[l]), f"{what}: scribble {l}"
+                assert np.array_equal(c.pyramid_download(rt.IMG_EDITED, l)[..., 0], ref.edited[l][..., 0]), f"{what}: edited {l}"
+                assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, l), ref.depth[l], f"{what}: depth {l}")
+
+        check("cold"); check("unchanged annotation")
+        sp, spitch, _, _ = c.pyramid_image(rt.IMG_SCRIBBLE, 0); ep, epitch, _, _ = c.pyramid_image(rt.IMG_EDITED, 0)
+        oracle.paint_image(100, 90, 64, 11, ref.edited[0], ref.scribble[0])
+        c.GPUPaintImage(100, 90, 64, 11, (ep, epitch), (sp, spitch), rows, cols)
+        check("after rtdd_paint_image")
+        def upload(ctx_, host, ptr, pitch, width):
+            host = np.ascontiguousarray(host)
+            ctx_._check(rt.lib().rtdd_upload(ctx_._h, C.c_void_p(ptr), C.c_size_t(pitch), C.c_void_p(host.ctypes.data), C.c_size_t(width), C.c_size_t(width), C.c_int(rows)))
+
+        oracle.paint_image(300, 200, 192, 15, ref.edited[0], ref.scribble[0])
+        upload(c, ref.scribble[0], sp, spitch, cols); upload(c, ref.edited[0], ep, epitch, cols * 3)
+        check("after rtdd_upload into the pyramid's images")
+        # through the raw pointers, behind this context's back (another context's copy): the caller has to say so
+        oracle.paint_image(40, 30, 0, 21, ref.edited[0], ref.scribble[0])
+        with rt.Context(0) as other:
+            upload(other, ref.scribble[0], sp, spitch, cols); upload(other, ref.edited[0], ep, epitch, cols * 3)
+        c.pyramid_annotation_changed()
+        check("after a foreign write + rtdd_pyramid_annotation_changed")
 
 
 @pytest.mark.parametrize("name", NAMES[:2])

@@ -87,3 +87,48 @@ def test_all_ten_reference_symbols_in_main_cpp_order(oracle, lut, rows, cols):
     _fn("_Z19GPUFreeDeviceMemoryi")(i32(P))
     # after the free the shim reports the call-order violation like the reference would fail: prints, does not crash
     solve(*_img(depth[0]), *_img(scribble[0]), *_img(gray[0]), i32(rows), i32(cols), f32(0.4), i32(1), f32(1e-5), i32(0))
+
+
+def test_mangled_solver_heals_a_timed_out_persistent_launch(oracle, lut, capfd):
+    """An unchanged main.cpp can neither set options nor upload its input again, and the reference's GPUMatrixFreeSolver always
+    returns with a valid depth map (src/GPUSolver.cu:311-314).  With a hand-off flag withheld on the shim's process-global context
+    (the only use of rtdd_dropin_context here: the testing knob), the persistent 1080p launch times out; the mangled call itself
+    must come back with the oracle's depth map, one warning printed, and the next call must be non-persistent."""
+    from realtimedepthdiffusion_amd.synth import make_problem
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=9)
+    L = rt.lib()
+    L.rtdd_dropin_context.restype = vp
+    h = vp(L.rtdd_dropin_context())
+    assert h.value
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 120, 0, 0, lut, 1, threads=oracle.max_threads())
+    _fn("_Z23GPUAllocateDeviceMemoryiii")(i32(rows), i32(cols), i32(1))
+    _fn("_Z14GPULoadWeightsf")(f32(0.4))
+    heals = i32(0); pers = i32(0)
+    assert L.rtdd_get_option(h, i32(rt.OPT_TIMEOUT_HEALS), C.byref(heals)) == 0
+    assert L.rtdd_get_option(h, i32(rt.OPT_PERSISTENT), C.byref(pers)) == 0
+    if pers.value == 0:
+        pytest.skip("the shim's process-global context has healed before in this process")
+    before = heals.value
+    assert L.rtdd_set_option(h, i32(rt.OPT_DEBUG_POLL_LIMIT_US), i32(3000)) == 0 and L.rtdd_set_option(h, i32(rt.OPT_DEBUG_WITHHOLD_TILE), i32(7)) == 0
+    capfd.readouterr()
+    solve = _fn("_Z19GPUMatrixFreeSolverPfmPhmS0_miififi")
+    try:
+        d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+        solve(*_img(d), *_img(m), *_img(g), i32(rows), i32(cols), f32(0.4), i32(120), f32(1e-5), i32(0))
+        assert_bit_equal(down(d), want, "mangled GPUMatrixFreeSolver over a timed-out persistent launch")
+        out = capfd.readouterr()
+        assert out.err.count("rtdd: persistent sweep kernel") == 1 and "GPUMatrixFreeSolver:" not in out.out, out
+        L.rtdd_get_option(h, i32(rt.OPT_TIMEOUT_HEALS), C.byref(heals)); L.rtdd_get_option(h, i32(rt.OPT_PERSISTENT), C.byref(pers))
+        assert heals.value == before + 1 and pers.value == 0
+        d2 = up(p["depth"])
+        solve(*_img(d2), *_img(m), *_img(g), i32(rows), i32(cols), f32(0.4), i32(120), f32(1e-5), i32(0))
+        assert_bit_equal(down(d2), want, "the next mangled solve (one launch per block of sweeps)")
+        info = rt.SolveInfo()
+        assert L.rtdd_last_solve_info(h, C.byref(info)) == 0 and info.persistent == 0 and info.kernel == 2, info.describe()
+        L.rtdd_get_option(h, i32(rt.OPT_TIMEOUT_HEALS), C.byref(heals))
+        assert heals.value == before + 1 and "rtdd:" not in capfd.readouterr().err
+    finally:
+        L.rtdd_set_option(h, i32(rt.OPT_DEBUG_WITHHOLD_TILE), i32(0)); L.rtdd_set_option(h, i32(rt.OPT_DEBUG_POLL_LIMIT_US), i32(0))
+        L.rtdd_set_option(h, i32(rt.OPT_PERSISTENT), i32(1))        # other tests of this process share the shim's context
+        _fn("_Z19GPUFreeDeviceMemoryi")(i32(1))
