@@ -168,9 +168,36 @@ def estimate_ms(rt, ctx, p, rows, cols, dev, n=20):
     kernels = []
     for l in range(1):                          # what the finest level ran (rtdd_last_solve_info reports the last solve: level 0)
         i = ctx.last_solve_info(); kernels.append(f"level 0: tile {i.tile}, {i.temporal_depth} sweeps per launch, persistent {i.persistent}")
+    # The region the reference itself clocks (src/main.cpp:234-293): upload of the host's scribble + edited images (:236-237), the
+    # cascade, convertTo + download of the u8 map (:290-291) -- page-locked host images, rtdd_live_submit / rtdd_live_wait.  One frame
+    # at a time = that region as it stands; two frames in flight (the copies on a second stream) = what a live loop sustains.
+    scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3)); outs = [rt.host_image((rows, cols)) for _ in range(2)]
+    scr.a[...] = ctx.pyramid_download(rt.IMG_SCRIBBLE, 0); ed.a[...] = ctx.pyramid_download(rt.IMG_EDITED, 0)
+    for _ in range(3):
+        ctx.live_submit(scr.a, ed.a, outs[0].a, 1000); ctx.live_wait()
+    t = time.perf_counter()
+    for _ in range(n):
+        ctx.live_submit(scr.a, ed.a, outs[0].a, 1000); ctx.live_wait()
+    ms_e2e = (time.perf_counter() - t) / n * 1e3
+    frames = 2 * n
+    t = time.perf_counter()
+    for f in range(frames):
+        if f >= 2:
+            ctx.live_wait()
+        ctx.live_submit(scr.a, ed.a, outs[f % 2].a, 1000)
+    while ctx.live_pending():
+        ctx.live_wait()
+    ms_live = (time.perf_counter() - t) / frames * 1e3
+    ctx.synchronize()
     ctx.pyramid_destroy()
+    for h in [scr, ed] + outs:
+        h.free()
+    h2d, d2h = rows * cols * 4, rows * cols
     return {"what": f"{cols}x{rows} {P}-level cascade, {pxit / 1e6:.1f} Mpixel-iterations, device-resident", "ms": ms,
-            "Mpixel_iterations_per_s": pxit / ms / 1e3, "finest_level": kernels[0]}
+            "Mpixel_iterations_per_s": pxit / ms / 1e3, "finest_level": kernels[0],
+            "ms_end_to_end": ms_e2e, "end_to_end_is": f"src/main.cpp:234-293 as the reference clocks it: H2D of scribble + edited ({h2d / 1e6:.1f} MB, page-locked), annotation pyramid, cascade, "
+                                                      f"D2H of the u8 map ({d2h / 1e6:.1f} MB), host waits for every frame",
+            "live_ms_per_frame": ms_live, "live_fps": 1e3 / ms_live, "live_is": "the same frames, two in flight: copies on a second stream overlap the other frame's arithmetic (rtdd_live_submit)"}
 
 
 def valu_roofline(px_sweeps_per_s, method):
@@ -182,11 +209,12 @@ def valu_roofline(px_sweeps_per_s, method):
             "mix_issue_cycles_measured": VALU_MIX_CYCLES, "frac_of_mix_issue_rate": achieved / VALU_PEAK_TOPS * VALU_MIX_CYCLES / 2.0}
 
 
-def sweep_4k(rt, dev, steps=10):
-    """The north star's 4K sweep (3840x2160 x 1000 Chebyshev-Jacobi sweeps), timed like the headline, outside its timed region."""
+def sweep_4k(rt, dev, steps=10, rows=2160, cols=3840, iters=1000, name="4k_jacobi1000"):
+    """The north star's 4K sweep (3840x2160 x 1000 Chebyshev-Jacobi sweeps), timed like the headline, outside its timed region; and
+    (rows = 4320, cols = 7680, iters = 200) the one Jacobi size whose working set (564 MB at 17 B/px) leaves the Infinity Cache: the
+    HBM-resident case of SURVEY 8(d)'s cache caveat."""
     import torch
     from realtimedepthdiffusion_amd.synth import make_problem
-    rows, cols, iters = 2160, 3840, 1000
     p = make_problem(rows, cols, seed=1234)
     ctx = rt.Context(int(dev.split(":")[1]))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -212,10 +240,21 @@ def sweep_4k(rt, dev, steps=10):
     launch_us = pr.sweep_ms * 1e3 / max(pr.launches, 1)
     sweeps_per_launch = pr.sweeps / max(pr.launches, 1)
     hbm_eq = 17.0 * rows * cols * sweeps_per_launch / (launch_us * 1e-6) / 1e9
-    return {"workload": "4k_jacobi1000: one 3840x2160 image, 1 level, 1000 Chebyshev-Jacobi sweeps", "value": rate / 1e6, "unit": "Mpixel-iterations/s",
-            "ms_per_step": el * 1e3, "kernel": f"k_sweep_blocked tile {info.tile}, {sweeps_per_launch:g} sweeps per launch, {launch_us:.1f} us per launch",
-            "valu": valu_roofline(rows * cols * sweeps_per_launch / (launch_us * 1e-6), "jacobi"),
-            "hbm_equivalent": {"achieved": hbm_eq, "peak": HBM_PEAK_GBS, "frac": hbm_eq / HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_pixel_sweep": 17.0}}
+    res = {"workload": f"{name}: one {cols}x{rows} image, 1 level, {iters} Chebyshev-Jacobi sweeps", "value": rate / 1e6, "unit": "Mpixel-iterations/s",
+           "ms_per_step": el * 1e3, "kernel": f"k_sweep_blocked tile {info.tile}, {sweeps_per_launch:g} sweeps per launch, {launch_us:.1f} us per launch",
+           "launch_us": launch_us, "sweeps_per_launch": sweeps_per_launch,
+           "valu": valu_roofline(rows * cols * sweeps_per_launch / (launch_us * 1e-6), "jacobi"),
+           "hbm_equivalent": {"achieved": hbm_eq, "peak": HBM_PEAK_GBS, "frac": hbm_eq / HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_pixel_sweep": 17.0,
+                              "algorithmic_bytes_per_launch": 17.0 * rows * cols * sweeps_per_launch}}
+    try:                                        # recorded counters of the same kernel instantiation (profiles/, scripts/profile_round.sh), as for the headline
+        k = json.load(open(os.path.join(ROOT, "profiles", "counters_latest.json"))).get(name, {})
+        if k and k.get("tile") == info.tile and k.get("persistent") == info.persistent and k.get("hbm_bytes_per_launch_corrected"):
+            res["traffic"] = k["hbm_bytes_per_launch_corrected"]
+            res["hbm_counter_frac"] = k["hbm_bytes_per_launch_corrected"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            res["counters_source"] = k.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
+    return res
 
 
 def effects(rt, dev):
@@ -498,6 +537,7 @@ def main():
         out["estimate_4k"] = estimate_ms(rt, c2, make_problem(2160, 3840, seed=1234), 2160, 3840, dev, n=10)   # the 6-level 4K cascade (src/main.cpp:95,261-288)
         c2.close()
         out["sweep_4k"] = sweep_4k(rt, dev)                                      # the north star's 4K stencil sweep
+        out["sweep_8k"] = sweep_4k(rt, dev, steps=5, rows=4320, cols=7680, iters=200, name="8k_jacobi200")   # HBM-resident (564 MB working set)
         out["effects"] = effects(rt, dev)
     if not dry and rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rows, cols, method)

@@ -186,6 +186,36 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
     CK(rtdd_pyramid_image(ctx, RTDD_IMG_ARTISTIC, 0, &p_art, &pi_art, nullptr, nullptr));
     CK(rtdd_pyramid_image(ctx, RTDD_IMG_DEPTH_U8, 0, &p_u8, &pi_u8, nullptr, nullptr));
 
+    // --live N without an effect: the reference's frame loop as it clocks it (main.cpp:232-295) -- every frame uploads the host's
+    // scribble and edited images (:236-237), estimates, downloads the u8 map (:290-291) -- two frames in flight (rtdd_live_submit):
+    // the copies of one frame overlap the arithmetic of the other.
+    if (live && job.effect.empty() && job.refine.empty()) {
+        struct Pinned { void *p = nullptr; ~Pinned() { if (p) rtdd_host_free(p); } } h_scr, h_ed, h_u8[2];
+        CK(rtdd_upload(ctx, d_bgr, (size_t)cols * 3, job.bgr.px.data(), (size_t)cols * 3, (size_t)cols * 3, rows));
+        CK(rtdd_pyramid_set_image(ctx, d_bgr, (size_t)cols * 3));
+        if (job.has_ann) {
+            CK(rtdd_upload(ctx, d_ann, cols, job.ann.px.data(), cols, cols, rows));
+            CK(rtdd_pyramid_set_annotation(ctx, d_ann, cols));
+        }
+        for (const Paint &p : job.paints)
+            CK(rtdd_paint_image(ctx, p.x, p.y, p.label, p.radius, (uint8_t *)p_ed, pi_ed, (uint8_t *)p_scr, pi_scr, rows, cols));
+        CK(rtdd_host_alloc(&h_scr.p, (size_t)rows * cols)); CK(rtdd_host_alloc(&h_ed.p, (size_t)rows * cols * 3));
+        CK(rtdd_host_alloc(&h_u8[0].p, (size_t)rows * cols)); CK(rtdd_host_alloc(&h_u8[1].p, (size_t)rows * cols));
+        CK(rtdd_download(ctx, h_scr.p, cols, p_scr, pi_scr, cols, rows));            // the host's Mats (main.cpp:160-168: decoded on the host there)
+        CK(rtdd_download(ctx, h_ed.p, (size_t)cols * 3, p_ed, pi_ed, (size_t)cols * 3, rows));
+        depth_u8->resize((size_t)rows * cols);
+        auto landed = [&](int f) { std::memcpy(depth_u8->data(), h_u8[f % 2].p, depth_u8->size()); if (every_map) every_map->push_back(*depth_u8); };
+        auto t0 = std::chrono::steady_clock::now();
+        for (int n = 0; n < count; n++) {
+            if (n >= 2) { CK(rtdd_live_wait(ctx)); landed(n - 2); }              // frame n-2's buffer is about to be reused
+            CK(rtdd_live_submit(ctx, (const uint8_t *)h_scr.p, cols, (const uint8_t *)h_ed.p, (size_t)cols * 3, job.iters, (uint8_t *)h_u8[n % 2].p, cols));
+        }
+        for (int f = count > 2 ? count - 2 : 0; f < count; f++) { CK(rtdd_live_wait(ctx)); landed(f); }
+        *ms_per_estimate = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (count > 0 ? count : 1);
+        CK(rtdd_ctx_synchronize(ctx));
+        return RTDD_OK;
+    }
+
     auto t0 = std::chrono::steady_clock::now();
     for (int n = 0; n < count; n++) {
         if (n == 0 || !live) {                                          // a new image (--batch: every image is independent -- rtdd_pyramid_set_image
@@ -286,6 +316,8 @@ int main(int argc, const char *argv[]) {
     const int total = live > 0 ? live : batch;
     std::printf("Processing Time: %.3f ms per estimate on device 0 (upload + estimate%s + download); %d estimate(s) on %d device(s) in %.1f ms wall incl. setup\n",
                 ms[0], job.effect.empty() ? "" : " + effect", total, devices, wall);
+    if (live > 0 && job.effect.empty() && job.refine.empty())
+        std::printf("Live: %.1f frames/s (%d frames, annotation upload + estimate + map download per frame, two frames in flight)\n", 1e3 / (ms[0] > 0 ? ms[0] : 1), live);
     if (!write_image(out + (png ? "DepthMap.png" : "DepthMap.pgm"), rgb.w, rgb.h, 1, depth[0].data())) { std::printf("cannot write %sDepthMap\n", out.c_str()); return 5; }
     if (!job.effect.empty()) {
         std::vector<unsigned char> o(art[0]);

@@ -260,6 +260,21 @@ int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *p
 int rtdd_pyramid_annotation_changed(rtdd_ctx *ctx);
 /* src/main.cpp:239-291; asynchronous; results in RTDD_IMG_DEPTH (all levels) and RTDD_IMG_DEPTH_U8 */
 int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations);
+/* Live mode: one frame of src/main.cpp:232-295 as the reference clocks it -- upload of the host's scribble and edited images
+ * (:236-237), the estimate, download of the u8 map (:290-291) -- pipelined two frames deep: the copies run on a second stream of the
+ * context's, so frame N+1's upload and frame N's download overlap the other frame's arithmetic and a frame costs about
+ * max(compute, copies).  rtdd_live_submit returns at once; the host buffers must stay valid (and unchanged) until the frame has been
+ * waited for, and should be page-locked (rtdd_host_alloc) -- pageable memory makes the copies synchronous.  hostScribble / hostEdited
+ * NULL: no upload, the annotation is the one already on the device.  A third submit waits for the oldest frame itself.
+ * rtdd_live_wait blocks until the OLDEST frame in flight has landed in its host buffer (a timed-out persistent launch is healed
+ * there like in rtdd_ctx_synchronize; with two frames in flight the healed older frame may already see the newer frame's
+ * annotation).  Results: hostDepthU8, and RTDD_IMG_DEPTH / RTDD_IMG_DEPTH_U8 on the device as after rtdd_estimate_depth. */
+int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribblePitch, const uint8_t *hostEdited, size_t editedPitch,
+                     int maxIterations, uint8_t *hostDepthU8, size_t depthPitch);
+int rtdd_live_wait(rtdd_ctx *ctx);
+int rtdd_live_pending(rtdd_ctx *ctx);                    /* frames submitted and not yet waited for: 0..2 */
+int rtdd_host_alloc(void **ptr, size_t bytes);           /* page-locked host memory (hipHostMalloc) / its release */
+int rtdd_host_free(void *ptr);
 /* Extension: one more solve of the finest level, in place on RTDD_IMG_DEPTH level 0, by rtdd_solve_ex with `params`
  * (e.g. RTDD_METHOD_RED_BLACK_GS + RTDD_RELAXATION_AUTO, or RTDD_METHOD_MULTIGRID, tolerance 1e-4), then RTDD_IMG_DEPTH_U8
  * again: "estimate, then converge".  The level-0 edge weights are rebuilt from the current depth, as every solve does

@@ -42,6 +42,7 @@ C_ABI_SYMBOLS = [
     "rtdd_pyramid_levels", "rtdd_pyramid_create", "rtdd_pyramid_destroy", "rtdd_pyramid_set_image",
     "rtdd_pyramid_set_annotation", "rtdd_pyramid_image", "rtdd_pyramid_annotation_changed", "rtdd_estimate_depth", "rtdd_refine_depth", "rtdd_bgr2gray", "rtdd_pyrdown_gray",
     "rtdd_pyrup_depth", "rtdd_depth_to_u8", "rtdd_upload", "rtdd_download",
+    "rtdd_live_submit", "rtdd_live_wait", "rtdd_live_pending", "rtdd_host_alloc", "rtdd_host_free",
 ]
 IMG_ORIGINAL, IMG_GRAY, IMG_SCRIBBLE, IMG_EDITED, IMG_DEPTH, IMG_DEPTH_U8, IMG_ARTISTIC = range(7)
 # Itanium-mangled names of the reference's ten free functions
@@ -303,6 +304,19 @@ class Context:
     def estimate_depth(self, maxIterations=1000):
         self._check(lib().rtdd_estimate_depth(self._h, C.c_int(maxIterations)))
 
+    # ---- live mode (src/main.cpp:232-295 pipelined): host images are numpy views of page-locked memory (host_image)
+    def live_submit(self, scribble, edited, depth_u8, maxIterations=1000):
+        sp = (C.c_void_p(scribble.ctypes.data), C.c_size_t(scribble.strides[0])) if scribble is not None else (None, C.c_size_t(0))
+        ep = (C.c_void_p(edited.ctypes.data), C.c_size_t(edited.strides[0])) if edited is not None else (None, C.c_size_t(0))
+        self._check(lib().rtdd_live_submit(self._h, sp[0], sp[1], ep[0], ep[1], C.c_int(maxIterations),
+                                           C.c_void_p(depth_u8.ctypes.data), C.c_size_t(depth_u8.strides[0])))
+
+    def live_wait(self):
+        self._check(lib().rtdd_live_wait(self._h))
+
+    def live_pending(self):
+        return int(lib().rtdd_live_pending(self._h))
+
     def refine_depth(self, method=METHOD_RED_BLACK_GS, maxIterations=200000, tolerance=1e-4, checkEvery=0, relaxation=RELAXATION_AUTO):
         """rtdd_refine_depth: converge the finest level of the last estimate in place.  Returns (iterations, residual)."""
         params = SolveParams(method, maxIterations, tolerance, checkEvery, relaxation if method == METHOD_RED_BLACK_GS else 0.0)
@@ -346,6 +360,32 @@ def device_image(host, device="cuda:0", align=512):
     if host.ndim == 3:
         view = view.unflatten(1, host.shape[1:])
     return view
+
+
+class host_image:
+    """A numpy array over page-locked host memory (rtdd_host_alloc), so that live-mode copies are asynchronous.  `.a` is the array;
+    free() or the garbage collector releases the memory (keep the object alive while frames that use it are in flight)."""
+
+    def __init__(self, shape, dtype="uint8"):
+        import numpy as np
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = C.c_void_p()
+        rc = lib().rtdd_host_alloc(C.byref(self._p), C.c_size_t(n))
+        if rc != RTDD_OK:
+            raise RtddError(rc, "rtdd_host_alloc")
+        self.a = np.frombuffer((C.c_char * n).from_address(self._p.value), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self._p is not None and self._p.value:
+            self.a = None
+            lib().rtdd_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def to_host(view):

@@ -77,10 +77,7 @@ static int replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
         rc = rtdd_solve_ex(ctx, op.depth, op.depthPitch, op.scribble, op.scribblePitch, op.gray, op.grayPitch, op.rows, op.cols, op.level, &op.params, nullptr);
         ctx->finish_u8 = u8; ctx->finish_u8_pitch = u8p;
     } else {
-        int from = -1;                                  // the level whose solve gave up; an estimate queued behind the failed call: every level
-        for (int l = 0; l < 32; l++) if (op.level_seq[l] != 0 && op.level_seq[l] == failed_seq) from = l;
-        if (from < 0) for (int l = 31; l >= 0 && from < 0; l--) if (op.level_seq[l] != 0) from = l;
-        if (from >= 0) rc = estimate_levels(ctx, op.maxIterations, from, nullptr);
+        rc = estimate_replay(ctx, op, failed_seq);
     }
     ctx->opt = now;
     return rc;
@@ -598,6 +595,7 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
         op.depth = depth; op.depthPitch = depthPitch; op.scribble = scribble; op.scribblePitch = scribblePitch; op.gray = gray; op.grayPitch = grayPitch;
         op.rows = rows; op.cols = cols; op.level = level; op.params = *params;
         op.finish_u8 = ctx->finish_u8; op.finish_u8_pitch = ctx->finish_u8_pitch;
+        op.id = ++ctx->op_counter;
         ctx->pending.push_back(op);
     }
     if (info) *info = ctx->last_info;

@@ -4,6 +4,7 @@
 #include <new>
 
 #include "rtdd_internal.hpp"
+#include "persist_sync.hpp"
 
 namespace rtdd {
 
@@ -21,6 +22,19 @@ struct Pyramid {
     // GPUPyrDownAnnotation only ever adds, SURVEY A.8, and the solver never moves a Dirichlet pixel): they are brought up to date
     // by the first estimate after the annotation changed, not by every estimate.
     bool annotation_dirty = true;
+    struct Live *live = nullptr;          // rtdd_live_submit's second stream, staging images and events (created on first use)
+};
+
+// Live mode (src/main.cpp:232-295, the body of the while loop, one frame): upload of the scribble and edited images (:236-237), the
+// estimate, download of the u8 map (:290-291).  Frames are pipelined two deep: the copies run on a stream of their own, frame N+1's
+// upload while frame N computes, frame N's download while frame N+1 computes.  Slot k = frame number % 2.
+struct Live {
+    hipStream_t up = nullptr, copy = nullptr;     // uploads and downloads each on a stream of their own: frame N+1's upload must not queue behind frame N's download
+    Image scribble_stage[2], edited_stage[2], u8_stage[2];
+    hipEvent_t h2d_done[2] = {nullptr, nullptr}, est_done[2] = {nullptr, nullptr}, d2h_done[2] = {nullptr, nullptr};
+    int *status_host = nullptr;           // page-locked, 2 x 8 ints: the kernels' control words as they were behind each frame's estimate
+    struct Frame { uint8_t *host = nullptr; size_t pitch = 0; bool in_flight = false; unsigned long long op_id = 0; } frame[2];
+    unsigned long long submitted = 0, waited = 0;
 };
 
 static bool inside(const Image &im, const void *p) {
@@ -48,9 +62,24 @@ static void free_image(Image &im) {
     im = Image();
 }
 
+static void live_free(Pyramid *p) {
+    Live *v = p->live;
+    if (!v) return;
+    if (v->up) { (void)hipStreamSynchronize(v->up); (void)hipStreamDestroy(v->up); }
+    if (v->copy) { (void)hipStreamSynchronize(v->copy); (void)hipStreamDestroy(v->copy); }
+    for (int k = 0; k < 2; k++) {
+        free_image(v->scribble_stage[k]); free_image(v->edited_stage[k]); free_image(v->u8_stage[k]);
+        for (hipEvent_t e : {v->h2d_done[k], v->est_done[k], v->d2h_done[k]}) if (e) (void)hipEventDestroy(e);
+    }
+    if (v->status_host) (void)hipHostFree(v->status_host);
+    delete v;
+    p->live = nullptr;
+}
+
 void pyramid_free(rtdd_ctx *ctx) {
     if (!ctx->pyr) return;
     Pyramid *p = ctx->pyr;
+    live_free(p);
     free_image(p->original); free_image(p->depth_u8); free_image(p->artistic);
     for (auto *v : {&p->gray, &p->scribble, &p->edited, &p->depth})
         for (auto &im : *v) free_image(im);
@@ -181,8 +210,7 @@ int rtdd_pyramid_annotation_changed(rtdd_ctx *ctx) {
     return RTDD_OK;
 }
 
-int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
-    if (!ctx) return RTDD_ERR_INVALID;
+static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, size_t u8_copy_pitch, unsigned long long *op_id) {
     if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
     REQUIRE(ctx, maxIterations >= 0, "maxIterations must be >= 0");
     Pyramid *p = ctx->pyr;
@@ -202,12 +230,128 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
     }
     PendingOp op;
     op.kind = PendingOp::kEstimate; op.opt = ctx->opt; op.maxIterations = maxIterations;
+    op.u8_copy = u8_copy; op.u8_copy_pitch = u8_copy_pitch;
     rc = estimate_levels(ctx, maxIterations, P - 1, op.level_seq);
+    if (rc == RTDD_OK && u8_copy) {
+        DeviceGuard g(ctx->device);
+        RTDD_HIP(ctx, hipMemcpy2DAsync(u8_copy, u8_copy_pitch, p->depth_u8.ptr, p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     if (rc == RTDD_OK && !ctx->healing) {
         if (ctx->pending.size() >= kMaxPendingOps) { ctx->pending.clear(); ctx->pending_overflow = true; }
+        op.id = ++ctx->op_counter;
+        if (op_id) *op_id = op.id;
         ctx->pending.push_back(op);
     }
     return rc;
+}
+
+int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    return estimate_submit(ctx, maxIterations, nullptr, 0, nullptr);
+}
+
+// ---- live mode ---------------------------------------------------------------------------------------------------------------------
+int rtdd_host_alloc(void **ptr, size_t bytes) {
+    if (!ptr) return RTDD_ERR_INVALID;
+    *ptr = nullptr;
+    return hipHostMalloc(ptr, bytes > 0 ? bytes : 1, hipHostMallocDefault) == hipSuccess ? RTDD_OK : RTDD_ERR_NOMEM;
+}
+
+int rtdd_host_free(void *ptr) { return !ptr || hipHostFree(ptr) == hipSuccess ? RTDD_OK : RTDD_ERR_HIP; }
+
+static int live_create(rtdd_ctx *ctx) {
+    Pyramid *p = ctx->pyr;
+    if (p->live) return RTDD_OK;
+    Live *v = new (std::nothrow) Live();
+    if (!v) return fail(ctx, RTDD_ERR_NOMEM, "live state");
+    p->live = v;
+    RTDD_HIP(ctx, hipStreamCreateWithFlags(&v->copy, hipStreamNonBlocking));       // (never joins the null stream implicitly: the context's stream may be it)
+    RTDD_HIP(ctx, hipStreamCreateWithFlags(&v->up, hipStreamNonBlocking));
+    int rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = alloc_image(ctx, v->scribble_stage[k], p->rows, p->cols, 1, 0)) != RTDD_OK) return rc;
+        if ((rc = alloc_image(ctx, v->edited_stage[k], p->rows, p->cols, 3, 0)) != RTDD_OK) return rc;
+        if ((rc = alloc_image(ctx, v->u8_stage[k], p->rows, p->cols, 1, 0)) != RTDD_OK) return rc;
+        RTDD_HIP(ctx, hipEventCreateWithFlags(&v->h2d_done[k], hipEventDisableTiming));
+        RTDD_HIP(ctx, hipEventCreateWithFlags(&v->est_done[k], hipEventDisableTiming));
+        RTDD_HIP(ctx, hipEventCreateWithFlags(&v->d2h_done[k], hipEventDisableTiming));
+    }
+    RTDD_HIP(ctx, hipHostMalloc((void **)&v->status_host, 2 * 8 * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < 16; i++) v->status_host[i] = 0;
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));                                // the staging images' fills
+    return RTDD_OK;
+}
+
+int rtdd_live_pending(rtdd_ctx *ctx) {
+    if (!ctx || !ctx->pyr || !ctx->pyr->live) return 0;
+    return (int)(ctx->pyr->live->submitted - ctx->pyr->live->waited);
+}
+
+int rtdd_live_wait(rtdd_ctx *ctx) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (!ctx->pyr || !ctx->pyr->live || ctx->pyr->live->submitted == ctx->pyr->live->waited) return fail(ctx, RTDD_ERR_STATE, "no frame in flight");
+    Pyramid *p = ctx->pyr;
+    Live *v = p->live;
+    DeviceGuard g(ctx->device);
+    const int k = (int)(v->waited % 2);
+    RTDD_HIP(ctx, hipEventSynchronize(v->d2h_done[k]));
+    if (v->status_host[8 * k + kSyncStatus] == 0) {                                 // the usual case: the frame is good, and so is everything logged before it
+        size_t n = 0;
+        while (n < ctx->pending.size() && ctx->pending[n].id <= v->frame[k].op_id) n++;
+        ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + n);
+        v->frame[k].in_flight = false; v->waited++;
+        return RTDD_OK;
+    }
+    // A sweep launch in front of this frame's download gave up (include/rtdd.h, RTDD_ERR_TIMEOUT): drain both streams, let the
+    // status check run the logged estimates again (each brings its staged u8 map with it), then fetch every frame in flight again.
+    RTDD_HIP(ctx, hipStreamSynchronize(v->up));
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
+    ctx->persistent_used = true;
+    const int rc = check_persistent_status(ctx);
+    if (rc != RTDD_OK) return rc;
+    for (unsigned long long f = v->waited; f < v->submitted; f++) {
+        const int j = (int)(f % 2);
+        RTDD_HIP(ctx, hipMemcpy2D(v->frame[j].host, v->frame[j].pitch, v->u8_stage[j].ptr, v->u8_stage[j].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost));
+        v->status_host[8 * j + kSyncStatus] = 0;
+    }
+    v->frame[k].in_flight = false; v->waited++;
+    return RTDD_OK;
+}
+
+int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribblePitch, const uint8_t *hostEdited, size_t editedPitch,
+                     int maxIterations, uint8_t *hostDepthU8, size_t depthPitch) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
+    Pyramid *p = ctx->pyr;
+    REQUIRE(ctx, (hostScribble == nullptr) == (hostEdited == nullptr), "scribble and edited images come together (or neither: the annotation is unchanged)");
+    REQUIRE(ctx, !hostScribble || (scribblePitch >= (size_t)p->cols && editedPitch >= (size_t)p->cols * 3), "pitch smaller than a row");
+    REQUIRE(ctx, hostDepthU8 && depthPitch >= (size_t)p->cols && maxIterations >= 0, "bad output buffer or iteration count");
+    DeviceGuard g(ctx->device);
+    int rc = live_create(ctx);
+    if (rc != RTDD_OK) return rc;
+    Live *v = p->live;
+    if (v->submitted - v->waited >= 2 && (rc = rtdd_live_wait(ctx)) != RTDD_OK) return rc;   // two frames in flight at most: the slot is free again
+    const int k = (int)(v->submitted % 2);
+    if (hostScribble) {
+        RTDD_HIP(ctx, hipMemcpy2DAsync(v->scribble_stage[k].ptr, v->scribble_stage[k].pitch, hostScribble, scribblePitch, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, v->up));
+        RTDD_HIP(ctx, hipMemcpy2DAsync(v->edited_stage[k].ptr, v->edited_stage[k].pitch, hostEdited, editedPitch, (size_t)p->cols * 3, p->rows, hipMemcpyHostToDevice, v->up));
+        RTDD_HIP(ctx, hipEventRecord(v->h2d_done[k], v->up));
+        RTDD_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->h2d_done[k], 0));
+        RTDD_HIP(ctx, hipMemcpy2DAsync(p->scribble[0].ptr, p->scribble[0].pitch, v->scribble_stage[k].ptr, v->scribble_stage[k].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+        RTDD_HIP(ctx, hipMemcpy2DAsync(p->edited[0].ptr, p->edited[0].pitch, v->edited_stage[k].ptr, v->edited_stage[k].pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+        p->annotation_dirty = true;
+    }
+    unsigned long long op_id = ctx->op_counter;
+    if ((rc = estimate_submit(ctx, maxIterations, (uint8_t *)v->u8_stage[k].ptr, v->u8_stage[k].pitch, &op_id)) != RTDD_OK) return rc;
+    RTDD_HIP(ctx, hipEventRecord(v->est_done[k], ctx->stream));
+    RTDD_HIP(ctx, hipStreamWaitEvent(v->copy, v->est_done[k], 0));
+    RTDD_HIP(ctx, hipMemcpy2DAsync(hostDepthU8, depthPitch, v->u8_stage[k].ptr, v->u8_stage[k].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, v->copy));
+    RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
+    RTDD_HIP(ctx, hipEventRecord(v->d2h_done[k], v->copy));
+    v->frame[k].host = hostDepthU8; v->frame[k].pitch = depthPitch; v->frame[k].in_flight = true; v->frame[k].op_id = op_id;
+    v->submitted++;
+    return RTDD_OK;
 }
 
 }  // extern "C"
@@ -259,6 +403,18 @@ int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level
     if (p->depth[0].rows > 0 && p->depth[0].cols > 0) return RTDD_OK;         // the u8 map left the solver's copy-back (above)
     DeviceGuard g(ctx->device);
     return launch_depth_to_u8(ctx, (const float *)p->depth[0].ptr, p->depth[0].pitch, (uint8_t *)p->depth_u8.ptr, p->depth_u8.pitch, p->rows, p->cols);   // :290
+}
+
+int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
+    Pyramid *p = ctx->pyr;
+    if (!p) return fail(ctx, RTDD_ERR_STATE, "the pyramid is gone");
+    int from = -1;                                  // the level whose solve gave up; an estimate queued behind the failed call: every level
+    for (int l = 0; l < 32; l++) if (failed_seq != 0 && op.level_seq[l] == failed_seq) from = l;
+    if (from < 0) for (int l = 31; l >= 0 && from < 0; l--) if (op.level_seq[l] != 0) from = l;
+    int rc = from >= 0 ? estimate_levels(ctx, op.maxIterations, from, nullptr) : RTDD_OK;
+    if (rc == RTDD_OK && op.u8_copy)
+        RTDD_HIP(ctx, hipMemcpy2DAsync(op.u8_copy, op.u8_copy_pitch, p->depth_u8.ptr, p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return rc;
 }
 
 }  // namespace rtdd

@@ -76,6 +76,8 @@ struct PendingOp {
     // kEstimate
     int maxIterations = 0;
     int level_seq[32] = {};               // sequence number of level l's solve (0: the level is empty)
+    uint8_t *u8_copy = nullptr; size_t u8_copy_pitch = 0;   // live mode: the u8 map is copied here (device) behind the estimate
+    unsigned long long id = 0;            // position in the context's call order (live mode drops the confirmed prefix of the log)
 };
 constexpr int kRestartSolve = -1000;      // internal status: the pending calls were healed inside a solve's residual check; that solve starts over
 constexpr size_t kMaxPendingOps = 4096;
@@ -117,6 +119,7 @@ struct rtdd_ctx {
     bool healing = false;           // a replay is running: nothing is logged, a second timeout is final
     bool heal_warned = false;
     int heals = 0;                  // RTDD_OPT_TIMEOUT_HEALS
+    unsigned long long op_counter = 0;
     int guard_seq = 0;              // sequence number the next guarded copy-back kernel reports when it finds the status word set
     bool persistent_used = false;   // a launch that can set the status word (sync_words[kSyncStatus]) happened since the last status check
     signed char persist_fit[17][2];  // per (tile id, contraction): does one workgroup of the persistent kernel fit a CU of THIS device (-1 = not asked yet)
@@ -221,6 +224,8 @@ int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base);
 int check_persistent_status(rtdd_ctx *ctx, bool in_solve = false);
 // cascade_api.cpp: levels from_level .. 0 of an estimate (src/main.cpp:261-291); level_seq (optional) receives each level's solve sequence number
 int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq);
+// an estimate of the pending log again, from the level whose solve has sequence number failed_seq (0: every level)
+int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq);
 
 // the reference's host-side omega recurrence (src/GPUSolver.cu:282-299)
 void omega_schedule(int n, std::vector<float> &out);

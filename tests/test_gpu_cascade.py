@@ -167,6 +167,48 @@ def test_estimate_heals_a_timed_out_persistent_level(oracle, lut, capfd):
         assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, 0), ref.depth[0], "estimate after a healed one (warm start)")
 
 
+@pytest.mark.parametrize("withhold", [False, True])
+def test_live_frames_pipelined_match_the_oracle(oracle, lut, withhold):
+    """rtdd_live_submit / rtdd_live_wait (src/main.cpp:232-295 per frame: upload scribble + edited, estimate, download the u8 map), two
+    frames in flight on two streams, page-locked host images: every frame's map is the oracle's n-th warm-started estimate -- also when
+    the first frame's persistent launch times out and both frames in flight are healed behind the caller's back."""
+    rows, cols = 540, 960
+    bgr, ann = _bgr(rows, cols, 31)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads())
+    with rt.Context(0) as c:
+        import torch
+        c.set_stream(torch.cuda.Stream().cuda_stream if not withhold else 0)        # a stream of its own, and the null stream
+        c.GPULoadWeights(0.4)
+        c.pyramid_create(rows, cols)
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann)); c.synchronize()
+        scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3)); out = [rt.host_image((rows, cols)) for _ in range(2)]
+        scr.a[...] = ref.scribble[0]; ed.a[...] = ref.edited[0]
+        if withhold:
+            c.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 1)
+        frames = 5
+        got = []
+        for n in range(frames):
+            if n >= 2:
+                c.live_wait(); got.append(out[n % 2].a.copy())
+            c.live_submit(scr.a, ed.a, out[n % 2].a, 1000)
+            assert c.live_pending() == min(n + 1, 2)
+        while c.live_pending():
+            k = len(got)
+            c.live_wait(); got.append(out[k % 2].a.copy())
+        c.synchronize()
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == (1 if withhold else 0)
+        for n in range(frames):
+            ref.estimate(1000)
+            assert np.array_equal(got[n], ref.depth_u8), f"frame {n}"
+        assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, 0), ref.depth[0], "depth after the last live frame")
+        # a frame without an upload: the annotation on the device stays
+        c.live_submit(None, None, out[0].a, 1000); c.live_wait()
+        ref.estimate(1000)
+        assert np.array_equal(out[0].a, ref.depth_u8)
+        with pytest.raises(rt.RtddError):
+            c.live_wait()                                                           # nothing in flight
+
+
 def test_annotation_pyramid_follows_every_write(oracle, lut):
     """The coarse annotation levels are rebuilt by the first estimate after the annotation changed, not by every estimate
     (src/main.cpp:249-259 does it every time; K6 only ever adds, so the images are the same).  Every library call that writes the

@@ -81,6 +81,26 @@ def test_harness_live_mode_is_the_warm_started_estimate(tmp_path):
     assert not np.array_equal(first.depth[0], third.depth[0])          # the warm start really changes something at 300 sweeps
 
 
+def test_harness_live_frames_are_pipelined_and_each_is_the_oracles(tmp_path):
+    """--live 4 --write-all: the four frames go through rtdd_live_submit / rtdd_live_wait, two in flight (annotation upload, estimate,
+    map download per frame: the region src/main.cpp:234-293 clocks); EVERY frame's map is the oracle's n-th warm-started estimate."""
+    g = load(NAMES[1])
+    _write_pnm(tmp_path / "img.ppm", g["bgr"][..., ::-1])
+    _write_pnm(tmp_path / "ann.pgm", g["annotation"])
+    paint = (60, 70, 192, 9)
+    out = subprocess.check_output([BIN, "-i", str(tmp_path / "img.ppm"), "-a", str(tmp_path / "ann.pgm"), "-o", str(tmp_path) + "/", "--live", "4", "--iters", "250",
+                                   "--write-all", "--paint", "%d,%d,%d,%d" % paint], text=True)
+    assert "Live:" in out and "frames/s" in out and "two frames in flight" in out, out
+    import oracle
+    from cascade_ref import Cascade
+    c = Cascade(oracle, g["bgr"], g["annotation"], oracle.load_weights(0.4), 1, threads=4)
+    oracle.paint_image(*paint, c.edited[0], c.scribble[0])
+    for n in range(4):
+        c.estimate(250)
+        assert np.array_equal(_read_pnm(tmp_path / f"DepthMap_{n}.pgm"), c.depth_u8), f"frame {n}"
+    assert np.array_equal(_read_pnm(tmp_path / "DepthMap.pgm"), c.depth_u8)
+
+
 def test_harness_batch_and_paint(tmp_path):
     """--paint (the mouse-drag brush, main.cpp:46-62) against GPUPaintImage's restatement + the restated cascade, every pixel;
     --batch B treats every image as independent: B = 3 on one device writes the same map as B = 1 (no warm start leaks in)."""
