@@ -351,7 +351,7 @@ def main():
         # ranks together (shard.timing_group): a rank-by-rank fallback could leave the ranks on different backends, waiting at the
         # first barrier.  RTDD_BENCH_BACKEND=gloo keeps everything on gloo (default for --dry-run and for ranks sharing a GPU).
         import datetime
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))      # (well above the RCCL probe's 60 s: shard.timing_group)
         want_rccl = (os.environ.get("RTDD_BENCH_BACKEND") or ("gloo" if (dry or share_gpu) else "nccl")) == "nccl"
         tgroup, tbackend = shard.timing_group(dist, f"cuda:{local}", want_rccl)
         if want_rccl and tbackend != "nccl" and rank == 0:

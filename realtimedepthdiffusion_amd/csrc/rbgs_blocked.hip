@@ -259,9 +259,27 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every storing wave drains its write-through stores
         __syncthreads();
-        if (exchange_wait<false>(sync_words, &dead_s, &seen_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, barrier (persist_sync.hpp)
+#ifndef RTDD_EXCHANGE_ACQUIRE
+#define RTDD_EXCHANGE_ACQUIRE 0      // 1: one agent-scope acquire by wave 0 and plain vector loads (the fallback form; built and tested once per round: tests/test_isa_hazards.py, scripts/build_variant.sh)
+#endif
+        if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, &seen_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, (acquire,) barrier (persist_sync.hpp)
+#if RTDD_EXCHANGE_ACQUIRE
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int y = y0 + g, ty = tr * G + g;
+            const bool central = xin && ty >= hy && ty < eh - hy;
+            if (colok && y >= 0 && y < rows && !central) {             // a halo pixel inside the image: some neighbour's centre
+                const float4 v = *(const float4 *)(Ex + (size_t)y * ip + x0);      // plain vector load behind the agent acquire
+                const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) a[g][i] = x0 + i < cols ? xv[i] : 0.0f;
+            }
+        }
+#else
         // no agent acquire: every halo load is a 16-byte sc1 load into the tile's registers, all issued, then ONE wait the loaded
-        // registers pass through (as in sweep_blocked.hip; MI355X_MICROARCH.md "Valid forms", table row 1)
+        // registers pass through (as in sweep_blocked.hip; MI355X_MICROARCH.md "Valid forms", table row 1).  The load's operand is
+        // read-write ("+v"): the register that holds a[g] on the path around the load IS the one the load fills, so the join needs no
+        // copy in front of the wait (tests/test_isa_hazards.py checks the disassembly: nothing touches a load's registers before it).
         typedef float f4v_t __attribute__((ext_vector_type(4)));
         f4v_t hv[G];
 #pragma unroll
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
             hv[g] = a[g];
             if (colok && y >= 0 && y < rows && !central) {             // a halo pixel inside the image: some neighbour's centre
                 const float *q = Ex + (size_t)y * ip + x0;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hv[g]) : "v"(q) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(hv[g]) : "v"(q) : "memory");
             }
         }
         static_assert(G == 4, "the wait below lists four registers");
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
                 for (int i = 0; i < 4; i++) a[g][i] = x0 + i < cols ? hv[g][i] : 0.0f;
             }
         }
+#endif
     }
     if (PERSIST && (blk & 1)) Y = X;                                     // the last block's parity names the result buffer
 

@@ -38,8 +38,11 @@ __device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
 // store of them sc1 and drained, and the flag protocol of persist_sync.hpp, the consumer needs no agent-scope acquire
 // (MI355X_MICROARCH.md, "Valid forms", table row 1).  The value is NOT there when the statement returns: wait_loads() below.
 typedef float f4v_t __attribute__((ext_vector_type(4)));
+// `dst` is a read-write operand: on the path AROUND a conditional load the register keeps its old value, so the register allocator has no
+// reason to give the load a register of its own and copy it at the join -- in front of the wait, where the copy would read stale bits.
+// tests/test_isa_hazards.py checks in the disassembly that nothing reads or writes a load's registers before the next s_waitcnt vmcnt(0).
 __device__ __forceinline__ void load_sc1(f4v_t &dst, const float *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(dst) : "v"(p) : "memory");
 }
 
 // Result stores.  RTDD_STORE_MODE (diagnostic knob): 0 plain, 1 non-temporal, 2 write-through (sc1).

@@ -33,11 +33,13 @@ def aggregate(units_local, elapsed_local, dist=None, device="cpu", group=None):
     return float(u.item()), float(t.item()), float(u.item()) / float(t.item())
 
 
-def timing_group(dist, device, want_rccl, timeout_s=120):
+def timing_group(dist, device, want_rccl, timeout_s=60):
     """The process group for the timing barrier and the two scalar reductions (nothing else crosses ranks).  Every rank is already
     in a gloo default group (it always comes up).  If RCCL is wanted, all ranks create an RCCL group and try one all-reduce on it;
     whether that worked is agreed over gloo (MIN of a flag), so either ALL ranks use RCCL or ALL stay on gloo -- a rank-by-rank
-    fallback could leave the ranks on different backends, waiting at the first barrier.  Returns (group or None, "nccl" | "gloo")."""
+    fallback could leave the ranks on different backends, waiting at the first barrier.  The RCCL probe's timeout (60 s) is well below the
+    gloo default group's (bench.py: 300 s), so a rank whose RCCL group failed at once still finds the others at the vote when their
+    probe has timed out.  A group that lost the vote is destroyed (best effort).  Returns (group or None, "nccl" | "gloo")."""
     import datetime
     import torch
     if not want_rccl:
@@ -53,4 +55,11 @@ def timing_group(dist, device, want_rccl, timeout_s=120):
         ok = 0
     flag = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)                     # the default (gloo) group
-    return (g, "nccl") if int(flag.item()) == 1 else (None, "gloo")
+    if int(flag.item()) == 1:
+        return g, "nccl"
+    if g is not None:
+        try:
+            dist.destroy_process_group(g)
+        except Exception:                                           # noqa: BLE001
+            pass
+    return None, "gloo"

@@ -55,5 +55,17 @@ def test_desaturation_and_haze_4k(ctx, oracle):
         assert np.array_equal(down(art), oracle.desaturate(orig, gray, depth, contract)), f"desaturation contract {contract}"
         art = up(np.zeros_like(orig))
         ctx.GPUSimulateHaze(o, d, art, rows, cols)
-        assert np.array_equal(down(art), oracle.haze(orig, depth, contract)), f"haze contract {contract}"      # bit-exact since round 3
+        got = down(art)
+        assert np.array_equal(got, oracle.haze(orig, depth, contract)), f"haze contract {contract}"      # bit-exact since round 3
+        if contract == 0:
+            # ... against code the kernel shares (one fixed f64 exp sequence on both sides).  The reference calls CUDA's expf
+            # (src/GPUDepthEffect.cu:88: <= 2 ulp, reproducible nowhere), so the statement tied to the REFERENCE's behaviour is a bound:
+            # against an independent numpy restatement with libm's exp, at most one grey level on at most 1e-4 of the values.
+            f32 = np.float32
+            t = np.exp(((f32(-2.0) * depth).astype(np.float64) / 255.0).astype(f32)).astype(f32)
+            w = ((f32(1) - t) * f32(255)).astype(f32)
+            v = (t[..., None] * orig.astype(f32)).astype(f32) + w[..., None]
+            ref = np.clip(np.trunc(np.nan_to_num(v, nan=0.0)), 0, 255).astype(np.uint8)
+            diff = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+            assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4, f"haze against libm exp: max {diff.max()}, {(diff != 0).mean():.2e} of values differ"
     ctx.set_option(rt.OPT_FP_CONTRACT, 1)

@@ -110,7 +110,7 @@ def test_haze_transmission_every_depth_pattern(ctx, oracle):
 
 # RTDD_OPT_DEFOCUS_PATH: 1 = the global summed-area table (four launches), 2 = per-tile tables in LDS (one launch; what images up to
 # ~1080p take by default).  Every defocus test runs both.
-DEFOCUS_PATHS = [1, 2]
+DEFOCUS_PATHS = [1, 2, 3]
 
 
 def _defocus(ctx, path, orig_dev, depth_dev, art_dev, rows, cols):

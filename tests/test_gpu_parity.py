@@ -73,7 +73,7 @@ def test_solver_bit_exact(ctx, oracle, lut, shape, level, levels, iters, contrac
     assert_bit_equal(got, want, f"solver {shape} level {level}")
 
 
-@pytest.mark.parametrize("tile,depth", [(1, 1), (1, 4), (1, 7), (1, 8), (1, 16), (2, 4), (2, 8), (2, 5), (3, 4), (3, 12), (3, 16), (12, 8), (13, 8), (13, 5), (9, 28), (9, 24), (11, 8), (4, 28), (14, 8), (14, 28), (14, 5), (14, 1),
+@pytest.mark.parametrize("tile,depth", [(1, 1), (1, 4), (1, 7), (1, 8), (1, 16), (2, 4), (2, 8), (2, 5), (3, 4), (3, 12), (3, 16), (12, 8), (13, 8), (13, 5), (9, 28), (9, 24), (11, 8), (4, 28), (14, 8), (14, 28), (14, 5), (14, 1), (15, 8), (15, 12), (15, 1), (16, 8), (16, 5), (16, 20),
                                         (5, 8), (5, 12), (6, 8), (6, 12), (7, 8), (7, 12), (8, 8), (8, 12), (10, 8), (10, 12), (4, 8), (4, 12)])
 @pytest.mark.parametrize("shape,iters,level,levels", [((200, 333), 37, 0, 1), ((67, 120), 64, 1, 2), ((300, 130), 24, 0, 2), ((129, 129), 19, 0, 1)])
 def test_blocked_kernel_bit_exact(ctx, oracle, lut, tile, depth, shape, iters, level, levels):
@@ -628,3 +628,46 @@ def test_automatic_configuration_keeps_the_column_kernel_to_the_small_levels(ctx
     ctx.synchronize()
     assert i.kernel == 2, i.describe()
     assert (i.tile == 14) == small, i.describe()
+
+
+def test_acquire_variant_of_the_hand_off_is_bit_exact(oracle, lut, tmp_path):
+    """The persistent kernels' hand-off has no agent-scope acquire (16-byte sc1 loads only; validated on gfx950 in SPX mode -- DESIGN.md).
+    Its documented fallback, -DRTDD_EXCHANGE_ACQUIRE=1 (one acquire by wave 0 + plain loads, in k_sweep_blocked AND k_rbgs_blocked), is
+    built as librtdd_acq.so by __graft_entry__.build() and must produce the same bits: a persistent 1080p Jacobi solve against the
+    oracle and a persistent red-black solve against the default library, in a process of its own (RTDD_LIBRARY selects the library)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "realtimedepthdiffusion_amd", "librtdd_acq.so")
+    if not os.path.exists(so):
+        pytest.skip("librtdd_acq.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=12)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 200, 0, 0, lut, 1, threads=oracle.max_threads())
+    with _fresh(rows, cols, False) as c:
+        d = up(p["depth"])
+        c.solve_ex(d, up(p["mask"]), up(p["gray"]), rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=64, tolerance=0.0); c.synchronize()
+        assert c.last_solve_info().persistent == 1
+        rb_want = down(d)
+    np.save(tmp_path / "want.npy", want); np.save(tmp_path / "rb_want.npy", rb_want)
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+import realtimedepthdiffusion_amd as rt
+from realtimedepthdiffusion_amd.synth import make_problem
+from gpu_util import up, down, assert_bit_equal
+p = make_problem({rows}, {cols}, seed=12)
+with rt.Context(0) as c:
+    c.GPUAllocateDeviceMemory({rows}, {cols}, 1); c.GPULoadWeights(0.4)
+    m, g = up(p["mask"]), up(p["gray"])
+    d = up(p["depth"]); c.GPUMatrixFreeSolver(d, m, g, {rows}, {cols}, 0.4, 200, 0.0, 0); c.synchronize()
+    assert c.last_solve_info().persistent == 1
+    assert_bit_equal(down(d), np.load({str(tmp_path / 'want.npy')!r}), "Jacobi, acquire variant")
+    d = up(p["depth"]); c.solve_ex(d, m, g, {rows}, {cols}, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=64, tolerance=0.0); c.synchronize()
+    assert c.last_solve_info().persistent == 1
+    assert_bit_equal(down(d), np.load({str(tmp_path / 'rb_want.npy')!r}), "red-black, acquire variant")
+print("acquire variant ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RTDD_LIBRARY=so), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "acquire variant ok" in out.stdout, out.stdout + out.stderr

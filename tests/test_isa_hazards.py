@@ -17,12 +17,12 @@ CSRC = os.path.join(ROOT, "realtimedepthdiffusion_amd", "csrc")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
-def _disassembly(tmp_path):
+def _disassembly(tmp_path, name="sweep_blocked.o", src=None):
     import glob
     import shutil
     rt.build()
-    obj = str(tmp_path / "sweep_blocked.o")
-    shutil.copy(os.path.join(CSRC, "sweep_blocked.o"), obj)
+    obj = str(tmp_path / name)
+    shutil.copy(src or os.path.join(CSRC, name), obj)
     subprocess.check_call([OBJDUMP, "--offloading", obj], stdout=subprocess.DEVNULL, cwd=str(tmp_path))     # writes <obj>.0.hipv4-...-gfx950 beside it
     dev = glob.glob(obj + ".*gfx950*")
     assert dev, os.listdir(tmp_path)
@@ -70,3 +70,71 @@ def test_hand_written_dpp_has_its_wait_states(tmp_path):
                         f"{head}: '{back}' writes EXEC {waits} wait state(s) before '{ins}'"
             checked += 1
     assert checked >= 16, f"only {checked} v_fmac_f32_dpp found: was the kernel renamed?"
+
+
+def _vgprs(text):
+    """Every VGPR named in an operand string."""
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out |= set(range(int(a), int(b) + 1))
+    out |= {int(n) for n in re.findall(r"\bv(\d+)\b", text)}
+    return out
+
+
+def _check_sc1_loads(asm, kernel, min_loads):
+    """The persistent hand-off reads its halo with `global_load_dwordx4 ... sc1` straight into the tile's registers and has NO
+    agent-scope acquire (csrc/persist_sync.hpp, exchange_wait<false>): the loaded registers are only valid behind the one
+    `s_waitcnt vmcnt(0)` that follows the loads, and the loads sit inside a divergent `if`.  A register copy the compiler placed between
+    a load and that wait (a phi at the join of the `if`) would silently read stale bits -- a wrong depth map, not an error.  So: in every
+    persistent instantiation, between each sc1 load and the next s_waitcnt vmcnt(0), no instruction may name the load's destination."""
+    funcs = re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", asm)
+    loads = 0
+    kernels = 0
+    for f in funcs:
+        head = f.split("\n", 1)[0]
+        if kernel not in head:
+            continue
+        lines = [l.split("//")[0].rstrip() for l in f.split("\n")[1:] if l.strip() and not l.lstrip().startswith(("//", ";"))]
+        instrs = [l.strip() for l in lines if re.match(r"\s+[a-z]", l)]
+        here = 0
+        for i, ins in enumerate(instrs):
+            if not (ins.startswith("global_load_dwordx4") and ins.rstrip().endswith("sc1")):
+                continue
+            dst = _vgprs(ins.split(None, 1)[1].split(",")[0])
+            assert len(dst) == 4, ins
+            for later in instrs[i + 1:]:
+                if later.startswith("s_waitcnt") and "vmcnt(0)" in later:
+                    break
+                if later.startswith(("s_endpgm", "s_branch")):
+                    raise AssertionError(f"{head}: no s_waitcnt vmcnt(0) behind '{ins}'")
+                ops = later.split(None, 1)[1] if " " in later else ""
+                assert not (_vgprs(ops) & dst), f"{head}: '{later}' touches the registers of '{ins}' before the wait"
+            here += 1
+        if here:
+            kernels += 1
+        loads += here
+    assert loads >= min_loads and kernels >= 1, f"only {loads} sc1 loads in {kernels} instantiations of {kernel}: was the hand-off rewritten?"
+    return kernels, loads
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="ROCm LLVM tools not present")
+def test_sc1_halo_loads_are_not_touched_before_their_wait(tmp_path):
+    kernels, loads = _check_sc1_loads(_disassembly(tmp_path), "k_sweep_blocked", 2 * 2 * 13)     # 13 tiles x 2 contractions, >= 2 loads each
+    assert kernels == 26, kernels                                                                   # every PERSIST instantiation (the others have no sc1 load)
+    kernels, loads = _check_sc1_loads(_disassembly(tmp_path, "rbgs_blocked.o"), "k_rbgs_blocked", 4 * 4)
+    assert kernels >= 4, kernels
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="ROCm LLVM tools not present")
+def test_acquire_fallback_of_the_hand_off_builds(tmp_path):
+    """RTDD_EXCHANGE_ACQUIRE=1 is the documented fallback of the no-acquire hand-off (agent-scope acquire + plain loads), in both
+    persistent kernels.  It must keep compiling, contain the cache invalidate and no sc1 load; tests/test_gpu_parity.py runs it on the GPU
+    (test_acquire_variant_of_the_hand_off_is_bit_exact) when the variant library has been built (scripts/build_variant.sh acq ...)."""
+    flags = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize",
+             "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-DRTDD_EXCHANGE_ACQUIRE=1"]
+    obj = str(tmp_path / "rbgs_acq.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + flags + ["-c", os.path.join(CSRC, "rbgs_blocked.hip"), "-o", obj])
+    asm = _disassembly(tmp_path, "rbgs_acq2.o", src=obj)
+    persistent = [f for f in re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", asm) if "k_rbgs_blocked" in f.split("\n", 1)[0] and "buffer_inv sc1" in f]
+    assert len(persistent) >= 4, "the acquire variant must invalidate at agent scope (buffer_inv sc1) in every persistent instantiation"
+    assert not any(re.search(r"global_load_dwordx4 .* sc1", f) for f in persistent)
