@@ -30,6 +30,7 @@ OPT_DEBUG_WITHHOLD_TILE, OPT_DEBUG_POLL_LIMIT_US = 7, 8
 OPT_AUTO_CYCLE_FIXED_NS, OPT_AUTO_CYCLE_FS_PER_PX, OPT_AUTO_SWEEP_FS_PER_PX, OPT_AUTO_SWEEP_FLOOR_NS = 9, 10, 11, 12
 OPT_DEBUG_FORCE_STATUS = 13
 OPT_TIMEOUT_HEALS = 14                     # read only
+OPT_DEFOCUS_LAST_PATH = 15                 # read only: 1 the global table, 2 the tile kernel
 RTDD_ERR_TIMEOUT = 6
 
 # every symbol include/rtdd.h declares (checked by tests/test_abi.py against the header)

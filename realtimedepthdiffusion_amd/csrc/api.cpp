@@ -242,7 +242,7 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 2, "sweep kernel must be 0..2"); ctx->opt.sweep_kernel = value; break;
         case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 28, "temporal depth must be 0..28"); ctx->opt.temporal_depth = value; break;
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
-        case RTDD_OPT_DEFOCUS_PATH: REQUIRE(ctx, value >= 0 && value <= 3, "defocus path must be 0..3"); ctx->opt.defocus_path = value; break;
+        case RTDD_OPT_DEFOCUS_PATH: REQUIRE(ctx, value >= 0 && value <= 2, "defocus path must be 0..2"); ctx->opt.defocus_path = value; if (value == 0) ctx->defocus_table_sticky = false; break;      // (setting the automatic choice again forgets what earlier depths made it choose)
         case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 16, "tile must be 0..16"); ctx->opt.tile = value; break;
         case RTDD_OPT_PERSISTENT: ctx->opt.persistent = value ? 1 : 0; break;
         case RTDD_OPT_AUTO_CYCLE_FIXED_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fixed_ns = value; break;
@@ -275,6 +275,7 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_DEBUG_POLL_LIMIT_US: *value = ctx->opt.debug_poll_limit_us; break;
         case RTDD_OPT_DEBUG_FORCE_STATUS: *value = ctx->opt.debug_force_status; break;
         case RTDD_OPT_TIMEOUT_HEALS: *value = ctx->heals; break;
+        case RTDD_OPT_DEFOCUS_LAST_PATH: *value = ctx->defocus_last_path; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_sat_build(const uint8_t *__restrict__ 
 
 // T(r, c) with T(-1, .) = T(., -1) = 0
 __device__ __forceinline__ u64 sat_at(const u64 *__restrict__ T, int tp, int r, int c) {
-    const u64 v = T[(uint32_t)(max(r, 0) * tp + max(c, 0))];
+    const u64 v = T[__umul24(max(r, 0), tp) + (uint32_t)max(c, 0)];       // (rows, tp < 2^24 and rows * tp < 2^32: check_effect; v_mul_lo_u32 is a quarter-rate instruction)
     return (r < 0 || c < 0) ? 0ull : v;
 }
 
@@ -679,8 +679,6 @@ __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restri
     }
 }
 
-#include "defocus_tiles.inc"          // the tiled-origin table: k_sat_tiles, k_defocus_tiles
-
 static inline dim3 grid64x4(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
 
 template <int MODE>
@@ -712,41 +710,6 @@ int launch_haze(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *dept
 
 int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *depth, size_t dp, uint8_t *art, size_t ap, int rows, int cols) {
     const int kernelSize = 0.025 * sqrtf(rows * rows + cols * cols);    // :42, evaluated once on the host (sqrtf is correctly rounded on both)
-    if (ctx->opt.defocus_path == 3) {
-        // (experiment, EXPERIMENTS.md round 4) the table with a local origin per tile (defocus_tiles.inc): one build launch, one lookup launch
-        const int hm = kernelSize / 2;
-        const int ths = hm <= 32 ? 6 : hm <= 64 ? 7 : 8;                // tile height 64 / 128 / 256 rows: >= the tallest nominal window
-        const int tp = (cols + 3) / 4 * 4;
-        const int strips = (cols + 255) / 256;
-        const size_t need = (((size_t)rows * tp + (size_t)strips * rows) * sizeof(u64) + 256) / sizeof(uint32_t);      // the table + its strips' last columns
-        if (ctx->sat_elems < need) {
-            if (ctx->sat) { RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream)); RTDD_HIP(ctx, hipFree(ctx->sat)); ctx->sat = nullptr; ctx->sat_elems = 0; }
-            RTDD_HIP(ctx, hipMalloc((void **)&ctx->sat, need * sizeof(uint32_t)));
-            ctx->sat_elems = need;
-        }
-        u64 *T = (u64 *)ctx->sat, *E = T + (size_t)rows * tp;
-        const bool vin = (uintptr_t)orig % 4 == 0 && op % 4 == 0, vout = vin && (uintptr_t)art % 4 == 0 && ap % 4 == 0;
-        {
-            const int gx = (cols + 255) / 256, gy = (rows + (1 << ths) - 1) >> ths, ntiles = gx * gy;
-            const int xcd_tiles = ntiles >= 64 ? (ntiles + 7) / 8 : 0;
-            const dim3 g(xcd_tiles > 0 ? 8 * xcd_tiles : ntiles);
-#define RTDD_ST_LAUNCH(V, R) hipLaunchKernelGGL((k_sat_tiles<V, R>), g, dim3(512), 0, ctx->stream, orig, op, T, E, tp, rows, cols, gx, ntiles, xcd_tiles)
-            if (vin) { if (ths == 6) RTDD_ST_LAUNCH(true, 8); else if (ths == 7) RTDD_ST_LAUNCH(true, 16); else RTDD_ST_LAUNCH(true, 32); }
-            else { if (ths == 6) RTDD_ST_LAUNCH(false, 8); else if (ths == 7) RTDD_ST_LAUNCH(false, 16); else RTDD_ST_LAUNCH(false, 32); }
-#undef RTDD_ST_LAUNCH
-            RTDD_LAUNCH_CHECK(ctx, "k_sat_tiles");
-        }
-        const int gx = (cols + 63) / 64, gy = (rows + 4 * kDefocusRows - 1) / (4 * kDefocusRows);
-        static const int st_env = getenv("RTDD_DEFOCUS_STRIP") ? atoi(getenv("RTDD_DEFOCUS_STRIP")) : 0;      // (developer knob: tiles per strip; 0 = default)
-        const int st = st_env > 0 ? (st_env < gx ? st_env : gx) : (gx < 8 ? gx : 8);
-        const int ntiles = (gx + st - 1) / st * st * gy;                 // numbered strip by strip (k_defocus_tiles); a narrower last strip leaves gaps
-        const int xcd_tiles = ntiles >= 64 ? (ntiles + 7) / 8 : 0;
-        const dim3 g4(xcd_tiles > 0 ? 8 * xcd_tiles : ntiles);
-        if (vout) hipLaunchKernelGGL(k_defocus_tiles<true>, g4, dim3(256), 0, ctx->stream, orig, op, depth, dp, T, E, tp, art, ap, rows, cols, kernelSize, ths, gx, gy, ntiles, xcd_tiles, st);
-        else hipLaunchKernelGGL(k_defocus_tiles<false>, g4, dim3(256), 0, ctx->stream, orig, op, depth, dp, T, E, tp, art, ap, rows, cols, kernelSize, ths, gx, gy, ntiles, xcd_tiles, st);
-        RTDD_LAUNCH_CHECK(ctx, "k_defocus_tiles");
-        return RTDD_OK;
-    }
     // small nominal windows (up to ~1080p): one launch, per-tile tables in LDS (k_defocus_tile).  RTDD_OPT_DEFOCUS_PATH: 0 automatic, 1 the
     // global table always, 2 the tile kernel wherever its region fits.
     if (ctx->opt.defocus_path != 1 && !(ctx->opt.defocus_path == 0 && ctx->defocus_table_sticky) && kernelSize / 2 <= kDtHM && (size_t)rows * cols < (1ull << 32) / 255) {
@@ -761,6 +724,7 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
         else { if (low) RTDD_DT_LAUNCH(false, 16); else RTDD_DT_LAUNCH(false, 24); }
 #undef RTDD_DT_LAUNCH
         RTDD_LAUNCH_CHECK(ctx, "k_defocus_tile");
+        ctx->defocus_last_path = 2;
         ctx->persistent_used = true;                 // (the next synchronising call reads the control words: check_persistent_status)
         return RTDD_OK;
     }
@@ -795,6 +759,7 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
     if (vout) hipLaunchKernelGGL(k_defocus<true>, g4, dim3(256), 0, ctx->stream, orig, op, depth, dp, T, tp, art, ap, rows, cols, kernelSize, gx, ntiles, xcd_tiles);
     else hipLaunchKernelGGL(k_defocus<false>, g4, dim3(256), 0, ctx->stream, orig, op, depth, dp, T, tp, art, ap, rows, cols, kernelSize, gx, ntiles, xcd_tiles);
     RTDD_LAUNCH_CHECK(ctx, "k_defocus");
+    ctx->defocus_last_path = 1;
     return RTDD_OK;
 }
 

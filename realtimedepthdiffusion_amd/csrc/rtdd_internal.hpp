@@ -107,6 +107,7 @@ struct rtdd_ctx {
     int deferred_plane = -1;
     uint8_t *finish_u8 = nullptr;
     size_t finish_u8_pitch = 0;
+    int defocus_last_path = 0;           // RTDD_OPT_DEFOCUS_LAST_PATH: what the most recent rtdd_simulate_defocus launched (1 table, 2 tile kernel)
     bool defocus_table_sticky = false;   // a tile-kernel defocus met out-of-range depths (seen at a synchronisation): automatic choice = the table from then on
     int flag_epoch = 0;             // the per-tile flags of the persistent kernels only ever grow: base value of the next persistent launch (api.cpp)
     int sync_header[2] = {0, 0};    // what sync_words[kSyncWithhold], [kSyncLimit] currently hold on the device

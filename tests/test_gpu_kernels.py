@@ -110,7 +110,7 @@ def test_haze_transmission_every_depth_pattern(ctx, oracle):
 
 # RTDD_OPT_DEFOCUS_PATH: 1 = the global summed-area table (four launches), 2 = per-tile tables in LDS (one launch; what images up to
 # ~1080p take by default).  Every defocus test runs both.
-DEFOCUS_PATHS = [1, 2, 3]
+DEFOCUS_PATHS = [1, 2]
 
 
 def _defocus(ctx, path, orig_dev, depth_dev, art_dev, rows, cols):
@@ -180,11 +180,19 @@ def test_defocus_automatic_path_survives_a_depth_that_is_no_depth(oracle):
     want = {id(d): oracle.defocus(orig, d, threads=min(8, oracle.max_threads())) for d in (crazy, sane)}
     c = rt.Context(0)
     try:
-        for depth in (crazy, crazy, sane):
+        assert c.get_option(rt.OPT_DEFOCUS_LAST_PATH) == 0
+        # which kernel the automatic choice launched is observable (RTDD_OPT_DEFOCUS_LAST_PATH): the tile kernel until a synchronisation
+        # has seen its "window beyond the region" flag, the table from then on, the tile kernel again once the option is set to 0 again
+        for depth, path in ((sane, 2), (crazy, 2), (crazy, 1), (sane, 1)):
             art = up(np.zeros_like(orig))
             c.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+            assert c.get_option(rt.OPT_DEFOCUS_LAST_PATH) == path, (path, c.get_option(rt.OPT_DEFOCUS_LAST_PATH))
             c.synchronize()
             assert np.array_equal(down(art), want[id(depth)])
+        c.set_option(rt.OPT_DEFOCUS_PATH, 0)
+        art = up(np.zeros_like(orig))
+        c.GPUSimulateDefocus(up(orig), up(sane), art, rows, cols); c.synchronize()
+        assert c.get_option(rt.OPT_DEFOCUS_LAST_PATH) == 2 and np.array_equal(down(art), want[id(sane)])
     finally:
         c.close()
 
