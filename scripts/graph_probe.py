@@ -27,3 +27,23 @@ with torch.cuda.stream(s):
     for _ in range(50): g.replay()
     s.synchronize(); graph = (time.perf_counter() - t) / 50
     print(f"{cols}x{rows}: eager {eager*1e3:.3f} ms, graph replay {graph*1e3:.3f} ms")
+    # the two coarsest levels on their own (the launch loops of k_sweep_col: 36 and 21 launches): eager against a captured graph
+    for lr, lc, it in ((67, 120, 1000), (135, 240, 500)):
+        q = make_problem(lr, lc, seed=7)
+        c2 = rt.Context(0); c2.set_stream(s.cuda_stream); c2.GPULoadWeights(0.4); c2.GPUAllocateDeviceMemory(lr, lc, 1)
+        d, m, gr = rt.device_image(q["depth"]), rt.device_image(q["mask"]), rt.device_image(q["gray"])
+        f = lambda: c2.GPUMatrixFreeSolver(d, m, gr, lr, lc, 0.4, it, 0.0, 0)
+        for _ in range(3): f()
+        s.synchronize(); t = time.perf_counter()
+        for _ in range(100): f()
+        s.synchronize(); eager = (time.perf_counter() - t) / 100
+        info = c2.last_solve_info()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=s):
+            f()
+        for _ in range(3): g2.replay()
+        s.synchronize(); t = time.perf_counter()
+        for _ in range(100): g2.replay()
+        s.synchronize(); graph = (time.perf_counter() - t) / 100
+        print(f"{lc}x{lr} x {it} sweeps ({info.launches} launches of tile {info.tile}, {info.temporal_depth} sweeps each): eager {eager*1e6:.1f} us, graph replay {graph*1e6:.1f} us")
+        c2.synchronize(); c2.close()

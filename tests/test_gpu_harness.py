@@ -1,6 +1,8 @@
 """The C++ headless harness (harness/rtdd_harness, host code over the C ABI) end to end on a golden crop (-m gpu)."""
+import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -161,3 +163,67 @@ def test_plain_c_program_drives_an_estimate(tmp_path):
                            os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-L" + lib_dir, "-lrtdd", "-Wl,-rpath," + lib_dir])
     out = subprocess.check_output([exe], text=True)
     assert "c_abi_smoke ok" in out, out
+
+
+def test_no_state_leaks_between_contexts_of_one_device(tmp_path):
+    """Several contexts on ONE device, first inside one process, interleaved -- a context that has healed a time-out (persistence off,
+    status word set and cleared), one whose defocus went to the table after a depth that is no depth, one with forced options -- must
+    leave a bystander context's flag epoch, options, counters and BITS alone; then, as a process tree, the harness with --devices 1
+    --batch 8 and bench.py --gpus 1 on a fixed batch, back to back, each verified (one context + stream per GPU, nothing
+    shared but the device)."""
+    import oracle
+    import realtimedepthdiffusion_amd as rt
+    from gpu_util import assert_bit_equal, down, up
+    from realtimedepthdiffusion_amd.synth import make_problem
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=21)
+    lut = oracle.load_weights(0.4)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 48, 0, 0, lut, 1, threads=oracle.max_threads())
+    m, g = up(p["mask"]), up(p["gray"])
+    rgb = np.random.default_rng(3).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    blur = oracle.defocus(rgb, want, threads=oracle.max_threads())
+
+    def check(c, what):
+        d = up(p["depth"])
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 48, 0.0, 0)
+        art = up(np.zeros_like(rgb))
+        c.GPUSimulateDefocus(up(rgb), d, art, rows, cols)
+        c.synchronize()
+        i = c.last_solve_info()
+        assert (i.persistent, c.get_option(rt.OPT_PERSISTENT), c.get_option(rt.OPT_TIMEOUT_HEALS), c.get_option(rt.OPT_DEFOCUS_LAST_PATH)) == (1, 1, 0, 2), (what, i.describe())
+        assert_bit_equal(down(d), want, what)
+        assert np.array_equal(down(art), blur), what
+
+    with rt.Context(0) as a, rt.Context(0) as b, rt.Context(0) as c3:
+        for c in (a, b, c3):
+            c.GPUAllocateDeviceMemory(rows, cols, 1); c.GPULoadWeights(0.4)
+        check(a, "bystander, before")
+        # b: a timed-out persistent launch, healed
+        b.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); b.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 5)
+        d = up(p["depth"]); b.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 48, 0.0, 0)
+        d_a = up(p["depth"]); a.GPUMatrixFreeSolver(d_a, m, g, rows, cols, 0.4, 48, 0.0, 0)          # queued while b's launch is failing
+        b.synchronize(); a.synchronize()
+        assert b.get_option(rt.OPT_TIMEOUT_HEALS) == 1 and b.get_option(rt.OPT_PERSISTENT) == 0
+        assert_bit_equal(down(d), want, "the healed context"); assert_bit_equal(down(d_a), want, "the bystander, during")
+        # c3: defocus sent to the table by a depth that is no depth; a forced status 2 reported
+        crazy = up(np.full((rows, cols), 3.0e5, np.float32)); art = up(np.zeros_like(rgb))
+        c3.GPUSimulateDefocus(up(rgb), crazy, art, rows, cols); c3.synchronize()
+        c3.GPUSimulateDefocus(up(rgb), crazy, art, rows, cols); c3.synchronize()
+        assert c3.get_option(rt.OPT_DEFOCUS_LAST_PATH) == 1
+        c3.set_option(rt.OPT_DEBUG_FORCE_STATUS, 2)
+        d3 = up(p["depth"]); c3.GPUMatrixFreeSolver(d3, m, g, rows, cols, 0.4, 48, 0.0, 0)
+        with pytest.raises(rt.RtddError):
+            c3.synchronize()
+        check(a, "bystander, after")
+    # the same as a process tree: the harness's batch, then the bench's, on the same device
+    gl = load(NAMES[1])
+    _write_pnm(tmp_path / "img.ppm", gl["bgr"][..., ::-1]); _write_pnm(tmp_path / "ann.pgm", gl["annotation"])
+    out = subprocess.check_output([BIN, "-i", str(tmp_path / "img.ppm"), "-a", str(tmp_path / "ann.pgm"), "-o", str(tmp_path) + "/", "--devices", "1", "--batch", "8", "--write-all"], text=True)
+    assert "8 estimate(s) on 1 device(s)" in out
+    single = _oracle_cascade(gl).depth_u8
+    for n in range(8):
+        assert np.array_equal(_read_pnm(tmp_path / f"DepthMap_{n}.pgm"), single), n
+    line = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "batch8_270x480x200", "--steps", "2", "--warmup", "1",
+                                    "--no-cpu-baseline", "--verify"], text=True, stderr=subprocess.DEVNULL).strip().splitlines()[-1]
+    v = json.loads(line)["verified"]
+    assert v["images_differing_all_ranks"] == 0 and len(v["rank0_images"]) == 8, v
