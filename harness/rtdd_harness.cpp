@@ -5,6 +5,7 @@
 // with plain files instead of windows:
 //     -i image.ppm  -a annotation.pgm      (main.cpp:81-90; binary PPM/PGM instead of JPEG/PNG)
 //     key 'd'  -> one depth estimate        (main.cpp:232-295)  -> <out>DepthMap.pgm     (main.cpp:306-310)
+//     key 's'  -> also the annotated image   (main.cpp:298-303)  -> <out>AnnotatedImage.ppm: the image with the scribbles painted in
 //     key 'b'/'g'/'h' -> --effect defocus|desaturation|haze     -> <out>ArtisticEffect.ppm (main.cpp:190-230, 312-316)
 //     key 't'  -> prints "Processing Time"  (main.cpp:320-322; wall clock here, the reference uses clock())
 //     --paint x,y,label,radius  = a mouse drag sample (main.cpp:46-62), repeatable
@@ -155,7 +156,7 @@ struct Job {
 
 // One GPU: context + stream + device staging, runs `count` estimates; keeps the last result on the host.
 static int run_device(int device, const Job &job, int count, bool live, std::vector<unsigned char> *depth_u8, std::vector<unsigned char> *art, double *ms_per_estimate,
-                      std::vector<std::vector<unsigned char>> *every_map = nullptr) {
+                      std::vector<std::vector<unsigned char>> *every_map = nullptr, std::vector<unsigned char> *annotated = nullptr) {
     // everything this function owns, released on EVERY return path (the CK() early returns included)
     struct Owned {
         rtdd_ctx *ctx = nullptr; hipStream_t stream = nullptr; unsigned char *d_bgr = nullptr, *d_ann = nullptr;
@@ -212,6 +213,7 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
         }
         for (int f = count > 2 ? count - 2 : 0; f < count; f++) { CK(rtdd_live_wait(ctx)); landed(f); }
         *ms_per_estimate = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (count > 0 ? count : 1);
+        if (annotated) { annotated->resize((size_t)rows * cols * 3); CK(rtdd_download(ctx, annotated->data(), (size_t)cols * 3, p_ed, pi_ed, (size_t)cols * 3, rows)); }
         CK(rtdd_ctx_synchronize(ctx));
         return RTDD_OK;
     }
@@ -248,7 +250,8 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
         if (every_map) every_map->push_back(*depth_u8);                 // --write-all: the n-th estimate of this device
     }
     *ms_per_estimate = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (count > 0 ? count : 1);
-    CK(rtdd_ctx_synchronize(ctx));                                      // also reports a persistent launch that gave up (RTDD_ERR_TIMEOUT)
+    if (annotated) { annotated->resize((size_t)rows * cols * 3); CK(rtdd_download(ctx, annotated->data(), (size_t)cols * 3, p_ed, pi_ed, (size_t)cols * 3, rows)); }   // editedImage[0], main.cpp:298-303
+    CK(rtdd_ctx_synchronize(ctx));                                      // (a persistent launch that gave up has been healed by now: include/rtdd.h RTDD_ERR_TIMEOUT)
     return RTDD_OK;
 }
 
@@ -299,7 +302,7 @@ int main(int argc, const char *argv[]) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { std::printf("no HIP device: %s\n", rtdd_status_string(RTDD_ERR_NO_DEVICE)); return 3; }
     if (devices > ndev) devices = ndev;
 
-    std::vector<std::vector<unsigned char>> depth(devices), art(devices);
+    std::vector<std::vector<unsigned char>> depth(devices), art(devices), annotated(devices);
     std::vector<std::vector<std::vector<unsigned char>>> every(devices);   // [device][n-th estimate on it]: image b = n * devices + device
     std::vector<double> ms(devices, 0.0);
     std::vector<int> rcs(devices, 0), counts(devices, 0);
@@ -308,7 +311,7 @@ int main(int argc, const char *argv[]) {
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     for (int d = 0; d < devices; d++)
-        th.emplace_back([&, d]() { rcs[d] = counts[d] ? run_device(d, job, counts[d], live > 0, &depth[d], &art[d], &ms[d], write_all ? &every[d] : nullptr) : 0; });
+        th.emplace_back([&, d]() { rcs[d] = counts[d] ? run_device(d, job, counts[d], live > 0, &depth[d], &art[d], &ms[d], write_all ? &every[d] : nullptr, d == 0 ? &annotated[0] : nullptr) : 0; });
     for (auto &t : th) t.join();
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (int d = 0; d < devices; d++) if (rcs[d]) return 4;
@@ -319,6 +322,11 @@ int main(int argc, const char *argv[]) {
     if (live > 0 && job.effect.empty() && job.refine.empty())
         std::printf("Live: %.1f frames/s (%d frames, annotation upload + estimate + map download per frame, two frames in flight)\n", 1e3 / (ms[0] > 0 ? ms[0] : 1), live);
     if (!write_image(out + (png ? "DepthMap.png" : "DepthMap.pgm"), rgb.w, rgb.h, 1, depth[0].data())) { std::printf("cannot write %sDepthMap\n", out.c_str()); return 5; }
+    {                                                                    // main.cpp:298-303: editedImage[0] -- the image with the scribbles in it
+        std::vector<unsigned char> o(annotated[0]);
+        for (size_t i = 0; i + 2 < o.size(); i += 3) { o[i] = annotated[0][i + 2]; o[i + 2] = annotated[0][i]; }     // BGR -> RGB for the file
+        if (!o.empty() && !write_image(out + (png ? "AnnotatedImage.png" : "AnnotatedImage.ppm"), rgb.w, rgb.h, 3, o.data())) return 5;
+    }
     if (!job.effect.empty()) {
         std::vector<unsigned char> o(art[0]);
         for (size_t i = 0; i < o.size(); i += 3) { o[i] = art[0][i + 2]; o[i + 2] = art[0][i]; }     // BGR -> RGB for the file

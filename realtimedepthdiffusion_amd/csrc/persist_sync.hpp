@@ -21,12 +21,9 @@
 
 namespace rtdd {
 
-#ifndef RTDD_FLAG_STRIDE
-#define RTDD_FLAG_STRIDE 64
-#endif
 // kSyncFlagStride: ints between the flags of consecutive tiles.  64 = one flag per 256 bytes (its own line, and neighbouring tiles on different memory channels): a tile's flag is stored once and polled
 // by up to 8 neighbours, all through memory (sc1); packed 32 to a line (round 2) every store and poll of 32 tiles met on one line: 1080p 1.17 -> 1.24 Tpx-it/s with one line each, +1.5 % more at 256 bytes.
-constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncNonLocal = 3 /* k_defocus_tile met windows beyond its region (effect_kernels.hip) */, kSyncFailedSeq = 4, kSyncFlags = 32, kSyncMaxTiles = 1024, kSyncFlagStride = RTDD_FLAG_STRIDE;
+constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncNonLocal = 3 /* k_defocus_tile met windows beyond its region (effect_kernels.hip) */, kSyncFailedSeq = 4, kSyncFlags = 32, kSyncMaxTiles = 1024, kSyncFlagStride = 64;
 constexpr int kSyncWords = kSyncFlags + kSyncMaxTiles * kSyncFlagStride;              // size of sync_words in ints
 constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: legitimate waits are microseconds
 
@@ -45,33 +42,26 @@ __device__ __forceinline__ bool solve_is_dead(int *sync_words, int seq, bool fir
 // Called by EVERY thread of the workgroup after its payload stores are drained (s_waitcnt vmcnt(0)) and a __syncthreads().
 // Publishes this tile's counter, waits for the up-to-8 neighbouring tiles' counters, makes their payload visible (one agent
 // acquire by wave 0) and ends with a __syncthreads().  Returns true when the launch is dead (see kSyncStatus): the caller
-// leaves.  `dead_lds` is a __shared__ int, zero at kernel start; `seen_lds` a __shared__ int set to the launch's flag base at kernel start.
+// leaves.  `dead_lds` is a __shared__ int, zero at kernel start.
 // Protocol (cdna_hip_programming.md Guideline 16, R1): write-through (sc1) payload stores; EVERY storing wave drains vmcnt;
 // workgroup barrier; ONE lane stores the flag (agent-scope atomic); 8 lanes poll the neighbours' flags relaxed with s_sleep;
 // ONE agent acquire; barrier; plain vector loads.
 template <bool ACQUIRE = true>
-__device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, int *seen_lds, int tid, int tile_id, int bx, int by, int gx, int gy, int value) {
+__device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, int tid, int tile_id, int bx, int by, int gx, int gy, int value) {
     int *flags = sync_words + kSyncFlags;
     if (tid == 0 && __hip_atomic_load(&sync_words[kSyncWithhold], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tile_id + 1)
         __hip_atomic_store(&flags[tile_id * kSyncFlagStride], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifndef RTDD_POLL_WAVES
-#define RTDD_POLL_WAVES 1
-#endif
-    // Lane i (of 9, i != 4) of a polling wave polls neighbour (i%3-1, i/3-1).  A poll is a round trip to memory (the flag was stored
-    // sc1: it is in no L2), so a flag that lands just behind a poll is seen a whole trip later: RTDD_POLL_WAVES waves poll, each
-    // started a fraction of a trip after the one before, and the first that has seen all its neighbours tells the others through
-    // `*dead_lds`'s neighbour word in LDS (`seen_lds`, monotonic like the flags).
+    // Lane i (of 9, i != 4) of wave 0 polls neighbour (i%3-1, i/3-1).  A poll is a round trip to memory (the flag was stored sc1: it is in
+    // no L2).  (Several polling waves, each started a fraction of a trip after the one before and the first to see all its neighbours
+    // telling the others through LDS, measured no faster: EXPERIMENTS.md.)
     const int pw = tid >> 6, pl = tid & 63;
-    constexpr int kPollWaves = RTDD_POLL_WAVES;
-    if (pw < kPollWaves && pl < 9 && pl != 4) {
+    if (pw == 0 && pl < 9 && pl != 4) {
         const int nx = bx + pl % 3 - 1, ny = by + pl / 3 - 1;
         if (nx >= 0 && ny >= 0 && nx < gx && ny < gy) {
             const int nb = ny * gx + nx;
             unsigned long long t0 = 0, limit = 0;
             unsigned spins = 0;
-            for (int i = 0; i < pw; i++) __builtin_amdgcn_s_sleep(12);  // stagger: ~0.35 us per wave
             while (__hip_atomic_load(&flags[nb * kSyncFlagStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value < 0) {
-                if (kPollWaves > 1 && __hip_atomic_load(seen_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - value >= 0) break;   // another wave has seen them all
                 __builtin_amdgcn_s_sleep(4);
                 if ((++spins & 63u) == 0) {                              // every 64 polls (tens of microseconds): clock and status word
                     const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -90,7 +80,6 @@ __device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, in
             }
         }
     }
-    if (kPollWaves > 1 && pw < kPollWaves && pl == 0) __hip_atomic_store(seen_lds, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (its lanes are through: by their own polls or told so)
     // ACQUIRE = false: the caller reads the handed-off bytes with 16-byte sc1 loads only (MI355X_MICROARCH.md, "Valid forms": the
     // polling wave after its poll has matched, the other waves after the barrier below)
     if (ACQUIRE && tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -62,7 +62,6 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
     __shared__ float4 edge[2][NTR][2][LX];
     __shared__ int published[NT / 64];
     __shared__ int dead_s;                     // the launch has failed (persist_sync.hpp): leave
-    __shared__ int seen_s;                     // exchange_wait: the newest flag value some polling wave has seen at all its neighbours
 
     // XCD-aware placement as in sweep_blocked.hip: workgroup p (on XCD p % 8) takes tile (p % 8) * xcd_tiles + p / 8
     int bx = blockIdx.x, by = blockIdx.y;
@@ -74,7 +73,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
     const int tid = threadIdx.x;
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
     if (tid < NT / 64) published[tid] = 0;
-    if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; seen_s = flag_base; }
+    if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
     __syncthreads();
     if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
 
@@ -213,17 +212,10 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
             }
         };
         // (first / last rows at a raised wave priority, as k_sweep_blocked: sweep_tile_sweeps.inc)
-#ifndef RTDD_RB_PRIO
-#define RTDD_RB_PRIO 1
-#endif
-#if RTDD_RB_PRIO
-        __builtin_amdgcn_s_setprio(RTDD_RB_PRIO);
-#endif
+        __builtin_amdgcn_s_setprio(1);
         group([](int g) { return g == 0 || g == G - 1; });
         if (!last_of_block) publish(h + 1, C ^ 1);
-#if RTDD_RB_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
         group([](int g) { return g != 0 && g != G - 1; });
     };
 
@@ -262,7 +254,7 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
 #ifndef RTDD_EXCHANGE_ACQUIRE
 #define RTDD_EXCHANGE_ACQUIRE 0      // 1: one agent-scope acquire by wave 0 and plain vector loads (the fallback form; built and tested once per round: tests/test_isa_hazards.py, scripts/build_variant.sh)
 #endif
-        if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, &seen_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, (acquire,) barrier (persist_sync.hpp)
+        if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, (acquire,) barrier (persist_sync.hpp)
 #if RTDD_EXCHANGE_ACQUIRE
 #pragma unroll
         for (int g = 0; g < G; g++) {

@@ -27,6 +27,7 @@
 #include "rtdd_internal.hpp"
 #include "persist_sync.hpp"
 #include "sweep_common.hpp"
+#include "sweep_diag.hpp"      // RTDD_STAMP / RTDD_TL / RTDD_XT: empty unless a diagnostic micro-benchmark asks for them
 
 namespace rtdd {
 
@@ -41,9 +42,6 @@ __device__ __forceinline__ float relax(float xl, float xr, float xu, float xd, f
     sum = CONTRACT ? __builtin_fmaf(wu, xu, sum) : sum + wu * xu;
     sum = CONTRACT ? __builtin_fmaf(wd, xd, sum) : sum + wd * xd;
     float r;                                   // cnt == 0 was replaced by 1 (sum is 0 there): r = 0 (:103)
-#ifdef RTDD_DIAG_NODIV        // (diagnostic ablation: timing only)
-    if (true) { r = sum * rcp; } else
-#endif
     if (FAST) {
         r = div_tail(sum, cnt, rcp);
         const bool tiny = __builtin_fabsf(sum) < 0x1p-100f && sum != 0.0f;
@@ -62,33 +60,6 @@ __device__ __forceinline__ float relax(float xl, float xr, float xu, float xd, f
 // Register budget: a G = 4 thread holds 6 x 16 + 8 live values; capping it at 128 VGPRs spills into the
 // sweep loop (measured 25 % slower), so G = 4 tiles ask for 3 waves/SIMD (168 VGPRs) unless the
 // workgroup is 1024 threads (which needs 4 waves/SIMD to be launchable at all).  G <= 3 fits 128.
-#ifdef RTDD_STAMPS   // diagnostic build only (scripts/ubench/blocked_phases.hip): per-workgroup phase timestamps
-__device__ unsigned long long g_stamps[4096][4];
-// k = 0: earliest wave (atomicMin would need init; wave 0 starts first in practice); k >= 1: LATEST wave of the workgroup
-// (atomicMax) -- without a barrier the oldest wave of each SIMD runs ahead, so stamping only wave 0 under-reports.
-#define RTDD_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) { \
-        if ((k) == 0) { if (threadIdx.x == 0) g_stamps[blockIdx.y * gridDim.x + blockIdx.x][0] = __builtin_amdgcn_s_memrealtime(); } \
-        else atomicMax(&g_stamps[blockIdx.y * gridDim.x + blockIdx.x][k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } while (0)
-#else
-#define RTDD_STAMP(k) do {} while (0)
-#endif
-#ifdef RTDD_TIMELINE   // diagnostic build only (scripts/ubench/sweep_timeline.hip): per-wave, per-sweep s_memtime stamps of ONE workgroup
-__device__ unsigned long long g_tl[16][64][4];      // [wave][sweep][0 top of sweep, 1 neighbours' rows in hand, 2 own edge rows published, 3 end]
-__device__ int g_tl_tile = 100;
-#define RTDD_TL(k, sw) do { if (tile_id_tl == g_tl_tile && (threadIdx.x & 63) == 0 && (sw) < 64) g_tl[threadIdx.x >> 6][(sw)][k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define RTDD_TL(k, sw) do {} while (0)
-#endif
-#ifdef RTDD_STAMPS
-__device__ unsigned long long g_xphase[4096][6];
-#define RTDD_XT(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); g_xphase[blockIdx.y * gridDim.x + blockIdx.x][k] += t_ - xt_; xt_ = t_; } } while (0)
-#define RTDD_XT_BEGIN unsigned long long xt_ = __builtin_amdgcn_s_memrealtime()
-#else
-#define RTDD_XT(k) do {} while (0)
-#define RTDD_XT_BEGIN do {} while (0)
-#endif
-
-
 template <int LX, int NT, int G, bool CONTRACT, bool PERSIST>
 __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) void k_sweep_blocked(float *Xk, float *Xm, float *Yk, float *Ym,
                                                       const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
@@ -104,7 +75,6 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     __shared__ float4 edge[2][NTR][2][LX];     // [buffer][thread row][0 = its top row, 1 = its bottom row][lane]
     __shared__ int published[NT / 64 + 1];     // per wave: number of sweeps whose edge rows it has published; [NT/64]: the maximum over the waves
     __shared__ int dead_s;                     // the launch has failed (persist_sync.hpp): leave
-    __shared__ int seen_s;                     // exchange_wait: the newest flag value some polling wave has seen at all its neighbours
 
     // (gx, gy) = the grid of tiles.  xcd_tiles > 0 (every multi-tile launch): a 1-D launch of 8 * xcd_tiles workgroups in which
     // workgroup p -- dispatched to XCD p % 8 -- takes tile number (p % 8) * xcd_tiles + p / 8, so that each XCD owns a run
@@ -119,13 +89,8 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     RTDD_STAMP(0);
     // Tile load and setup at a raised wave priority: where two workgroups share a CU (4K, 8K) the one that has just arrived gets through
     // its loads, table gathers and reciprocals ahead of the other one's sweeps and joins them sooner (4K +2.7 %, 8K +2.3 %; levels 1-3:
-    // the same; the write-back at a raised priority too: no more).  RTDD_SETUP_PRIO=0 turns it off.
-#ifndef RTDD_SETUP_PRIO
-#define RTDD_SETUP_PRIO 2
-#endif
-#if RTDD_SETUP_PRIO
-    __builtin_amdgcn_s_setprio(RTDD_SETUP_PRIO);
-#endif
+    // the same; the write-back at a raised priority too: no more).
+    __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x;
     const int lx = tid % LX, tr = tid / LX;
     const int ntr = (int)blockDim.x / LX;          // thread rows actually launched (blockDim.x <= NT: small levels launch only the thread rows they need)
@@ -160,16 +125,14 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     if (colok && y0 - 1 >= 0 && y0 < rows) mup = *(const uint4 *)(M + (size_t)(y0 - 1) * ip + x0);     // the row above the block: its down-weights
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
     if (tid <= NT / 64) published[tid] = 0;
-    if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; seen_s = flag_base; }
+    if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
     __syncthreads();
     if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
 
 #include "sweep_tile_setup.inc"       // vxr / vpr / mr / mup -> a, b, weights, divisors, reciprocals
 
     RTDD_STAMP(1);
-#if RTDD_SETUP_PRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
     // ---- n sweeps in registers -------------------------------------------------------------------
     // One sweep, written for instruction-level parallelism: the weighted sums and quotients of a GROUP of rows first (12 independent
     // 7-deep chains the scheduler can interleave -- a wave alone on its SIMD issues a dependent VALU instruction only every ~6.6 cycles,
@@ -247,7 +210,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 #ifndef RTDD_EXCHANGE_ACQUIRE
 #define RTDD_EXCHANGE_ACQUIRE 0
 #endif
-            if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, &seen_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, (acquire,) barrier
+            if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, (acquire,) barrier
             RTDD_XT(2);
             RTDD_XT(3);
 #if RTDD_EXCHANGE_ACQUIRE
@@ -327,13 +290,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
             store_result((float4 *)(Ym + off), vm);
         }
     }
-#if RTDD_STORE_MODE == 2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#ifdef RTDD_STAMPS
-    __builtin_amdgcn_s_waitcnt(0);
-    RTDD_STAMP(3);
-#endif
+    RTDD_STAMP_LAST(3);
 }
 
 // ---- the same sweeps in a COLUMN layout (tile 14): a thread owns 1 pixel x 4 rows --------------------------------------------
@@ -454,10 +411,7 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
                 if (gone) { up = 0.0f; dn = 0.0f; }
             }
         }
-#ifdef RTDD_TIMELINE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-        RTDD_TL(1, s);
+        RTDD_TL_ROWS_IN_HAND(s);
         const float omega = omegas[s], gamma_v = gamma;     // (scalar operands: the vector form measured no faster, see k_sweep_blocked)
         // (the lane shifts stay DPP here: through the LDS crossbar -- 8 ds_bpermute_b32 per thread and sweep, as k_sweep_blocked does with
         // its 2 per row -- the coarse levels measured 20 % SLOWER, and with no shifts at all (timing only) no faster: EXPERIMENTS.md)
@@ -503,18 +457,11 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
         };
         // The rows the neighbouring waves wait for are computed at a raised wave priority and the interior rows at the normal one: the
         // chain read -> first / last row -> publish is what a sweep of these small levels waits on, and with four waves per SIMD the
-        // arbiter otherwise gives a wave's interior rows the same share (estimate 1.145 -> 1.119 ms; RTDD_COL_PRIO=0 turns it off).
-#ifndef RTDD_COL_PRIO
-#define RTDD_COL_PRIO 1
-#endif
-#if RTDD_COL_PRIO
-        __builtin_amdgcn_s_setprio(RTDD_COL_PRIO);
-#endif
+        // arbiter otherwise gives a wave's interior rows the same share (estimate 1.145 -> 1.119 ms).
+        __builtin_amdgcn_s_setprio(1);
         pair(0, R - 1);
         if (!last) publish(buf ^ 1, oth[0], oth[R - 1], s + 2);
-#if RTDD_COL_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
         RTDD_TL(2, s);
         pair(1, 2);
         RTDD_TL(3, s);
@@ -681,14 +628,10 @@ static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fi
         fprintf(stderr, "[rtdd] %dx%d n=%d -> tile %d depth %d persistent %d (model %.3f us/sweep)\n", cols, rows, n, *tile, *T, (int)*persist, best);
 }
 
-#ifdef RTDD_EXP_ONE_TILE   // (compile-time experiments: -DRTDD_EXP_ONE_TILE='RTDD_TILE_CASE(4, 32, 1024, 3)' builds one instantiation in seconds)
-#define RTDD_ALL_TILES RTDD_EXP_ONE_TILE
-#else
 #define RTDD_ALL_TILES \
     RTDD_TILE_CASE(1, 16, 256, 4) RTDD_TILE_CASE(2, 32, 512, 4) RTDD_TILE_CASE(3, 32, 1024, 4) RTDD_TILE_CASE(4, 32, 1024, 3) RTDD_TILE_CASE(5, 32, 512, 3) \
     RTDD_TILE_CASE(6, 16, 512, 3) RTDD_TILE_CASE(7, 16, 256, 3) RTDD_TILE_CASE(8, 32, 1024, 2) RTDD_TILE_CASE(9, 16, 1024, 1) RTDD_TILE_CASE(10, 16, 512, 2) \
     RTDD_TILE_CASE(11, 32, 1024, 1) RTDD_TILE_CASE(12, 32, 768, 4) RTDD_TILE_CASE(13, 32, 512, 6)
-#endif
 
 // Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
 // holding x_{k+n} / x_{k+n-1}.  omegas_dev[0..n) must already be on the device.

@@ -45,21 +45,8 @@ __device__ __forceinline__ void load_sc1(f4v_t &dst, const float *p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(dst) : "v"(p) : "memory");
 }
 
-// Result stores.  RTDD_STORE_MODE (diagnostic knob): 0 plain, 1 non-temporal, 2 write-through (sc1).
-#ifndef RTDD_STORE_MODE
-#define RTDD_STORE_MODE 0
-#endif
-__device__ __forceinline__ void store_result(float4 *p, float4 v) {
-#if RTDD_STORE_MODE == 1
-    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
-#elif RTDD_STORE_MODE == 2
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const f4v t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
-#else
-    *p = v;
-#endif
-}
+// Result stores: plain (non-temporal and write-through stores measured no faster: EXPERIMENTS.md).
+__device__ __forceinline__ void store_result(float4 *p, float4 v) { *p = v; }
 
 // ---- IEEE f32 division with a loop-invariant divisor ---------------------------------------------
 // `sum / cnt` must be the correctly rounded quotient (the reference relies on nvcc's default

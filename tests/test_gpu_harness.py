@@ -117,6 +117,7 @@ def test_harness_batch_and_paint(tmp_path):
     d3 = _read_pnm(tmp_path / "DepthMap.pgm")
     want = _oracle_cascade(g, paints=paints, annotation=False, estimates=1, iters=200)
     assert np.array_equal(d3, want.depth_u8)
+    assert np.array_equal(_read_pnm(tmp_path / "AnnotatedImage.ppm"), want.edited[0][..., ::-1])       # main.cpp:298-303: editedImage[0] (BGR in memory)
     assert d3[40, 40] == 0 and d3[180, 200] == 254
     subprocess.check_output(args + ["--batch", "1"], text=True)
     assert np.array_equal(_read_pnm(tmp_path / "DepthMap.pgm"), d3)
