@@ -44,13 +44,16 @@ WORKLOADS = {
     "1080p_rbsor_1e-4": dict(rows=1080, cols=1920, iters=400000, method="sor_cycles", tolerance=1e-4),
     "8k_multigrid_1e-4": dict(rows=4320, cols=7680, iters=200, method="multigrid", tolerance=1e-4),
     "1080p_multigrid_1e-4": dict(rows=1080, cols=1920, iters=200, method="multigrid", tolerance=1e-4),
+    # RTDD_METHOD_AUTO: V-cycles while they pay, then SOR cycles -- the documented entry point for config 5 (V-cycles alone stall on photographs)
+    "8k_auto_1e-4": dict(rows=4320, cols=7680, iters=400000, method="auto", tolerance=1e-4),
+    "1080p_auto_1e-4": dict(rows=1080, cols=1920, iters=400000, method="auto", tolerance=1e-4),
 }
 # Algorithmic HBM bytes per pixel-sweep: Chebyshev-Jacobi 17 (x_k 4 + x_{k-1} 4 + x_{k+1} 4 + 4 weight indices 4 + mask 1);
 # red-black 13 (no x_{k-1}).  A V(2,2) cycle is counted as its 4 level-0 red-black sweeps for `value`; its algorithmic traffic per image
 # pixel is: level 0 -- 4 sweeps 52 + residual 13 (x 4, indices 4, mask 1, r 4) + restriction 20 (r 4, weights 16) + prolongation 24
 # (weights 16, x read+write 8) = 109 B; the coarse levels hold 1/3 as many points, each 4 sweeps x 48 (9 coefficients 36, e 8, b 4) +
 # residual 48 + restriction 20 + prolongation 24 = 284 B -> 95 B per image pixel; 204 B per cycle = 51 B per counted sweep.
-ALGO_BYTES = {"jacobi": 17.0, "rbgs": 13.0, "sor_cycles": 13.0, "multigrid": 51.0}
+ALGO_BYTES = {"jacobi": 17.0, "rbgs": 13.0, "sor_cycles": 13.0, "multigrid": 51.0, "auto": 13.0}
 MG_SWEEPS_PER_CYCLE = 4
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # VALU roof: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md chip table) = 78.6 T lane-operations/s (= 157.3 TFLOP/s / 2).
@@ -200,6 +203,45 @@ def estimate_ms(rt, ctx, p, rows, cols, dev, n=20):
             "live_ms_per_frame": ms_live, "live_fps": 1e3 / ms_live, "live_is": "the same frames, two in flight: copies on a second stream overlap the other frame's arithmetic (rtdd_live_submit)"}
 
 
+def photo_problem(rows, cols):
+    """A photograph-like problem of any size: the bundled Dog pair (tests/golden/Dog_full.npz: 672 x 624, decoded) tiled, every other
+    copy mirrored so that the seams are no edges.  Thin high-contrast structures at pixel scale -- what the synthetic images lack and
+    what stalls the V-cycle."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "Dog_full.npz"), allow_pickle=False)
+    bgr, ann = g["bgr"], g["annotation"]
+
+    def tile(a):
+        a2 = np.concatenate([a, a[:, ::-1]], 1); a4 = np.concatenate([a2, a2[::-1]], 0)
+        ry, rx = -(-rows // a4.shape[0]), -(-cols // a4.shape[1])
+        return np.ascontiguousarray(np.tile(a4, (ry, rx) + (1,) * (a.ndim - 2))[:rows, :cols])
+    bgr, ann = tile(bgr), tile(ann)
+    gray = ((bgr[..., 0].astype(np.int32) * 1868 + bgr[..., 1].astype(np.int32) * 9617 + bgr[..., 2].astype(np.int32) * 4899 + 8192) >> 14).astype(np.uint8)
+    mask = np.where(ann != 32, 255, 32).astype(np.uint8)                       # src/main.cpp:160-168
+    depth = np.where(ann != 32, ann, 255).astype(np.float32)
+    return {"gray": gray, "mask": mask, "depth": depth}
+
+
+def photo_record(rt, dev, rows, cols):
+    """The same residual-stopped solves on the photograph-like image, once each, cold start: plain V-cycles (capped at 60) and
+    RTDD_METHOD_AUTO -- so that the line shows what the synthetic image hides: where the V-cycle stalls and what the fall-back costs."""
+    import torch
+    p = photo_problem(rows, cols)
+    ctx = rt.Context(int(dev.split(":")[1])); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.GPUAllocateDeviceMemory(rows, cols, 1); ctx.GPULoadWeights(0.4)
+    m, g = rt.device_image(p["mask"], dev), rt.device_image(p["gray"], dev)
+    out = {"image": f"tests/golden/Dog_full.npz (672 x 624) tiled with mirroring to {cols}x{rows}, scribbles on {float((p['mask'] == 255).mean()) * 100:.1f} % of the pixels"}
+    for name, method, cap in (("multigrid_60_cycles", rt.METHOD_MULTIGRID, 60), ("auto", rt.METHOD_AUTO, 400000)):
+        d = rt.device_image(p["depth"], dev)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        its, res = ctx.solve_ex(d, m, g, rows, cols, 0, method=method, maxIterations=cap, tolerance=1e-4)
+        ctx.synchronize()
+        out[name] = {"ms": (time.perf_counter() - t) * 1e3, "cycles": ctx.last_cycles, "sweeps": its if method == rt.METHOD_AUTO else 0,
+                     "residual": float(res), "converged": bool(res <= 1e-4)}
+    ctx.close()
+    return out
+
+
 def valu_roofline(px_sweeps_per_s, method):
     ops = VALU_OPS.get(method)
     if ops is None:
@@ -312,7 +354,7 @@ def main():
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--persistent", type=int, default=-1)
-    ap.add_argument("--method", default=None, choices=["jacobi", "rbgs", "sor_cycles", "multigrid"],
+    ap.add_argument("--method", default=None, choices=["jacobi", "rbgs", "sor_cycles", "multigrid", "auto"],
                     help="override the workload's method; everything but jacobi is an EXTENSION (not the headline)")
     ap.add_argument("--verify", action="store_true", help="after the timed region every rank compares the depth map of each of its images (last step) with the CPU oracle, bit for bit; "
                     "the line then carries `verified` (checker only: outside the timed region)")
@@ -370,7 +412,7 @@ def main():
     w = WORKLOADS[args.workload]
     rows, cols, iters = w["rows"], w["cols"], w["iters"]
     method = args.method or w.get("method", "jacobi")
-    tolerance = w.get("tolerance", 1e-4 if method in ("sor_cycles", "multigrid") else 0.0)
+    tolerance = w.get("tolerance", 1e-4 if method in ("sor_cycles", "multigrid", "auto") else 0.0)
     batch = w.get("batch", 0)
     # which images this rank owns: a fixed batch is dealt round-robin (strong scaling); otherwise one image per rank (weak)
     my_images = shard.images_for_rank(batch, world, rank) if batch else [rank]
@@ -409,6 +451,9 @@ def main():
                     executed.append(ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_RED_BLACK_GS, maxIterations=iters, tolerance=tolerance, relaxation=rt.RELAXATION_AUTO))
                 elif method == "multigrid":
                     executed.append(ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_MULTIGRID, maxIterations=iters, tolerance=tolerance))
+                elif method == "auto":                  # counted as the level-0 sweeps it ran: 4 per V-cycle + the SOR sweeps behind them
+                    its_, res_ = ctx.solve_ex(d, m, g, rows, cols, 0, method=rt.METHOD_AUTO, maxIterations=iters, tolerance=tolerance)
+                    executed.append((its_ + MG_SWEEPS_PER_CYCLE * ctx.last_cycles, res_, ctx.last_cycles))
                 else:
                     ctx.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, iters, 1e-5, 0)
 
@@ -470,7 +515,7 @@ def main():
     if info is not None:
         out["config"].update({"kernel": info.kernel, "tile": info.tile, "temporal_depth": info.temporal_depth, "persistent": info.persistent, "fp_contract": info.fp_contract})
         kname = {"jacobi": "k_sweep_blocked", "rbgs": "k_rbgs_blocked", "sor_cycles": "k_rbgs_blocked (+ residual checks)",
-                 "multigrid": "whole V(2,2) cycle, all levels: 204 B per image pixel and cycle"}[method]
+                 "multigrid": "whole V(2,2) cycle, all levels: 204 B per image pixel and cycle", "auto": "V(2,2) cycles, then k_rbgs_blocked"}[method]
         hbm_equivalent = {"achieved": hbm_eq, "peak": HBM_PEAK_GBS, "frac": hbm_eq / HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_pixel_sweep": algo_bytes,
                           "algorithmic_bytes_per_launch": algo_bytes * rows * cols * sweeps_per_launch,
                           "note": "what the sweeps would move through HBM one launch per sweep; with temporal blocking the tile stays in registers, so this can exceed 1 and is NOT the binding roof"}
@@ -527,6 +572,8 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=tgroup)
         out["verified"] = {"against": "oracle.solve, bit for bit" if method == "jacobi" else "(hash only: no fixed-count oracle for this method)", "images_differing_all_ranks": int(flag.item()),
                            "rank0_images": [my_images[k] for k in range(len(problems))], "rank0_sha256_16": shas}
+    if not dry and rank == 0 and world == 1 and method in ("multigrid", "auto"):
+        out["photograph_like"] = photo_record(rt, dev, rows, cols)             # outside the timed region
     if executed:
         out["config"]["converged"] = {"tolerance": tolerance, "iterations": [e[0] for e in executed], "unit": "cycles" if method == "multigrid" else "sweeps",
                                       "residual": max(e[1] for e in executed), "start": "cold (depth 255 + labels)"}
