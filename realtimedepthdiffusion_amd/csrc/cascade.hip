@@ -127,6 +127,79 @@ __global__ __launch_bounds__(256) void k_pyrup_inject(const float *__restrict__ 
 #undef SROW
 }
 
+// The same for the exact-doubling case (cv::cuda::pyrUp: every level pair of an even-sized cascade -- 1080p: three of its four), FOUR
+// output pixels per thread: the 4 source columns x 3 (2) source rows a group needs are loaded once (12 loads instead of 36), the
+// arithmetic per pixel is pyrup_cuda_h's operation for operation, the results leave as one 16-byte store, mask and edited image as
+// dwords.  1920 x 1080: 15.5 -> ~6 us.
+template <bool CONTRACT>
+__global__ __launch_bounds__(256) void k_pyrup_inject4(const float *__restrict__ src, size_t sp, int rows, int cols,
+                                                       float *__restrict__ dst, size_t dp, int drows, int dcols,
+                                                       const uint8_t *__restrict__ edited, size_t ep,
+                                                       const uint8_t *__restrict__ mask, size_t mp,
+                                                       float *__restrict__ coarse_out, size_t cp, int *sync_words, int seq) {
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;
+    if (x0 >= dcols || y >= drows) return;
+    const int c0 = x0 >> 1, cy = y >> 1;
+    const int ci[4] = {clamp_abs(c0 - 1, cols), clamp_abs(c0, cols), clamp_abs(c0 + 1, cols), clamp_abs(c0 + 2, cols)};
+    // horizontal pass of one source row for the four outputs (k = x0 .. x0 + 3: even, odd, even, odd)
+    auto hrow = [&](int r, float (&h)[4]) {
+        const float *s = (const float *)((const char *)src + (size_t)r * sp);
+        const float v0 = s[ci[0]], v1 = s[ci[1]], v2 = s[ci[2]], v3 = s[ci[3]];
+        float e0 = 0.0f, o0 = 0.0f, e1 = 0.0f, o1 = 0.0f;
+        if (CONTRACT) {
+            e0 = __builtin_fmaf(0.0625f, v0, e0); e0 = __builtin_fmaf(0.375f, v1, e0); e0 = __builtin_fmaf(0.0625f, v2, e0);
+            o0 = __builtin_fmaf(0.25f, v1, o0); o0 = __builtin_fmaf(0.25f, v2, o0);
+            e1 = __builtin_fmaf(0.0625f, v1, e1); e1 = __builtin_fmaf(0.375f, v2, e1); e1 = __builtin_fmaf(0.0625f, v3, e1);
+            o1 = __builtin_fmaf(0.25f, v2, o1); o1 = __builtin_fmaf(0.25f, v3, o1);
+        } else {
+            e0 = e0 + 0.0625f * v0; e0 = e0 + 0.375f * v1; e0 = e0 + 0.0625f * v2;
+            o0 = o0 + 0.25f * v1; o0 = o0 + 0.25f * v2;
+            e1 = e1 + 0.0625f * v1; e1 = e1 + 0.375f * v2; e1 = e1 + 0.0625f * v3;
+            o1 = o1 + 0.25f * v2; o1 = o1 + 0.25f * v3;
+        }
+        h[0] = e0; h[1] = o0; h[2] = e1; h[3] = o1;
+    };
+    float out[4];
+    if ((y & 1) == 0) {
+        float h0[4], h1[4], h2[4];
+        hrow(clamp_abs(cy - 1, rows), h0); hrow(clamp_abs(cy, rows), h1); hrow(clamp_abs(cy + 1, rows), h2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float sum = 0.0f;
+            if (CONTRACT) { sum = __builtin_fmaf(0.0625f, h0[i], sum); sum = __builtin_fmaf(0.375f, h1[i], sum); sum = __builtin_fmaf(0.0625f, h2[i], sum); }
+            else { sum = sum + 0.0625f * h0[i]; sum = sum + 0.375f * h1[i]; sum = sum + 0.0625f * h2[i]; }
+            out[i] = 4.0f * sum;
+        }
+        if (coarse_out) {               // the coarse level's caller-visible image on the side: fine pixels (x0, y) and (x0 + 2, y) store coarse (c0, cy), (c0 + 1, cy)
+            const float *s = (const float *)((const char *)src + (size_t)cy * sp);
+            float *q = (float *)((char *)coarse_out + (size_t)cy * cp);
+            q[c0] = s[c0]; q[c0 + 1] = s[c0 + 1];
+        }
+    } else {
+        float h1[4], h2[4];
+        hrow(clamp_abs(cy, rows), h1); hrow(clamp_abs(cy + 1, rows), h2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float sum = 0.0f;
+            if (CONTRACT) { sum = __builtin_fmaf(0.25f, h1[i], sum); sum = __builtin_fmaf(0.25f, h2[i], sum); }
+            else { sum = sum + 0.25f * h1[i]; sum = sum + 0.25f * h2[i]; }
+            out[i] = 4.0f * sum;
+        }
+    }
+    if (mask) {                         // GPUConvertToFloat fused in: Dirichlet pixels take their label (src/GPUImageProcessing.cu:19)
+        const uint32_t m4 = *(const uint32_t *)(mask + (size_t)y * mp + x0);
+        if (m4 & 0x80808080u) {         // (some byte >= 128: look closer; 255 is the only value that counts)
+            const uint32_t *e3 = (const uint32_t *)(edited + (size_t)y * ep + 3 * (size_t)x0);
+            const uint32_t w0 = e3[0], w1 = e3[1], w2 = e3[2];
+            const uint32_t lab[4] = {w0 & 255, w0 >> 24, (w1 >> 16) & 255, (w2 >> 8) & 255};      // channel 0 of pixels x0 .. x0 + 3
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (((m4 >> (8 * i)) & 255) == 255) out[i] = (float)lab[i];
+        }
+    }
+    *(float4 *)((char *)dst + (size_t)y * dp + 4 * (size_t)x0) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 // GpuMat::convertTo(CV_8UC1): saturate(round-half-even) -- src/main.cpp:290
 __global__ __launch_bounds__(256) void k_depth_to_u8(const float *__restrict__ src, size_t sp, uint8_t *__restrict__ dst, size_t dp, int rows, int cols) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -173,6 +246,14 @@ int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, in
     int *sw = guarded ? ctx->sync_words : nullptr;
     const int seq = ctx->guard_seq;
     if (coarse_out && (drows < 2 * rows || dcols < 2 * cols)) return fail(ctx, RTDD_ERR_INVALID, "pyrUp: the fine level must be at least twice the coarse one");
+    const bool doubling = drows == 2 * rows && dcols == 2 * cols && dcols % 4 == 0 && rows >= 2 && cols >= 2;
+    const bool aligned = (uintptr_t)dst % 16 == 0 && dp % 16 == 0 && (!mask || ((uintptr_t)mask % 4 == 0 && mp % 4 == 0 && (uintptr_t)edited % 4 == 0 && ep % 4 == 0));
+    if (doubling && aligned) {          // four pixels per thread
+        if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject4<true>, grid64x4(drows, dcols / 4), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
+        else hipLaunchKernelGGL(k_pyrup_inject4<false>, grid64x4(drows, dcols / 4), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
+        RTDD_LAUNCH_CHECK(ctx, "k_pyrup_inject4");
+        return RTDD_OK;
+    }
     if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject<true>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
     else hipLaunchKernelGGL(k_pyrup_inject<false>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
     RTDD_LAUNCH_CHECK(ctx, "k_pyrup_inject");
