@@ -572,7 +572,7 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=tgroup)
         out["verified"] = {"against": "oracle.solve, bit for bit" if method == "jacobi" else "(hash only: no fixed-count oracle for this method)", "images_differing_all_ranks": int(flag.item()),
                            "rank0_images": [my_images[k] for k in range(len(problems))], "rank0_sha256_16": shas}
-    if not dry and rank == 0 and world == 1 and method in ("multigrid", "auto"):
+    if not dry and rank == 0 and world == 1 and method in ("multigrid", "auto") and not args.no_estimate:
         out["photograph_like"] = photo_record(rt, dev, rows, cols)             # outside the timed region
     if executed:
         out["config"]["converged"] = {"tolerance": tolerance, "iterations": [e[0] for e in executed], "unit": "cycles" if method == "multigrid" else "sweeps",
