@@ -145,6 +145,14 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
     return in_solve ? kRestartSolve : RTDD_OK;
 }
 
+// Calls that change what a logged solve / estimate would run on (the level planes, the weight table, the pyramid's images) first
+// settle the log: synchronise and look at the status word while the state the logged calls were made against still exists.
+int settle_pending(rtdd_ctx *ctx) {
+    if (ctx->pending.empty() || ctx->healing) return RTDD_OK;
+    RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return check_persistent_status(ctx);
+}
+
 static void free_levels(rtdd_ctx *ctx) {
     for (auto &L : ctx->levels) {
         for (auto &p : L.plane)
@@ -317,6 +325,7 @@ int rtdd_allocate(rtdd_ctx *ctx, int rows, int cols, int levels) {
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, rows > 0 && cols > 0 && levels > 0 && levels <= 30, "rows, cols, levels must be positive");
     DeviceGuard g(ctx->device);
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_levels(ctx);
     ctx->levels.resize(levels);
@@ -343,6 +352,7 @@ int rtdd_allocate(rtdd_ctx *ctx, int rows, int cols, int levels) {
 int rtdd_free(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     DeviceGuard g(ctx->device);
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     mg_release(ctx);
     free_levels(ctx);
@@ -352,6 +362,7 @@ int rtdd_free(rtdd_ctx *ctx) {
 int rtdd_load_weights(rtdd_ctx *ctx, float beta) {
     if (!ctx) return RTDD_ERR_INVALID;
     DeviceGuard g(ctx->device);
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     for (int w = 0; w < 256; w++) ctx->lut_host[w] = expf(-beta * w);      // src/GPUSolver.cu:267, host libm
     ctx->lut_host[256] = 0;
     RTDD_HIP(ctx, hipMemcpyAsync(ctx->lut_dev, ctx->lut_host, sizeof(ctx->lut_host), hipMemcpyHostToDevice, ctx->stream));

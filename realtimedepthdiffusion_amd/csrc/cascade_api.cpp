@@ -107,6 +107,7 @@ int rtdd_pyramid_create(rtdd_ctx *ctx, int rows, int cols) {
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, rows > 0 && cols > 0, "rows and cols must be positive");
     DeviceGuard g(ctx->device);
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pyramid_free(ctx);
     Pyramid *p = new (std::nothrow) Pyramid();
@@ -135,6 +136,7 @@ int rtdd_pyramid_create(rtdd_ctx *ctx, int rows, int cols) {
 int rtdd_pyramid_destroy(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     DeviceGuard g(ctx->device);
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pyramid_free(ctx);
     return RTDD_OK;
@@ -146,6 +148,7 @@ int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch) {
     Pyramid *p = ctx->pyr;
     REQUIRE(ctx, bgr && pitch >= (size_t)p->cols * 3, "bad image");
     DeviceGuard g(ctx->device);
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }    // (a new image resets the warm-start state a logged estimate ran on)
     RTDD_HIP(ctx, hipMemcpy2DAsync(p->original.ptr, p->original.pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
     RTDD_HIP(ctx, hipMemcpy2DAsync(p->edited[0].ptr, p->edited[0].pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));   // :158
     // A new image is a new problem (the reference loads one image per process, src/main.cpp:93): everything an estimate carries

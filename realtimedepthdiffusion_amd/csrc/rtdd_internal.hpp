@@ -223,6 +223,7 @@ void pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited)
 int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base);
 // in_solve: called from a residual check inside rtdd_solve_ex -- after a successful heal of the calls before it that solve starts over (kRestartSolve)
 int check_persistent_status(rtdd_ctx *ctx, bool in_solve = false);
+int settle_pending(rtdd_ctx *ctx);      // before a call changes what the logged calls ran on: synchronise + check (+ heal) while that state still exists
 // cascade_api.cpp: levels from_level .. 0 of an estimate (src/main.cpp:261-291); level_seq (optional) receives each level's solve sequence number
 int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq);
 // an estimate of the pending log again, from the level whose solve has sequence number failed_seq (0: every level)

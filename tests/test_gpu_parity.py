@@ -671,3 +671,21 @@ print("acquire variant ok")
 """
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RTDD_LIBRARY=so), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "acquire variant ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_a_logged_solve_is_healed_before_its_weight_table_changes(oracle, lut):
+    """Calls that change what a logged (not yet confirmed) solve ran on settle the log first: a timed-out solve followed by GPULoadWeights
+    with another beta must be replayed with the table it was made with -- the result is the oracle's for beta = 0.4, and the next solve
+    uses the new table."""
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=14)
+    m, g = up(p["mask"]), up(p["gray"])
+    with _fresh(rows, cols, True) as c:
+        d = up(p["depth"])
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 80, 0.0, 0)
+        c.GPULoadWeights(0.2)                                            # settles the log: the solve above is healed here
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1
+        assert_bit_equal(down(d), oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 80, 0, 0, lut, 1, threads=oracle.max_threads()), "healed with the table of its call")
+        d2 = up(p["depth"])
+        c.GPUMatrixFreeSolver(d2, m, g, rows, cols, 0.2, 80, 0.0, 0); c.synchronize()
+        assert_bit_equal(down(d2), oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 80, 0, 0, oracle.load_weights(0.2), 1, threads=oracle.max_threads()), "the next solve: new table")
