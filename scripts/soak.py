@@ -1,8 +1,10 @@
-"""Round-3 soak of the persistent hand-off (sc1 halo loads without an agent acquire, monotonic flags): N back-to-back persistent
+"""Soak of the persistent hand-off (sc1 halo loads without an agent acquire, monotonic flags): N back-to-back persistent
 1080p solves -- 3 of 5 Chebyshev-Jacobi x 1000 (125 exchanges of 252 workgroups each), 1 red-black SOR x 200, 1 V-cycle x 3 -- while a
 second stream streams 1 GiB through the memory system every third solve (uneven load, warm caches), then M cold 1080p estimates.
-EVERY Jacobi result must equal the CPU oracle's bits (computed once here), every other result its first run's, and
-rtdd_ctx_synchronize must never report a timeout.  usage: soak_r3.py [N solves] [M estimates]"""
+EVERY Jacobi result must equal the CPU oracle's bits (computed once here), every other result its first run's, and no launch may
+time out: since round 4 a time-out is healed silently, so RTDD_OPT_TIMEOUT_HEALS must still read 0 at the end of each phase.  Third
+phase (round 4): K pairs of pipelined live frames (rtdd_live_submit, two in flight, uploads / downloads on their own streams) from a
+cold start, each map against the oracle cascade's first / second estimate.  usage: soak.py [N solves] [M estimates] [K live pairs]"""
 import sys, os, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,6 +13,7 @@ import realtimedepthdiffusion_amd as rt
 from realtimedepthdiffusion_amd.synth import make_problem
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 m_est = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+k_live = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 rows, cols = 1080, 1920
 p = make_problem(rows, cols, seed=1234)
 lut = oracle.load_weights(0.4)
@@ -37,7 +40,8 @@ for i in range(n):
     h = hashlib.sha1(d.cpu().numpy().tobytes()).hexdigest()
     assert ref.setdefault(kind, h) == h, (i, kind, "differs from " + ("the ORACLE" if kind == "jacobi" else "its first run"))
     if i % 1000 == 999: print(i + 1, "solves ok, %.1f s" % (time.time() - t), flush=True)
-print("soak ok:", n, "solves (every Jacobi result == the oracle's bits),", {k: v[:12] for k, v in ref.items()}, flush=True)
+assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 0 and c.get_option(rt.OPT_PERSISTENT) == 1, "a persistent launch timed out (and was healed)"
+print("soak ok:", n, "solves (every Jacobi result == the oracle's bits, no time-out healed),", {k: v[:12] for k, v in ref.items()}, flush=True)
 c.close(); torch.cuda.synchronize()
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -60,4 +64,26 @@ for i in range(m_est):
     h = hashlib.sha1(c.pyramid_download(rt.IMG_DEPTH, 0).tobytes()).hexdigest()
     assert h == ref_e, (i, "estimate differs from the oracle cascade")
     if i % 500 == 499: print(i + 1, "estimates ok, %.1f s" % (time.time() - t), flush=True)
-print("soak ok:", m_est, "estimates, every one == the oracle cascade's bits", ref_e[:12])
+assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 0, "a persistent launch timed out (and was healed)"
+print("soak ok:", m_est, "estimates, every one == the oracle cascade's bits", ref_e[:12], flush=True)
+
+# ---- live frames, two in flight: cold start, frame 1 == the oracle's first estimate, frame 2 == its second (warm-started) one
+u8_1 = hashlib.sha1(cas.depth_u8.tobytes()).hexdigest()
+cas.estimate(1000)
+u8_2 = hashlib.sha1(cas.depth_u8.tobytes()).hexdigest()
+scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3)); outs = [rt.host_image((rows, cols)) for _ in range(2)]
+c.pyramid_set_image(img); c.pyramid_set_annotation(an); c.synchronize()
+scr.a[...] = c.pyramid_download(rt.IMG_SCRIBBLE, 0); ed.a[...] = c.pyramid_download(rt.IMG_EDITED, 0)
+t = time.time()
+for i in range(k_live):
+    c.pyramid_set_image(img); c.pyramid_set_annotation(an)
+    if i % 3 == 0:
+        with torch.cuda.stream(side):
+            noise.mul_(1.0001)
+    c.live_submit(scr.a, ed.a, outs[0].a, 1000); c.live_submit(scr.a, ed.a, outs[1].a, 1000)
+    c.live_wait(); h1 = hashlib.sha1(outs[0].a.tobytes()).hexdigest()
+    c.live_wait(); h2 = hashlib.sha1(outs[1].a.tobytes()).hexdigest()
+    assert (h1, h2) == (u8_1, u8_2), (i, "a live frame differs from the oracle cascade")
+    if i % 500 == 499: print(i + 1, "live pairs ok, %.1f s" % (time.time() - t), flush=True)
+assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 0, "a persistent launch timed out (and was healed)"
+print("soak ok:", k_live, "pairs of pipelined live frames, every map == the oracle cascade's", u8_1[:12], u8_2[:12])
