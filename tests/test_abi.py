@@ -33,6 +33,10 @@ def test_header_symbols_are_exported(so):
 
 def test_reference_mangled_symbols_are_exported(so):
     assert set(rt.DROPIN_SYMBOLS) <= _exported(so)
+    # the one extern "C" name include/rtdd_dropin.hpp declares beside the ten: the shim's context, unmangled
+    dropin = open(os.path.join(ROOT, "include", "rtdd_dropin.hpp")).read()
+    assert set(re.findall(r'extern "C"[^;]*?\b(rtdd_[a-z_0-9]+)\s*\(', dropin)) == {"rtdd_dropin_context"}
+    assert "rtdd_dropin_context" in _exported(so)
     # the mangled names really are what the reference's declarations produce
     hdr = os.path.join(ROOT, "include", "rtdd_dropin.hpp")
     src = '#include "%s"\nvoid* p[] = {(void*)GPUAllocateDeviceMemory,(void*)GPUFreeDeviceMemory,(void*)GPULoadWeights,(void*)GPUMatrixFreeSolver,(void*)GPUConvertToFloat,(void*)GPUPyrDownAnnotation,(void*)GPUPaintImage,(void*)GPUSimulateDefocus,(void*)GPUSimulateDesaturation,(void*)GPUSimulateHaze};' % hdr
