@@ -278,3 +278,27 @@ def test_deterministic_exp_of_the_haze_restatement(oracle):
     assert n_differ < 0.002 * x.size                             # glibc's expf misrounds ~0.06 % of arguments; this one none of these
     sp, _ = oracle.expf_det(np.array([np.nan, np.inf, -np.inf, 89.5, -104.5], np.float32))
     assert np.isnan(sp[0]) and sp[1] == np.inf and sp[2] == 0 and sp[3] == np.inf and sp[4] == 0
+
+
+def test_cascade_pieces_agree_with_scipy_witnesses(oracle):
+    """The OpenCV steps of the estimate are third-party arithmetic restated from published formulas (oracle/rtdd_cascade_oracle.c) and
+    unpinned by the reference.  Independent witnesses, written against the formulas and not against that file: BT.601 fixed-point gray in
+    numpy integers; pyrDown as scipy's separable correlation with [1 4 6 4 1] in `mirror` mode (= reflect-101) on integers, rounded
+    (s + 128) >> 8, every second sample; the exact-doubling pyrUp as zero insertion + the same kernel x 4 / 256 in f64 (interior only:
+    the border rule is OpenCV's own), within f32 rounding."""
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    for rows, cols in ((7, 9), (67, 120), (135, 241), (270, 480)):
+        bgr = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+        g = oracle.bgr2gray(bgr)
+        b, gr, r = (bgr[..., i].astype(np.int64) for i in range(3))
+        assert np.array_equal(g, ((b * 1868 + gr * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8))
+        k = np.array([1, 4, 6, 4, 1], np.int64)
+        full = ndimage.correlate1d(ndimage.correlate1d(g.astype(np.int64), k, axis=0, mode="mirror"), k, axis=1, mode="mirror")
+        assert np.array_equal(oracle.pyrdown_u8(g), ((full[::2, ::2] + 128) >> 8).astype(np.uint8)), (rows, cols)
+        src = rng.uniform(0, 255, (rows, cols)).astype(np.float32)
+        up = oracle.pyrup_f32(src, 2 * rows, 2 * cols, contract=0)
+        z = np.zeros((2 * rows, 2 * cols)); z[::2, ::2] = src
+        kf = np.array([1, 4, 6, 4, 1], np.float64)
+        want = ndimage.correlate1d(ndimage.correlate1d(z, kf, axis=0, mode="constant"), kf, axis=1, mode="constant") * 4 / 256
+        assert np.abs(up[2:-3, 2:-3] - want[2:-3, 2:-3]).max() <= 2e-4, (rows, cols)
