@@ -8,7 +8,8 @@
 //     key 's'  -> also the annotated image   (main.cpp:298-303)  -> <out>AnnotatedImage.ppm: the image with the scribbles painted in
 //     key 'b'/'g'/'h' -> --effect defocus|desaturation|haze     -> <out>ArtisticEffect.ppm (main.cpp:190-230, 312-316)
 //     key 't'  -> prints "Processing Time"  (main.cpp:320-322; wall clock here, the reference uses clock())
-//     --paint x,y,label,radius  = a mouse drag sample (main.cpp:46-62), repeatable
+//     --paint x,y,label,radius  = a mouse drag sample (main.cpp:46-62), repeatable; --paint-at F:x,y,label,radius = the same while --live
+//                                 runs, in front of frame F (the user painting into a live view)
 //     --refine sor|mg|auto [--tolerance T] = extension: converge the finest level after the estimate (rtdd_refine_depth)
 // and adds what the reference cannot do: --devices N --batch B runs B independent estimates
 // round-robin over N GPUs, one host thread + one HIP stream + one rtdd_ctx per GPU, no collective.
@@ -143,11 +144,11 @@ static bool write_image(const std::string &path, int w, int h, int ch, const uns
 
 #define CK(call) do { int rc_ = (call); if (rc_ != RTDD_OK) { std::printf("%s: %s (%s)\n", #call, rtdd_status_string(rc_), rtdd_last_error(ctx)); return rc_; } } while (0)
 
-struct Paint { int x, y, label, radius; };
+struct Paint { int x, y, label, radius, frame; };      // frame: --paint-at (live mode: in front of that frame); --paint: before the first estimate
 struct Job {
     Pnm bgr, ann;                 // bgr is BGR-interleaved like cv::imread's Mat
     bool has_ann = false;
-    std::vector<Paint> paints;
+    std::vector<Paint> paints, live_paints;
     std::string effect;
     int iters = 1000;
     std::string refine;           // "" | "sor" | "mg": rtdd_refine_depth after every estimate
@@ -208,10 +209,23 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
         auto landed = [&](int f) { std::memcpy(depth_u8->data(), h_u8[f % 2].p, depth_u8->size()); if (every_map) every_map->push_back(*depth_u8); };
         auto t0 = std::chrono::steady_clock::now();
         for (int n = 0; n < count; n++) {
-            if (n >= 2) { CK(rtdd_live_wait(ctx)); landed(n - 2); }              // frame n-2's buffer is about to be reused
+            bool painted = false;
+            for (const Paint &p : job.live_paints)
+                if (p.frame == n) {
+                    // main.cpp:46-62: the mouse callback paints the DEVICE images and downloads them into the host's Mats, which the next
+                    // estimate uploads again (:236-237).  The frames in flight are let land first: they read the images being painted.
+                    if (!painted) while (rtdd_live_pending(ctx) > 0) { const int f = n - rtdd_live_pending(ctx); CK(rtdd_live_wait(ctx)); landed(f); }
+                    CK(rtdd_paint_image(ctx, p.x, p.y, p.label, p.radius, (uint8_t *)p_ed, pi_ed, (uint8_t *)p_scr, pi_scr, rows, cols));
+                    painted = true;
+                }
+            if (painted) {
+                CK(rtdd_download(ctx, h_scr.p, cols, p_scr, pi_scr, cols, rows));
+                CK(rtdd_download(ctx, h_ed.p, (size_t)cols * 3, p_ed, pi_ed, (size_t)cols * 3, rows));
+            }
+            if (rtdd_live_pending(ctx) >= 2) { const int f = n - 2; CK(rtdd_live_wait(ctx)); landed(f); }              // frame n-2's buffer is about to be reused
             CK(rtdd_live_submit(ctx, (const uint8_t *)h_scr.p, cols, (const uint8_t *)h_ed.p, (size_t)cols * 3, job.iters, (uint8_t *)h_u8[n % 2].p, cols));
         }
-        for (int f = count > 2 ? count - 2 : 0; f < count; f++) { CK(rtdd_live_wait(ctx)); landed(f); }
+        while (rtdd_live_pending(ctx) > 0) { const int f = count - rtdd_live_pending(ctx); CK(rtdd_live_wait(ctx)); landed(f); }
         *ms_per_estimate = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (count > 0 ? count : 1);
         if (annotated) { annotated->resize((size_t)rows * cols * 3); CK(rtdd_download(ctx, annotated->data(), (size_t)cols * 3, p_ed, pi_ed, (size_t)cols * 3, rows)); }
         CK(rtdd_ctx_synchronize(ctx));
@@ -257,7 +271,7 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
 
 int main(int argc, const char *argv[]) {
     if (argc == 1) { std::printf("Usage: rtdd_harness -i image.ppm [-a annotation.pgm] [-o prefix] [--effect defocus|desaturation|haze] [--iters N] [--refine sor|mg|auto [--tolerance T]]\n"
-                                 "                    [--paint x,y,label,radius]... [--live N] [--devices D --batch B [--write-all]] [--png]\n"
+                                 "                    [--paint x,y,label,radius]... [--live N [--paint-at frame:x,y,label,radius]...] [--devices D --batch B [--write-all]] [--png]\n"
                                  "       rtdd_harness --convert in.(png|ppm|pgm) out.(png|ppm|pgm)       (8-bit PNG <-> PNM, no GPU)\n"); return 0; }
     if (argc == 4 && !std::strcmp(argv[1], "--convert")) {               // file format conversion only (no GPU): PNG <-> PNM
         Pnm im;
@@ -282,7 +296,8 @@ int main(int argc, const char *argv[]) {
         else if (!std::strcmp(argv[i], "--live")) live = std::atoi(next());
         else if (!std::strcmp(argv[i], "--write-all")) write_all = true;           // every estimate of a --batch: <out>DepthMap_<b>.pgm|png
         else if (!std::strcmp(argv[i], "--png")) png = true;                       // DepthMap.png / ArtisticEffect.png like the reference
-        else if (!std::strcmp(argv[i], "--paint")) { Paint p{0, 0, 0, 0}; if (std::sscanf(next(), "%d,%d,%d,%d", &p.x, &p.y, &p.label, &p.radius) == 4) job.paints.push_back(p); }
+        else if (!std::strcmp(argv[i], "--paint")) { Paint p{0, 0, 0, 0, -1}; if (std::sscanf(next(), "%d,%d,%d,%d", &p.x, &p.y, &p.label, &p.radius) == 4) job.paints.push_back(p); }
+        else if (!std::strcmp(argv[i], "--paint-at")) { Paint p{0, 0, 0, 0, 0}; if (std::sscanf(next(), "%d:%d,%d,%d,%d", &p.frame, &p.x, &p.y, &p.label, &p.radius) == 5) job.live_paints.push_back(p); }
         else if (!std::strcmp(argv[i], "-h")) std::printf("Usage:\n -i input image (binary PPM)\n -a annotated image (binary PGM)\n");
     }
     Pnm rgb;

@@ -103,6 +103,29 @@ def test_harness_live_frames_are_pipelined_and_each_is_the_oracles(tmp_path):
     assert np.array_equal(_read_pnm(tmp_path / "DepthMap.pgm"), c.depth_u8)
 
 
+def test_harness_painting_into_a_live_view(tmp_path):
+    """--live 5 --paint-at 2:... --paint-at 4:...: strokes in front of frames 2 and 4 (main.cpp:46-62: the mouse callback paints the
+    device images and downloads them into the host's, the next frame uploads them, :236-237).  Every frame == the oracle cascade with
+    the same strokes at the same places in the sequence of warm-started estimates."""
+    g = load(NAMES[0])
+    _write_pnm(tmp_path / "img.ppm", g["bgr"][..., ::-1])
+    _write_pnm(tmp_path / "ann.pgm", g["annotation"])
+    strokes = {2: (50, 60, 254, 11), 4: (180, 200, 0, 7)}
+    args = [BIN, "-i", str(tmp_path / "img.ppm"), "-a", str(tmp_path / "ann.pgm"), "-o", str(tmp_path) + "/", "--live", "5", "--iters", "200", "--write-all"]
+    for f, st in strokes.items():
+        args += ["--paint-at", "%d:%d,%d,%d,%d" % ((f,) + st)]
+    subprocess.check_output(args, text=True)
+    import oracle
+    from cascade_ref import Cascade
+    c = Cascade(oracle, g["bgr"], g["annotation"], oracle.load_weights(0.4), 1, threads=4)
+    for n in range(5):
+        if n in strokes:
+            oracle.paint_image(*strokes[n], c.edited[0], c.scribble[0])
+        c.estimate(200)
+        assert np.array_equal(_read_pnm(tmp_path / f"DepthMap_{n}.pgm"), c.depth_u8), f"frame {n}"
+    assert np.array_equal(_read_pnm(tmp_path / "AnnotatedImage.ppm"), c.edited[0][..., ::-1])
+
+
 def test_harness_batch_and_paint(tmp_path):
     """--paint (the mouse-drag brush, main.cpp:46-62) against GPUPaintImage's restatement + the restated cascade, every pixel;
     --batch B treats every image as independent: B = 3 on one device writes the same map as B = 1 (no warm start leaks in)."""
