@@ -49,8 +49,9 @@ enum rtdd_status {
                                        -- rtdd_ctx_synchronize, rtdd_download, a residual-stopped rtdd_solve_ex -- sets RTDD_OPT_PERSISTENT
                                        to 0 for the rest of the context's life, prints one warning on stderr, runs the solves / estimates made
                                        since the previous synchronisation again from the failed one on (up to 4096 of them are remembered)
-                                       and returns RTDD_OK: see RTDD_OPT_TIMEOUT_HEALS.  Other work queued behind a failed solve (an effect
-                                       reading its depth map) has seen the solve's INPUT and is not run again.  As with any asynchronous
+                                       and returns RTDD_OK: see RTDD_OPT_TIMEOUT_HEALS.  The three depth effects queued behind an unconfirmed solve
+                                       are remembered and run again with it (they may have read the solve's INPUT); the annotation calls
+                                       (paint, pyrDown, convert) are not -- they do not depend on a solve.  As with any asynchronous
                                        call, the images handed to a solve must stay valid until a synchronising call has returned: a
                                        replay reads and writes them again.  Calls that change what a logged call ran on (rtdd_allocate,
                                        rtdd_free, rtdd_load_weights, rtdd_pyramid_create / _destroy / _set_image) settle the log first */

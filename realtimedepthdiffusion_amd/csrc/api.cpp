@@ -76,15 +76,35 @@ static int replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
         ctx->finish_u8 = op.finish_u8; ctx->finish_u8_pitch = op.finish_u8_pitch;
         rc = rtdd_solve_ex(ctx, op.depth, op.depthPitch, op.scribble, op.scribblePitch, op.gray, op.grayPitch, op.rows, op.cols, op.level, &op.params, nullptr);
         ctx->finish_u8 = u8; ctx->finish_u8_pitch = u8p;
-    } else {
+    } else if (op.kind == PendingOp::kEstimate) {
         rc = estimate_replay(ctx, op, failed_seq);
+    } else if (op.kind == PendingOp::kDefocus) {
+        rc = launch_defocus(ctx, op.original, op.originalPitch, op.depth, op.depthPitch, op.artistic, op.artisticPitch, op.rows, op.cols);
+    } else if (op.kind == PendingOp::kDesaturate) {
+        rc = launch_desaturate(ctx, op.original, op.originalPitch, op.gray, op.grayPitch, op.depth, op.depthPitch, op.artistic, op.artisticPitch, op.rows, op.cols);
+    } else {
+        rc = launch_haze(ctx, op.original, op.originalPitch, op.depth, op.depthPitch, op.artistic, op.artisticPitch, op.rows, op.cols);
     }
     ctx->opt = now;
     return rc;
 }
 
+// A depth effect queued behind solves that no synchronising call has confirmed yet is logged with them: should one of those solves turn
+// out to have timed out, the effect ran on its INPUT and is run again behind the replayed solve.  (Nothing unconfirmed: nothing to log.)
+static void log_effect(rtdd_ctx *ctx, PendingOp::Kind kind, const uint8_t *original, size_t originalPitch, const uint8_t *gray, size_t grayPitch,
+                       const float *depth, size_t depthPitch, uint8_t *artistic, size_t artisticPitch, int rows, int cols) {
+    if (ctx->healing || ctx->pending.empty() || ctx->pending.size() >= kMaxPendingOps) return;
+    PendingOp op;
+    op.kind = kind; op.opt = ctx->opt; op.id = ++ctx->op_counter;
+    op.original = original; op.originalPitch = originalPitch; op.gray = gray; op.grayPitch = grayPitch;
+    op.depth = const_cast<float *>(depth); op.depthPitch = depthPitch; op.artistic = artistic; op.artisticPitch = artisticPitch;
+    op.rows = rows; op.cols = cols;
+    ctx->pending.push_back(op);
+}
+
 static bool op_holds(const PendingOp &op, int seq) {
     if (op.kind == PendingOp::kSolve) return op.seq == seq;
+    if (op.kind != PendingOp::kEstimate) return false;
     for (int l = 0; l < 32; l++) if (op.level_seq[l] != 0 && op.level_seq[l] == seq) return true;
     return false;
 }
@@ -707,7 +727,9 @@ int rtdd_simulate_defocus(rtdd_ctx *ctx, const uint8_t *original, size_t origina
     if (rc != RTDD_OK || rows == 0 || cols == 0) return rc;
     REQUIRE(ctx, original != artistic, "defocus cannot run in place");
     DeviceGuard g(ctx->device);
-    return launch_defocus(ctx, original, originalPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    rc = launch_defocus(ctx, original, originalPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    if (rc == RTDD_OK) log_effect(ctx, PendingOp::kDefocus, original, originalPitch, nullptr, 0, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    return rc;
 }
 
 int rtdd_simulate_desaturation(rtdd_ctx *ctx, const uint8_t *original, size_t originalPitch, const uint8_t *gray, size_t grayPitch,
@@ -717,7 +739,9 @@ int rtdd_simulate_desaturation(rtdd_ctx *ctx, const uint8_t *original, size_t or
     if (rc != RTDD_OK || rows == 0 || cols == 0) return rc;
     REQUIRE(ctx, gray && grayPitch >= (size_t)cols, "bad gray image");
     DeviceGuard g(ctx->device);
-    return launch_desaturate(ctx, original, originalPitch, gray, grayPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    rc = launch_desaturate(ctx, original, originalPitch, gray, grayPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    if (rc == RTDD_OK) log_effect(ctx, PendingOp::kDesaturate, original, originalPitch, gray, grayPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    return rc;
 }
 
 int rtdd_simulate_haze(rtdd_ctx *ctx, const uint8_t *original, size_t originalPitch, const float *depth, size_t depthPitch,
@@ -726,7 +750,9 @@ int rtdd_simulate_haze(rtdd_ctx *ctx, const uint8_t *original, size_t originalPi
     int rc = check_effect(ctx, original, depth, artistic, originalPitch, depthPitch, artisticPitch, rows, cols);
     if (rc != RTDD_OK || rows == 0 || cols == 0) return rc;
     DeviceGuard g(ctx->device);
-    return launch_haze(ctx, original, originalPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    rc = launch_haze(ctx, original, originalPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    if (rc == RTDD_OK) log_effect(ctx, PendingOp::kHaze, original, originalPitch, nullptr, 0, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    return rc;
 }
 
 }  // extern "C"

@@ -64,7 +64,7 @@ struct Options {
 // needs to run it again when a persistent launch gave up (api.cpp, "self-healing").  A solve is one sequence number (handed to the
 // kernel that publishes its result: k_finish, or k_pyrup_inject inside an estimate); an estimate is one per pyramid level.
 struct PendingOp {
-    enum Kind { kSolve = 0, kEstimate = 1 } kind = kSolve;
+    enum Kind { kSolve = 0, kEstimate = 1, kDefocus = 2, kDesaturate = 3, kHaze = 4 } kind = kSolve;
     Options opt;                          // the options in force when the call was made
     // kSolve: the arguments of rtdd_solve_ex (+ the optional u8 copy of the result, rtdd_refine_depth)
     float *depth = nullptr; size_t depthPitch = 0;
@@ -78,6 +78,10 @@ struct PendingOp {
     int level_seq[32] = {};               // sequence number of level l's solve (0: the level is empty)
     uint8_t *u8_copy = nullptr; size_t u8_copy_pitch = 0;   // live mode: the u8 map is copied here (device) behind the estimate
     unsigned long long id = 0;            // position in the context's call order (live mode drops the confirmed prefix of the log)
+    // kDefocus / kDesaturate / kHaze: a depth effect queued BEHIND an unconfirmed solve (it may have read that solve's input instead of
+    // its result); `depth` / `depthPitch` / `gray` / `grayPitch` / `rows` / `cols` above, and:
+    const uint8_t *original = nullptr; size_t originalPitch = 0;
+    uint8_t *artistic = nullptr; size_t artisticPitch = 0;
 };
 constexpr int kRestartSolve = -1000;      // internal status: the pending calls were healed inside a solve's residual check; that solve starts over
 constexpr size_t kMaxPendingOps = 4096;

@@ -689,3 +689,26 @@ def test_a_logged_solve_is_healed_before_its_weight_table_changes(oracle, lut):
         d2 = up(p["depth"])
         c.GPUMatrixFreeSolver(d2, m, g, rows, cols, 0.2, 80, 0.0, 0); c.synchronize()
         assert_bit_equal(down(d2), oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 80, 0, 0, oracle.load_weights(0.2), 1, threads=oracle.max_threads()), "the next solve: new table")
+
+
+def test_effects_queued_behind_a_timed_out_solve_are_replayed_with_it(oracle, lut):
+    """solve -> defocus / desaturation / haze of its depth map -> synchronise, all asynchronous, and the solve's persistent launch times
+    out: the effects ran on the solve's INPUT.  They are logged behind the unconfirmed solve and run again behind its replay: after the
+    synchronising call all three images are the oracle's effects of the oracle's depth map."""
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=17)
+    rgb = np.random.default_rng(5).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 60, 0, 0, lut, 1, threads=oracle.max_threads())
+    with _fresh(rows, cols, True) as c:
+        d, m, g, o = up(p["depth"]), up(p["mask"]), up(p["gray"]), up(rgb)
+        arts = [up(np.zeros_like(rgb)) for _ in range(3)]
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 60, 0.0, 0)
+        c.GPUSimulateDefocus(o, d, arts[0], rows, cols)
+        c.GPUSimulateDesaturation(o, g, d, arts[1], rows, cols)
+        c.GPUSimulateHaze(o, d, arts[2], rows, cols)
+        c.synchronize()
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1
+        assert_bit_equal(down(d), want, "the healed solve")
+        assert np.array_equal(down(arts[0]), oracle.defocus(rgb, want, threads=oracle.max_threads())), "defocus behind a healed solve"
+        assert np.array_equal(down(arts[1]), oracle.desaturate(rgb, p["gray"], want, 1)), "desaturation behind a healed solve"
+        assert np.array_equal(down(arts[2]), oracle.haze(rgb, want, 1)), "haze behind a healed solve"
