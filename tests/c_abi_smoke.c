@@ -42,6 +42,26 @@ int main(void) {
     const int a = depth[45 * cols + 20], b = depth[45 * cols + 135], mid = depth[45 * cols + 79];
     printf("label0 %d label254 %d left-of-edge %d\n", a, b, mid);
     if (a != 0 || b != 254 || mid > 127) { printf("unexpected depth values\n"); return 1; }   /* the edge at cols/2 keeps the left half near label 0 */
+    /* the frame loop of src/main.cpp:232-295 from C: page-locked host images, two frames in flight; a frame that re-uploads the same
+     * annotation is the next warm-started estimate -- the same map as calling rtdd_estimate_depth again */
+    void *p_scr, *p_ed; size_t pi_scr, pi_ed;
+    CK(rtdd_pyramid_image(ctx, RTDD_IMG_SCRIBBLE, 0, &p_scr, &pi_scr, NULL, NULL));
+    CK(rtdd_pyramid_image(ctx, RTDD_IMG_EDITED, 0, &p_ed, &pi_ed, NULL, NULL));
+    void *h_scr = NULL, *h_ed = NULL, *h_out[2] = {NULL, NULL};
+    CK(rtdd_host_alloc(&h_scr, (size_t)rows * cols)); CK(rtdd_host_alloc(&h_ed, (size_t)rows * cols * 3));
+    CK(rtdd_host_alloc(&h_out[0], (size_t)rows * cols)); CK(rtdd_host_alloc(&h_out[1], (size_t)rows * cols));
+    CK(rtdd_download(ctx, h_scr, cols, p_scr, pi_scr, cols, rows));
+    CK(rtdd_download(ctx, h_ed, (size_t)cols * 3, p_ed, pi_ed, (size_t)cols * 3, rows));
+    CK(rtdd_live_submit(ctx, (const uint8_t *)h_scr, cols, (const uint8_t *)h_ed, (size_t)cols * 3, 1000, (uint8_t *)h_out[0], cols));
+    CK(rtdd_live_submit(ctx, (const uint8_t *)h_scr, cols, (const uint8_t *)h_ed, (size_t)cols * 3, 1000, (uint8_t *)h_out[1], cols));
+    if (rtdd_live_pending(ctx) != 2) { printf("two frames should be in flight\n"); return 1; }
+    CK(rtdd_live_wait(ctx)); CK(rtdd_live_wait(ctx));
+    CK(rtdd_download(ctx, depth, cols, p_u8, pi_u8, cols, rows));             /* the device's map = the second frame's */
+    if (memcmp(depth, h_out[1], (size_t)rows * cols) != 0) { printf("live frame differs from the device's map\n"); return 1; }
+    int heals = -1;
+    CK(rtdd_get_option(ctx, RTDD_OPT_TIMEOUT_HEALS, &heals));
+    if (heals != 0) { printf("unexpected heal\n"); return 1; }
+    rtdd_host_free(h_scr); rtdd_host_free(h_ed); rtdd_host_free(h_out[0]); rtdd_host_free(h_out[1]);
     CK(rtdd_pyramid_destroy(ctx));
     rtdd_ctx_destroy(ctx);
     free(bgr); free(ann); free(depth);
