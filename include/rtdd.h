@@ -97,8 +97,9 @@ enum rtdd_option {
     RTDD_OPT_DEBUG_WITHHOLD_TILE = 7, /* testing aid: tile number + 1 whose hand-off flag a persistent launch never publishes (0 = off),
                                        so that its neighbours run into the poll limit -> RTDD_ERR_TIMEOUT */
     RTDD_OPT_DEBUG_POLL_LIMIT_US = 8, /* testing aid: that poll limit in microseconds (0 = the default, 200 ms) */
-    RTDD_OPT_DEBUG_FORCE_STATUS = 13, /* testing aid: value (0..2) stored into the kernels' status word right behind the next temporally blocked
-                                       Jacobi launch, persistent or not, as if a wave of it had given up (one shot: resets to 0) */
+    RTDD_OPT_DEBUG_FORCE_STATUS = 13, /* testing aid: value (1, 2) stored into the kernels' status word right behind the next temporally blocked
+                                       Jacobi launch, persistent or not, as if a wave of it had given up (one shot: resets to 0); 3 = status 1
+                                       now AND once more when that solve is run again, so that the replay fails too (-> RTDD_ERR_TIMEOUT) */
     RTDD_OPT_DEFOCUS_LAST_PATH = 15, /* read only: what the most recent rtdd_simulate_defocus launched -- 1 the global table, 2 the tile kernel (0: none yet).
                                        Setting RTDD_OPT_DEFOCUS_PATH to 0 also forgets an earlier fall-back of the automatic choice to the table */
     RTDD_OPT_TIMEOUT_HEALS = 14,    /* read only: how many times this context has healed a timed-out persistent launch (see RTDD_ERR_TIMEOUT) */

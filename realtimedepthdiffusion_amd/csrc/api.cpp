@@ -69,7 +69,8 @@ int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
 static int replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
     const Options now = ctx->opt;
     ctx->opt = op.opt;
-    ctx->opt.persistent = 0; ctx->opt.debug_force_status = 0;
+    ctx->opt.persistent = 0;
+    ctx->opt.debug_force_status = op.opt.debug_force_status == 3 ? 1 : 0;      // (3: the testing aid that makes the REPLAY fail as well)
     int rc = RTDD_OK;
     if (op.kind == PendingOp::kSolve) {
         uint8_t *u8 = ctx->finish_u8; const size_t u8p = ctx->finish_u8_pitch;
@@ -279,7 +280,7 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_AUTO_SWEEP_FLOOR_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_sweep_floor_ns = value; break;
         case RTDD_OPT_DEBUG_WITHHOLD_TILE: REQUIRE(ctx, value >= 0 && value <= kSyncMaxTiles, "tile number + 1 out of range"); ctx->opt.debug_withhold_tile = value; break;
         case RTDD_OPT_DEBUG_POLL_LIMIT_US: REQUIRE(ctx, value >= 0 && value <= 10000000, "poll limit must be 0..1e7 us"); ctx->opt.debug_poll_limit_us = value; break;
-        case RTDD_OPT_DEBUG_FORCE_STATUS: REQUIRE(ctx, value >= 0 && value <= 2, "status must be 0..2"); ctx->opt.debug_force_status = value; break;
+        case RTDD_OPT_DEBUG_FORCE_STATUS: REQUIRE(ctx, value >= 0 && value <= 3, "status must be 0..3"); ctx->opt.debug_force_status = value; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;

@@ -713,7 +713,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         // the launch-per-block instantiation too): the next synchronising call must read it whatever the mode
         ctx->persistent_used = true;
         if (ctx->opt.debug_force_status) {                          // testing aid (include/rtdd.h): as if a wave of this launch had given up
-            RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncStatus), ctx->opt.debug_force_status, 1, ctx->stream));
+            RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncStatus), ctx->opt.debug_force_status == 3 ? 1 : ctx->opt.debug_force_status, 1, ctx->stream));
             ctx->opt.debug_force_status = 0;
         }
         ctx->last_info.kernel = 2; ctx->last_info.tile = tile; ctx->last_info.temporal_depth = persistent ? block_sweeps : m; ctx->last_info.persistent = persistent ? 1 : 0;

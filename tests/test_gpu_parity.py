@@ -712,3 +712,23 @@ def test_effects_queued_behind_a_timed_out_solve_are_replayed_with_it(oracle, lu
         assert np.array_equal(down(arts[0]), oracle.defocus(rgb, want, threads=oracle.max_threads())), "defocus behind a healed solve"
         assert np.array_equal(down(arts[1]), oracle.desaturate(rgb, p["gray"], want, 1)), "desaturation behind a healed solve"
         assert np.array_equal(down(arts[2]), oracle.haze(rgb, want, 1)), "haze behind a healed solve"
+
+
+def test_a_second_time_out_during_the_replay_is_reported(oracle, lut):
+    """RTDD_OPT_DEBUG_FORCE_STATUS = 3: status 1 behind the solve and again behind its replay.  One heal is attempted, the second failure
+    is final: RTDD_ERR_TIMEOUT, the caller's depth untouched (the replay's copy-back stored nothing either), and the context works
+    afterwards -- without persistence."""
+    rows, cols = 270, 480
+    p = make_problem(rows, cols, seed=19)
+    with _fresh(rows, cols, False) as c:
+        d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+        c.set_option(rt.OPT_DEBUG_FORCE_STATUS, 3)
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 40, 0.0, 0)
+        with pytest.raises(rt.RtddError) as e:
+            c.synchronize()
+        assert e.value.status == rt.RTDD_ERR_TIMEOUT and "again" in str(e.value), e.value
+        assert_bit_equal(down(d), p["depth"], "a solve that failed twice must leave its input")
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1 and c.get_option(rt.OPT_PERSISTENT) == 0
+        c.synchronize()                                                  # reported once
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 40, 0.0, 0); c.synchronize()
+        assert_bit_equal(down(d), oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 40, 0, 0, lut, 1, threads=4), "the context works afterwards")
