@@ -21,7 +21,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 
 // cv::cvtColor(BGR2GRAY), 8u fixed point -- src/main.cpp:111,138
 __global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t *__restrict__ bgr, size_t bp, uint8_t *__restrict__ gray, size_t gp, int rows, int cols) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     const uint8_t *p = bgr + (size_t)y * bp + 3 * x;
     gray[(size_t)y * gp + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t *__restrict__ bg
 // cv::pyrDown (8u): 5x5 [1 4 6 4 1]/16 separable, reflect-101, (s+128)>>8 -- src/main.cpp:112,144,245
 __global__ __launch_bounds__(256) void k_pyrdown_u8(const uint8_t *__restrict__ src, size_t sp, int rows, int cols,
                                                     uint8_t *__restrict__ dst, size_t dp, int drows, int dcols) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= dcols || y >= drows) return;
     const int k[5] = {1, 4, 6, 4, 1};
     int cx[5];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_pyrup_inject(const float *__restrict__ 
                                                       const uint8_t *__restrict__ edited, size_t ep,
                                                       const uint8_t *__restrict__ mask, size_t mp,
                                                       float *__restrict__ coarse_out, size_t cp, int *sync_words, int seq) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;    // (persist_sync.hpp: the coarse solve gave up)
     if (x >= dcols || y >= drows) return;
     // the estimate driver reads the coarse level straight from the solver's plane; the caller-visible coarse depth image (the
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_pyrup_inject4(const float *__restrict__
                                                        const uint8_t *__restrict__ edited, size_t ep,
                                                        const uint8_t *__restrict__ mask, size_t mp,
                                                        float *__restrict__ coarse_out, size_t cp, int *sync_words, int seq) {
-    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + wave_id();
     if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;
     if (x0 >= dcols || y >= drows) return;
     const int c0 = x0 >> 1, cy = y >> 1;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_pyrup_inject4(const float *__restrict__
 
 // GpuMat::convertTo(CV_8UC1): saturate(round-half-even) -- src/main.cpp:290
 __global__ __launch_bounds__(256) void k_depth_to_u8(const float *__restrict__ src, size_t sp, uint8_t *__restrict__ dst, size_t dp, int rows, int cols) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     const float r = __builtin_rintf(((const float *)((const char *)src + (size_t)y * sp))[x]);
     dst[(size_t)y * dp + x] = !(r >= 0.0f) ? 0 : (r >= 255.0f ? 255 : (uint8_t)(int)r);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_depth_to_u8(const float *__restrict__ s
 __global__ __launch_bounds__(256) void k_decode_annotation(const uint8_t *__restrict__ bgr, size_t bp, const uint8_t *__restrict__ ann, size_t ap,
                                                            uint8_t *__restrict__ edited, size_t ep, uint8_t *__restrict__ scribble, size_t sp,
                                                            int rows, int cols) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     const uint8_t a = ann[(size_t)y * ap + x];
     const uint8_t *p = bgr + (size_t)y * bp + 3 * x;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_decode_annotation(const uint8_t *__rest
 }
 
 __global__ __launch_bounds__(256) void k_fill_f32(float *__restrict__ dst, size_t dp, int rows, int cols, float v) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     ((float *)((char *)dst + (size_t)y * dp))[x] = v;
 }

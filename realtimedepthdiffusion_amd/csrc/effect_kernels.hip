@@ -61,7 +61,7 @@ template <int MODE, bool CONTRACT, bool VEC>
 __global__ __launch_bounds__(256) void k_blend(const uint8_t *__restrict__ orig, size_t op, const uint8_t *__restrict__ gray, size_t gp,
                                                const float *__restrict__ depth, size_t dp, uint8_t *__restrict__ art, size_t ap,
                                                int rows, int cols) {
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     if (y >= rows) return;
     const float *drow = (const float *)((const char *)depth + (size_t)y * dp);
     const uint8_t *orow = orig + (size_t)y * op;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_sat_colsum(const uint8_t *__restrict__ 
 constexpr int kScanChunk = 32;
 __global__ __launch_bounds__(1024) void k_sat_colbase(u64 *__restrict__ colsum, int tp, int nbands) {
     __shared__ u64 tot[16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_id(), nw = (int)blockDim.x >> 6;
     const int x = min(blockIdx.x * 64 + lane, tp - 1);             // (the last workgroup's spare lanes repeat column tp-1: same values, same stores)
     const int chunk = min((nbands + nw - 1) / nw, kScanChunk);      // bands per wave and round
     u64 carry = 0;                                                  // bands before this round of nw * chunk
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
     const int p = blockIdx.x;
     const int tile = xcd_tiles > 0 ? (p & 7) * xcd_tiles + (p >> 3) : p;
     if (tile >= ntiles) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = wave_id();
     const int x0 = (tile % gx) * 64, x = x0 + lane, xc = min(x, cols - 1);
     const int yw = (tile / gx) * (4 * kDefocusRows) + wv * kDefocusRows;
     const bool whole = VEC && x0 + 64 <= cols;                      // wave-uniform: the dword path
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restri
 #if RTDD_DT_PRIO
     __builtin_amdgcn_s_setprio(RTDD_DT_PRIO);
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
     const int tx0 = (tile % gx) * kDtW, ty0 = (tile / gx) * kDtH;
     const int R0 = ty0 - hm, C0 = (tx0 - hm) & ~3;                  // (a multiple of four, also when negative: groups of four never straddle column 0)
     const int rh = kDtH + 2 * hm, rpw = (rh + kDtWorkers - 1) / kDtWorkers;      // region rows, rows per worker

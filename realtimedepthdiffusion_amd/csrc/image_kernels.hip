@@ -9,7 +9,7 @@ namespace rtdd {
 __global__ __launch_bounds__(256) void k_convert(const uint8_t *__restrict__ src, size_t srcPitch, float *__restrict__ dst, size_t dstPitch,
                                                  const uint8_t *__restrict__ mask, size_t maskPitch, int rows, int cols) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     if (mask[(size_t)y * maskPitch + x] == 255)
         ((float *)((char *)dst + (size_t)y * dstPitch))[x] = (float)src[(size_t)y * srcPitch + 3 * x];
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_pyrdown_annotation(const uint8_t *__res
                                                             int prows, int pcols, uint8_t *__restrict__ cs, size_t csp,
                                                             uint8_t *__restrict__ ce, size_t cep, int crows, int ccols) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     if (x >= ccols || y >= crows) return;
     int hit = -1;
 #pragma unroll
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_pyrdown_annotation(const uint8_t *__res
 __global__ __launch_bounds__(256) void k_paint(int x0, int y0, int x1, int y1, int color, uint8_t *__restrict__ edited, size_t editedPitch,
                                                uint8_t *__restrict__ scribble, size_t scribblePitch) {
     const int x = x0 + blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = y0 + blockIdx.y * 4 + wave_id();
     if (x > x1 || y > y1) return;
     uint8_t *e = edited + (size_t)y * editedPitch + 3 * x;
     e[0] = (uint8_t)color; e[1] = (uint8_t)color; e[2] = (uint8_t)color;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_mg_stencil0(const uint32_t *__restrict_
     __shared__ float lut[257];
     for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
     __syncthreads();
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     const size_t p = (size_t)y * ip + x;
     const uint32_t m = M[p];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_mg_stencil0(const uint32_t *__restrict_
 // interpolation weights of coarse-coincident and edge points; cell centres in the second pass
 template <int PASS>
 __global__ __launch_bounds__(256) void k_mg_build_p(Stencil s, float *P0, float *P1, float *P2, float *P3) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= s.cols || y >= s.rows) return;
     const size_t q = (size_t)y * s.pitch + x;
     const float d = s.D[q];
@@ -162,7 +162,7 @@ __device__ __forceinline__ float pweight(const Interp &ip, int pitch, int rows, 
 // (its diagonal couplings are all zero), so the four diagonal q are skipped -- again only +-0 terms.
 template <bool FIVE>
 __global__ __launch_bounds__(256) void k_mg_galerkin(Stencil f, Interp ip, float *E, float *S, float *SE, float *SW, float *D, int crows, int ccols, int cpitch) {
-    const int J = blockIdx.x * 64 + (threadIdx.x & 63), I = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int J = blockIdx.x * 64 + (threadIdx.x & 63), I = blockIdx.y * 4 + wave_id();
     if (J >= ccols || I >= crows) return;
     float out[3][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};      // [dI + 1][dJ + 1]
 #pragma unroll
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_mg_galerkin(Stencil f, Interp ip, float
 // a coupling towards an inactive point would read e = 0 for ever: harmless; but a coupling FROM an inactive point was
 // zeroed above while its mirror is read through the neighbour -- so zero the couplings that END at an inactive point too
 __global__ __launch_bounds__(256) void k_mg_prune(float *E, float *S, float *SE, float *SW, const float *D, int rows, int cols, int pitch) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     const size_t q = (size_t)y * pitch + x;
     if (!(at(D, pitch, rows, cols, y, x + 1) > 0.0f)) E[q] = 0.0f;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_mg_residual0(const float *__restrict__ 
     __shared__ float lut[257];
     for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
     __syncthreads();
-    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + wave_id();
     if (x0 >= cols || y >= rows) return;
     const size_t p = (size_t)y * ip + x0;                          // the solver planes' guard rows/columns make these addresses valid
     const float4 c4 = *(const float4 *)(X + p), u4 = *(const float4 *)(X + p - ip), d4 = *(const float4 *)(X + p + ip);
@@ -257,7 +257,7 @@ __device__ __forceinline__ float gs_sum(const Stencil &s, const float *e, const 
 }
 
 __global__ __launch_bounds__(256) void k_mg_residual(Stencil s, const float *e, const float *b, float *R) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= s.cols || y >= s.rows) return;
     const size_t q = (size_t)y * s.pitch + x;
     const float d = s.D[q];
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_mg_residual(Stencil s, const float *e, 
 
 // one colour of the four-colour Gauss-Seidel sweep; the launch covers that colour's quarter grid
 __global__ __launch_bounds__(256) void k_mg_gs(Stencil s, float *e, const float *b, int colour) {
-    const int x = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)) + (colour & 1), y = 2 * (blockIdx.y * 4 + (threadIdx.x >> 6)) + (colour >> 1);
+    const int x = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)) + (colour & 1), y = 2 * (blockIdx.y * 4 + wave_id()) + (colour >> 1);
     if (x >= s.cols || y >= s.rows) return;
     const size_t q = (size_t)y * s.pitch + x;
     const float d = s.D[q];
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_mg_gs_tile(Stencil s, const
 // Terms are added in the order of the plain loops (py, then px), a zero weight adds nothing -- as the restatement does.
 __global__ __launch_bounds__(256) void k_mg_restrict(const float *__restrict__ R, Interp ip, int frows, int fcols, int fpitch, float *bc, float *ec, int crows, int ccols, int cpitch) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int J0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), I = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int J0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), I = blockIdx.y * 4 + wave_id();
     if (J0 >= ccols || I >= crows) return;
     const int x0 = 2 * J0;                                         // < fcols, a multiple of 4: the 16-byte loads stay inside the row
     float acc0 = 0.0f, acc1 = 0.0f;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void k_mg_restrict(const float *__restrict__ R
 // target += P e_c; four fine points per thread (16-byte loads of the four weight planes and of the target row)
 __global__ __launch_bounds__(256) void k_mg_prolong(const float *__restrict__ ec, int crows, int ccols, int cpitch, Interp ip, int frows, int fcols, int fpitch, float *T, int tpitch) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + wave_id();
     if (x0 >= fcols || y >= frows) return;
     const size_t q = (size_t)y * fpitch + x0;
     // A fine point on an EVEN row lies on a coarse row: its weights towards the coarse row below (planes P2, P3) are +0 by
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void k_mg_prolong(const float *__restrict__ ec
 // x <- clamp(x + alpha (x - x_prev)): removes an error component that shrinks by lambda = alpha / (1 + alpha) per cycle
 template <bool CONTRACT>
 __global__ __launch_bounds__(256) void k_mg_extrapolate(float *X, const float *Xp, int ip, int rows, int cols, float alpha) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     const size_t p = (size_t)y * ip + x;
     const float v = X[p], d = v - Xp[p];

@@ -144,6 +144,15 @@ struct rtdd_ctx {
 
 namespace rtdd {
 
+#ifdef __HIPCC__
+// A thread's wave number within its workgroup as a SCALAR (every lane of a wave holds the same value; v_readfirstlane tells the compiler
+// so): row indices and row pointers derived from it are then computed once per wave on the scalar unit.  Left as `threadIdx.x >> 6` they
+// are per-lane values, and `(size_t)y * pitch` becomes two v_mul_lo_u32 and a v_mad_u64_u32 per row pointer -- quarter-rate
+// instructions: 17 of them in the desaturation kernel, 16 in k_prepare4, 31 in k_pyrup_inject4 (round 4: all but one gone; the streaming
+// kernels are memory-bound, so it bought them only 1-9 %: EXPERIMENTS.md).
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+#endif
+
 int fail(rtdd_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
 
 #define RTDD_HIP(ctx, call)                                                        \

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_prepare(const float *__restrict__ depth
                                                  float *__restrict__ X0, float *__restrict__ X1,
                                                  uint32_t *__restrict__ M, int ip, int rows, int cols, int gated, int thr) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
     const uint8_t *grow = gray + (size_t)y * grayPitch;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_prepare4(const float *__restrict__ dept
                                                   float *__restrict__ X0, float *__restrict__ X1,
                                                   uint32_t *__restrict__ M, int ip, int rows, int cols, int gated, int thr) {
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     if (x0 >= cols || y >= rows) return;
     const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
     const uint8_t *grow = gray + (size_t)y * grayPitch, *srow = scribble + (size_t)y * scribblePitch;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_index_to_weight(const uint8_t *__restri
                                                          const float *__restrict__ depth, size_t depthPitch,
                                                          int32_t *__restrict__ index2, int rows, int cols, int gated, int thr) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
     const int g = gray[(size_t)y * grayPitch + x];
     const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_sweep1(const float *__restrict__ X, flo
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = wave_id();
     const int x0 = blockIdx.x * 256 + lane * 4;
     const int ybeg = (blockIdx.y * 4 + wave) * R;
     const int yend = min(ybeg + R, rows);
@@ -273,7 +273,7 @@ __device__ __forceinline__ uint8_t round_u8(float v) {
 __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
                                                 int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;
     if (x >= cols || y >= rows) return;
     const float v = X[(size_t)y * ip + x];
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int
 __global__ __launch_bounds__(256) void k_finish4(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
                                                  int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq) {
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;
     if (x0 >= cols || y >= rows) return;
     const float4 v = *(const float4 *)(X + (size_t)y * ip + x0);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ X, c
     for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
     __syncthreads();
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     float d = 0.0f;
     if (x0 < cols && y < rows) {
         const size_t p = (size_t)y * ip + x0;                      // guard rows/columns make every address below valid
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_rbgs_half(float *__restrict__ X, const 
     __shared__ float lut[257];
     for (int i = threadIdx.x; i < 257; i += 256) lut[i] = lut_g[i];
     __syncthreads();
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * 4 + wave_id();
     const int x = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)) + ((y + colour) & 1);
     if (x >= cols || y >= rows) return;
     const uint32_t m = M[(size_t)y * ip + x];
