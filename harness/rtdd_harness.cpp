@@ -42,6 +42,12 @@ static bool read_pnm(const std::string &path, Pnm &im) {
     skip(); if (std::fscanf(f, "%d", &im.h) != 1) { std::fclose(f); return false; }
     skip(); if (std::fscanf(f, "%d", &maxv) != 1 || maxv != 255) { std::fclose(f); return false; }
     std::fgetc(f);
+    if (im.w <= 0 || im.h <= 0 || im.w > 65535 || im.h > 65535) { std::fclose(f); return false; }
+    const long at = std::ftell(f);
+    std::fseek(f, 0, SEEK_END);
+    const long left = std::ftell(f) - at;                          // (a header must not make us allocate what the file cannot hold)
+    std::fseek(f, at, SEEK_SET);
+    if (at < 0 || left < 0 || (unsigned long long)left < (unsigned long long)im.w * im.h * im.ch) { std::fclose(f); return false; }
     im.px.resize((size_t)im.w * im.h * im.ch);
     const bool ok = std::fread(im.px.data(), 1, im.px.size(), f) == im.px.size();
     std::fclose(f);
@@ -84,8 +90,10 @@ static bool read_png(const std::string &path, Pnm &im) {
         p += 12 + len;
     }
     const int spp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;      // samples per pixel in the file
-    if (depth != 8 || !spp || interlace || im.w <= 0 || im.h <= 0) return false;
+    if (depth != 8 || !spp || interlace || im.w <= 0 || im.h <= 0 || im.w > 65535 || im.h > 65535) return false;
     const size_t stride = (size_t)im.w * spp;
+    // (deflate expands by at most ~1032 : 1: a header that promises more than its IDAT can hold is refused before anything is allocated)
+    if ((unsigned long long)(stride + 1) * im.h > (unsigned long long)idat.size() * 1100ull + 65536ull) return false;
     std::vector<unsigned char> raw((stride + 1) * im.h);
     uLongf rawlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;

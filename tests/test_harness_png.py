@@ -61,3 +61,36 @@ def test_dataset_annotation_rule_on_png(tmp_path, harness):
     Image.fromarray(np.repeat(v[..., None], 3, 2), "RGB").save(tmp_path / "ann.png")
     subprocess.check_call([harness, "--convert", str(tmp_path / "ann.png"), str(tmp_path / "ann.ppm")])
     assert np.array_equal(_read_pnm(tmp_path / "ann.ppm")[..., 0], v)
+
+
+def test_png_code_under_address_and_ub_sanitizers(tmp_path):
+    """The harness's file readers parse untrusted bytes (PNG chunks, zlib streams, PNM headers).  A build of the host program with
+    -fsanitize=address,undefined (CPU only: --convert never touches the device) must convert good files cleanly and REJECT damaged
+    ones -- truncated, bit-flipped, lying about their size -- with an error, never with a sanitizer report."""
+    from PIL import Image
+    exe = str(tmp_path / "rtdd_harness_asan")
+    lib_dir = os.path.join(ROOT, "realtimedepthdiffusion_amd")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "harness", "rtdd_harness.cpp"), "-L" + lib_dir, "-lrtdd", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-lz"]
+    if subprocess.run(cmd, capture_output=True).returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    Image.fromarray(img, "RGB").save(tmp_path / "good.png")
+    r = subprocess.run([exe, "--convert", str(tmp_path / "good.png"), str(tmp_path / "good.ppm")], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr, r.stderr
+    assert np.array_equal(_read_pnm(tmp_path / "good.ppm"), img)
+    good = (tmp_path / "good.png").read_bytes()
+    bad = {"truncated": good[: len(good) // 2], "no_iend": good[:-12], "empty": b"", "signature_only": good[:8]}
+    for k in range(12):                                                  # bit flips all over the file (CRCs are not checked: the data must fail safely)
+        b = bytearray(good); pos = int(rng.integers(8, len(b))); b[pos] ^= 1 << int(rng.integers(0, 8)); bad[f"flip{k}"] = bytes(b)
+    huge = bytearray(good); huge[16:24] = (70000).to_bytes(4, "big") + (70000).to_bytes(4, "big"); bad["lying_size"] = bytes(huge)
+    bad["pnm_short"] = b"P6\n4000 4000\n255\n" + b"\x00" * 100
+    for name, data in bad.items():
+        path = tmp_path / (name + (".ppm" if name.startswith("pnm") else ".png"))
+        path.write_bytes(data)
+        r = subprocess.run([exe, "--convert", str(path), str(tmp_path / "out.ppm")], env=env, capture_output=True, text=True, timeout=60)
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (name, r.stderr[-2000:])
+        assert r.returncode in (0, 2, 5), (name, r.returncode, r.stderr[-500:])   # converted (a flip in ancillary bytes) or refused -- never crashed
