@@ -4,7 +4,9 @@ second stream streams 1 GiB through the memory system every third solve (uneven 
 EVERY Jacobi result must equal the CPU oracle's bits (computed once here), every other result its first run's, and no launch may
 time out: since round 4 a time-out is healed silently, so RTDD_OPT_TIMEOUT_HEALS must still read 0 at the end of each phase.  Third
 phase (round 4): K pairs of pipelined live frames (rtdd_live_submit, two in flight, uploads / downloads on their own streams) from a
-cold start, each map against the oracle cascade's first / second estimate.  usage: soak.py [N solves] [M estimates] [K live pairs]"""
+cold start, each map against the oracle cascade's first / second estimate.  Fourth phase: H fresh contexts, each made to time out (a
+hand-off flag withheld) in front of three queued solves and an effect, each healed to the oracle's bits.
+usage: soak.py [N solves] [M estimates] [K live pairs] [H healed contexts]"""
 import sys, os, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -87,3 +89,32 @@ for i in range(k_live):
     if i % 500 == 499: print(i + 1, "live pairs ok, %.1f s" % (time.time() - t), flush=True)
 assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 0, "a persistent launch timed out (and was healed)"
 print("soak ok:", k_live, "pairs of pipelined live frames, every map == the oracle cascade's", u8_1[:12], u8_2[:12])
+c.close(); torch.cuda.synchronize()
+
+# ---- the healing path itself, many times over (round 4): a fresh context per round, a hand-off flag withheld at a random tile, three
+# queued 1080p solves (each on the one before's result) + an effect behind them; the synchronising call must return OK with the oracle's bits
+k_heal = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+chain = p["depth"].copy()
+for _ in range(3):
+    chain = oracle.solve(chain, p["mask"], p["gray"], 120, 0, 0, lut, 1, threads=oracle.max_threads())
+ref_chain = hashlib.sha1(chain.tobytes()).hexdigest()
+rgb = np.random.default_rng(1).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+ref_haze = hashlib.sha1(oracle.haze(rgb, chain, 1).tobytes()).hexdigest()
+o = rt.device_image(rgb); art = rt.device_image(np.zeros_like(rgb))
+rng = np.random.default_rng(7)
+t = time.time()
+for i in range(k_heal):
+    c = rt.Context(0); c.set_stream(main.cuda_stream); c.GPULoadWeights(0.4); c.GPUAllocateDeviceMemory(rows, cols, 1)
+    c.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 1500); c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, int(rng.integers(1, 253)))
+    with torch.cuda.stream(main):
+        d = src.clone()
+    for _ in range(3):
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 120, 1e-5, 0)
+    c.GPUSimulateHaze(o, d, art, rows, cols)
+    c.synchronize()
+    assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1, (i, "no time-out?")
+    assert hashlib.sha1(d.cpu().numpy().tobytes()).hexdigest() == ref_chain, (i, "healed solves differ from the oracle")
+    assert hashlib.sha1(art.cpu().numpy().tobytes()).hexdigest() == ref_haze, (i, "the effect behind the healed solves differs")
+    c.close()
+    if i % 50 == 49: print(i + 1, "healed contexts ok, %.1f s" % (time.time() - t), flush=True)
+print("soak ok:", k_heal, "contexts, each healed one timed-out persistent launch: three queued solves + haze == the oracle's bits")
