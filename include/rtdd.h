@@ -46,15 +46,23 @@ enum rtdd_status {
                                        an error (the reference's solver always leaves a valid depth map, src/GPUSolver.cu:311-314): the
                                        failed launch and everything queued behind it drain at once, the copy-back kernels behind them store
                                        nothing (every affected call keeps its input), and the next call that synchronises the stream anyway
-                                       -- rtdd_ctx_synchronize, rtdd_download, a residual-stopped rtdd_solve_ex -- sets RTDD_OPT_PERSISTENT
-                                       to 0 for the rest of the context's life, prints one warning on stderr, runs the solves / estimates made
-                                       since the previous synchronisation again from the failed one on (up to 4096 of them are remembered)
-                                       and returns RTDD_OK: see RTDD_OPT_TIMEOUT_HEALS.  The three depth effects queued behind an unconfirmed solve
-                                       are remembered and run again with it (they may have read the solve's INPUT); the annotation calls
-                                       (paint, pyrDown, convert) are not -- they do not depend on a solve.  As with any asynchronous
-                                       call, the images handed to a solve must stay valid until a synchronising call has returned: a
-                                       replay reads and writes them again.  Calls that change what a logged call ran on (rtdd_allocate,
-                                       rtdd_free, rtdd_load_weights, rtdd_pyramid_create / _destroy / _set_image) settle the log first */
+                                       -- rtdd_ctx_synchronize, rtdd_download, a residual-stopped rtdd_solve_ex -- switches persistent launches
+                                       off (suspended for RTDD_OPT_PERSISTENT_REARM_AFTER solves, twice as many after every further time-out,
+                                       for good after four: RTDD_OPT_PERSISTENT_SUSPENDED), prints one warning on stderr, runs the solves /
+                                       estimates still unconfirmed again from the failed one on and returns RTDD_OK: see RTDD_OPT_TIMEOUT_HEALS.
+                                       The three depth effects queued behind an unconfirmed solve are remembered and run again with it (they
+                                       may have read the solve's INPUT); the calls that read a solve's output without being remembered --
+                                       rtdd_pyrup_depth, rtdd_depth_to_u8, rtdd_index_to_weight, rtdd_upload -- and the calls that change what
+                                       a remembered call ran on (rtdd_ctx_set_stream, rtdd_allocate, rtdd_free, rtdd_load_weights,
+                                       rtdd_pyramid_create / _destroy / _set_image) first settle the log: synchronise, look at the status
+                                       word, heal.  The annotation calls (paint, pyrDown, convert) are neither: they do not depend on a solve.
+                                       LIFETIME RULE: the images handed to a solve, an estimate or an effect must stay valid until an rtdd
+                                       call that synchronises (rtdd_ctx_synchronize, rtdd_download, rtdd_live_wait, a settling call above) has
+                                       returned RTDD_OK -- a replay reads and writes them again, and a hipDeviceSynchronize / hipStreamSynchronize
+                                       of the caller's own does not look at the status word.  A call leaves the log as soon as the kernel that
+                                       publishes its result has run with the status word clear (no synchronisation needed), so the log holds
+                                       calls in flight, not history.  A host that cannot keep that rule sets RTDD_OPT_TIMEOUT_HEAL to 0:
+                                       nothing is remembered, a time-out comes back as RTDD_ERR_TIMEOUT from the next synchronising call */
 };
 
 /* Solver variants.  RTDD_METHOD_CHEBYSHEV_JACOBI is the reference's only scheme
@@ -84,7 +92,8 @@ enum rtdd_option {
                                        the context's life once a call has met depths far outside [0, 255]: windows beyond a tile's region are
                                        summed directly there, exactly but at a cost that grows with their area).  Same bits either way */
     RTDD_OPT_ROWS_PER_WAVE = 4,     /* one-sweep kernel: rows each wave walks (0 = auto) */
-    RTDD_OPT_PERSISTENT = 6,        /* 1 (default): levels whose tiles all fit on the chip at once run ALL sweeps in one launch,
+    RTDD_OPT_PERSISTENT = 6,        /* (rtdd_get_option returns what is in force: 0 while a time-out has persistent launches suspended)
+                                       1 (default): levels whose tiles all fit on the chip at once run ALL sweeps in one launch,
                                        neighbouring workgroups trading halo strips in memory (no kernel boundaries); larger levels (4K, 8K) run
                                        one launch per block of sweeps.  0: one launch per block of sweeps everywhere */
     /* RTDD_METHOD_AUTO prices the V-cycles still needed against finishing with SOR cycles.  The prices are these four CONSTANTS
@@ -103,6 +112,12 @@ enum rtdd_option {
     RTDD_OPT_DEFOCUS_LAST_PATH = 15, /* read only: what the most recent rtdd_simulate_defocus launched -- 1 the global table, 2 the tile kernel (0: none yet).
                                        Setting RTDD_OPT_DEFOCUS_PATH to 0 also forgets an earlier fall-back of the automatic choice to the table */
     RTDD_OPT_TIMEOUT_HEALS = 14,    /* read only: how many times this context has healed a timed-out persistent launch (see RTDD_ERR_TIMEOUT) */
+    RTDD_OPT_TIMEOUT_HEAL = 16,     /* 1 (default): heal as described at RTDD_ERR_TIMEOUT; 0: remember nothing, report the time-out */
+    RTDD_OPT_PERSISTENT_REARM_AFTER = 17, /* solves run without persistence after the FIRST healed time-out before persistent launches are tried
+                                       again (default 32; doubles with every further time-out; after four time-outs persistence stays off;
+                                       0: off for good at the first).  Setting RTDD_OPT_PERSISTENT to 1 explicitly re-arms at once */
+    RTDD_OPT_PERSISTENT_SUSPENDED = 18, /* read only: 0 persistent launches are armed (or RTDD_OPT_PERSISTENT is 0 by the caller's choice); n > 0: suspended
+                                       for n more solves after a time-out; -1: off for the rest of the context's life */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),
@@ -123,8 +138,9 @@ const char *rtdd_status_string(int status);
 int rtdd_version(void);                                  /* major * 100 + minor.  200: rtdd_solve_info grew from 12 to 36 bytes (kernel .. launches);
                                                           * rtdd_solve_ex / rtdd_refine_depth / rtdd_last_solve_info write the whole struct, so a
                                                           * caller compiled against a 1xx header must be rebuilt (#define RTDD_VERSION below).  210 adds
-                                                          * rtdd_pyramid_annotation_changed, RTDD_OPT_TIMEOUT_HEALS and the self-healing time-out */
-#define RTDD_VERSION 210
+                                                          * rtdd_pyramid_annotation_changed, RTDD_OPT_TIMEOUT_HEALS and the self-healing time-out; 220: RTDD_OPT_TIMEOUT_HEAL,
+                                                          * persistence re-armed after a time-out, rtdd_estimate_depth_batch */
+#define RTDD_VERSION 220
 
 /* ---- solver (include/GPUSolver.h:6-10) ------------------------------------------------------ */
 

@@ -94,13 +94,40 @@ static int replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
 // out to have timed out, the effect ran on its INPUT and is run again behind the replayed solve.  (Nothing unconfirmed: nothing to log.)
 static void log_effect(rtdd_ctx *ctx, PendingOp::Kind kind, const uint8_t *original, size_t originalPitch, const uint8_t *gray, size_t grayPitch,
                        const float *depth, size_t depthPitch, uint8_t *artistic, size_t artisticPitch, int rows, int cols) {
-    if (ctx->healing || ctx->pending.empty() || ctx->pending.size() >= kMaxPendingOps) return;
+    if (ctx->healing || ctx->pending.empty()) return;
+    prune_confirmed(ctx);
+    if (ctx->pending.empty() || ctx->pending.size() >= kMaxPendingOps) return;
     PendingOp op;
     op.kind = kind; op.opt = ctx->opt; op.id = ++ctx->op_counter;
     op.original = original; op.originalPitch = originalPitch; op.gray = gray; op.grayPitch = grayPitch;
     op.depth = const_cast<float *>(depth); op.depthPitch = depthPitch; op.artistic = artistic; op.artisticPitch = artisticPitch;
     op.rows = rows; op.cols = cols;
     ctx->pending.push_back(op);
+}
+
+// Sequence number of the kernel that publishes the LAST result of a logged call (0: the call publishes no solve).
+static int last_seq(const PendingOp &op) {
+    if (op.kind == PendingOp::kSolve) return op.seq;
+    if (op.kind != PendingOp::kEstimate) return 0;
+    int m = 0;
+    for (int l = 0; l < 32; l++) if (op.level_seq[l] > m) m = op.level_seq[l];
+    return m;
+}
+
+// The copy-back kernels report, in page-locked memory, the sequence number of the latest solve whose result they published while the
+// status word was clear (persist_sync.hpp solve_is_dead).  Every logged call up to and including that solve -- the effects queued in
+// front of it too: they ran behind solves that had succeeded -- can never be asked for again, so it leaves the log here, without any
+// synchronisation: the log holds the calls still in flight (plus the effects behind the last solve), not everything since the last
+// rtdd_ctx_synchronize, and the caller's pointers are kept no longer than any asynchronous call keeps them.
+void prune_confirmed(rtdd_ctx *ctx) {
+    if (!ctx->confirm_host || ctx->pending.empty() || ctx->healing) return;
+    const int confirmed = *(volatile int *)ctx->confirm_host;
+    size_t n = 0;
+    for (size_t i = 0; i < ctx->pending.size(); i++) {
+        const int s = last_seq(ctx->pending[i]);
+        if (s != 0 && s <= confirmed) n = i + 1;
+    }
+    if (n) ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + n);
 }
 
 static bool op_holds(const PendingOp &op, int seq) {
@@ -132,19 +159,26 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
         return fail(ctx, RTDD_ERR_TIMEOUT, "blocked sweep kernel: a wave timed out waiting for a neighbouring wave of its own workgroup (internal error); "
                                            "the results since the last synchronisation are invalid");
     }
-    if (ctx->healing || ctx->pending_overflow) {
+    // Persistence off, and suspended: rearm_after solves after the first heal, twice as many after every further one, for good after
+    // kMaxRearms heals (an unchanged main.cpp on the drop-in shim can set no option: one scheduling accident on a shared GPU must not
+    // cost it the persistent kernel until exit, and a GPU that stays shared must not cost it a 200 ms stall every few frames).
+    ctx->opt.persistent = 0;
+    ctx->heals++;
+    if (ctx->heals > kMaxRearms || ctx->opt.rearm_after <= 0) ctx->persist_suspend = -1;
+    else { const long long n = (long long)ctx->opt.rearm_after << (ctx->heals - 1); ctx->persist_suspend = n > (1 << 30) ? (1 << 30) : (int)n; }
+    if (ctx->healing || ctx->pending_overflow || !ctx->opt.timeout_heal) {
         std::string msg = kTimeoutText;
-        msg += ctx->healing ? "; it happened again while the calls were being run again without persistence" : "; too many calls were queued without a synchronisation to run them again";
+        msg += ctx->healing ? "; it happened again while the calls were being run again without persistence"
+             : !ctx->opt.timeout_heal ? "; RTDD_OPT_TIMEOUT_HEAL is 0, so nothing was run again" : "; too many calls were queued without a synchronisation to run them again";
         msg += "; the results since the last synchronisation are invalid";
         ctx->pending.clear(); ctx->pending_overflow = false;
         return fail(ctx, RTDD_ERR_TIMEOUT, msg.c_str());
     }
-    // heal: persistence off from now on, the logged calls again from the first failed one
-    ctx->opt.persistent = 0;
-    ctx->heals++;
+    // heal: the logged calls again from the first failed one
     if (!ctx->heal_warned) {
         ctx->heal_warned = true;
-        std::fprintf(stderr, "rtdd: %s; running the affected calls again one launch per block of sweeps -- RTDD_OPT_PERSISTENT is 0 for this context from now on\n", kTimeoutText);
+        std::fprintf(stderr, "rtdd: %s; running the affected calls again one launch per block of sweeps -- persistent launches are suspended for this context's next %d solves "
+                             "(twice as long after every further time-out, for good after %d)\n", kTimeoutText, ctx->persist_suspend, kMaxRearms);
     }
     std::vector<PendingOp> ops;
     ops.swap(ctx->pending);
@@ -229,6 +263,13 @@ int rtdd_ctx_create(int device, rtdd_ctx **out) {
               hipMalloc((void **)&ctx->sync_words, kSyncWords * sizeof(int)) == hipSuccess &&
               hipMemset(ctx->sync_words, 0, kSyncWords * sizeof(int)) == hipSuccess;
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    // the word the copy-back kernels report confirmed solves in: page-locked host memory the device writes directly (persist_sync.hpp)
+    if (ok && hipHostMalloc((void **)&ctx->confirm_host, 64, hipHostMallocMapped) == hipSuccess) {
+        *ctx->confirm_host = 0;
+        void *dev_view = nullptr;
+        ok = hipHostGetDevicePointer(&dev_view, ctx->confirm_host, 0) == hipSuccess &&
+             hipMemcpy(ctx->sync_words + kSyncConfirmPtr, &dev_view, sizeof(dev_view), hipMemcpyHostToDevice) == hipSuccess;
+    } else ok = false;
     if (!ok) { rtdd_ctx_destroy(ctx); return RTDD_ERR_HIP; }
     *out = ctx;
     return RTDD_OK;
@@ -246,6 +287,7 @@ int rtdd_ctx_destroy(rtdd_ctx *ctx) {
     if (ctx->residual_dev) (void)hipFree(ctx->residual_dev);
     if (ctx->sync_words) (void)hipFree(ctx->sync_words);
     if (ctx->sat) (void)hipFree(ctx->sat);
+    if (ctx->confirm_host) (void)hipHostFree(ctx->confirm_host);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
     return RTDD_OK;
@@ -253,6 +295,9 @@ int rtdd_ctx_destroy(rtdd_ctx *ctx) {
 
 int rtdd_ctx_set_stream(rtdd_ctx *ctx, rtdd_stream stream) {
     if (!ctx) return RTDD_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    // the logged calls were queued on the OLD stream: confirm (or heal) them there before anything is queued on the new one
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     ctx->stream = (hipStream_t)stream;
     return RTDD_OK;
 }
@@ -273,7 +318,9 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
         case RTDD_OPT_DEFOCUS_PATH: REQUIRE(ctx, value >= 0 && value <= 2, "defocus path must be 0..2"); ctx->opt.defocus_path = value; if (value == 0) ctx->defocus_table_sticky = false; break;      // (setting the automatic choice again forgets what earlier depths made it choose)
         case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 16, "tile must be 0..16"); ctx->opt.tile = value; break;
-        case RTDD_OPT_PERSISTENT: ctx->opt.persistent = value ? 1 : 0; break;
+        case RTDD_OPT_PERSISTENT: ctx->opt.persistent = ctx->persistent_wanted = value ? 1 : 0; ctx->persist_suspend = 0; break;    // (said explicitly: armed at once, whatever a heal suspended)
+        case RTDD_OPT_TIMEOUT_HEAL: ctx->opt.timeout_heal = value ? 1 : 0; if (!value && !ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } break;
+        case RTDD_OPT_PERSISTENT_REARM_AFTER: REQUIRE(ctx, value >= 0 && value <= (1 << 20), "must be 0..2^20"); ctx->opt.rearm_after = value; break;
         case RTDD_OPT_AUTO_CYCLE_FIXED_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fixed_ns = value; break;
         case RTDD_OPT_AUTO_CYCLE_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fs_per_px = value; break;
         case RTDD_OPT_AUTO_SWEEP_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_sweep_fs_per_px = value; break;
@@ -304,6 +351,9 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_DEBUG_POLL_LIMIT_US: *value = ctx->opt.debug_poll_limit_us; break;
         case RTDD_OPT_DEBUG_FORCE_STATUS: *value = ctx->opt.debug_force_status; break;
         case RTDD_OPT_TIMEOUT_HEALS: *value = ctx->heals; break;
+        case RTDD_OPT_TIMEOUT_HEAL: *value = ctx->opt.timeout_heal; break;
+        case RTDD_OPT_PERSISTENT_REARM_AFTER: *value = ctx->opt.rearm_after; break;
+        case RTDD_OPT_PERSISTENT_SUSPENDED: *value = ctx->persist_suspend; break;
         case RTDD_OPT_DEFOCUS_LAST_PATH: *value = ctx->defocus_last_path; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
@@ -611,8 +661,13 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
     if (rc != RTDD_OK) return rc;
     DeviceGuard g(ctx->device);
-    ctx->solve_seq = ctx->solve_seq >= (1 << 30) ? 1 : ctx->solve_seq + 1;
-    const int seq = ctx->solve_seq;
+    if (ctx->solve_seq >= (1 << 30)) {              // (once in 10^9 solves) the sequence numbers start over: nothing may be left that compares against them
+        if (!ctx->healing) { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
+        RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *(volatile int *)ctx->confirm_host = 0;
+        ctx->solve_seq = 0;
+    }
+    const int seq = ++ctx->solve_seq;
     const Options asked = ctx->opt;
     rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq);
     // A residual check inside the solve found the status word set, and the calls before this one have been healed (check_persistent_status):
@@ -621,7 +676,9 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     if (rc == kRestartSolve) rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq);
     if (rc == kRestartSolve) rc = fail(ctx, RTDD_ERR_TIMEOUT, "the solve was restarted after a timed-out persistent launch and failed again");
     if (rc != RTDD_OK) return rc;
-    if (!ctx->healing && !ctx->in_estimate) {       // remembered until the next synchronising call has seen the status word clear
+    if (!ctx->healing && ctx->persist_suspend > 0 && --ctx->persist_suspend == 0 && ctx->persistent_wanted) ctx->opt.persistent = 1;     // re-armed (check_persistent_status)
+    if (!ctx->healing && !ctx->in_estimate && ctx->opt.timeout_heal) {       // remembered until a copy-back kernel or a synchronising call has confirmed it
+        prune_confirmed(ctx);
         if (ctx->pending.size() >= kMaxPendingOps) { ctx->pending.clear(); ctx->pending_overflow = true; }
         PendingOp op;
         op.kind = PendingOp::kSolve; op.opt = asked; op.seq = seq;
@@ -668,6 +725,9 @@ int rtdd_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch, c
     REQUIRE(ctx, rows > 0 && cols > 0 && grayPitch >= (size_t)cols && depthPitch >= (size_t)cols * 4, "bad size or pitch");
     if (ctx->maxLevel < 0) return fail(ctx, RTDD_ERR_STATE, "rtdd_allocate has not been called (maxLevel unknown)");
     DeviceGuard g(ctx->device);
+    // reads a depth image a logged, unconfirmed solve may not have written (its copy-back stores nothing after a time-out) and is not
+    // logged itself: confirm or heal first.  Nothing logged: nothing to wait for.
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     return launch_index_to_weight(ctx, gray, grayPitch, depth, depthPitch, index2, level, rows, cols);
 }
 
@@ -681,6 +741,7 @@ int rtdd_convert_to_float(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, fl
     if (rows == 0 || cols == 0) return RTDD_OK;
     REQUIRE(ctx, srcPitch >= (size_t)cols * 3 && dstPitch >= (size_t)cols * 4 && maskPitch >= (size_t)cols, "pitch smaller than a row");
     DeviceGuard g(ctx->device);
+    pyramid_note_write(ctx, dst, dst);             // (the coarsest depth image of the context's pyramid? then the next estimate injects again)
     return launch_convert(ctx, src, srcPitch, dst, dstPitch, mask, maskPitch, rows, cols);
 }
 

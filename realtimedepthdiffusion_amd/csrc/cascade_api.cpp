@@ -47,6 +47,9 @@ void pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited)
     if (!p) return;
     for (int l = 0; l < p->levels; l++)
         if (inside(p->scribble[l], scribble) || inside(p->edited[l], edited) || inside(p->scribble[l], edited) || inside(p->edited[l], scribble)) p->annotation_dirty = true;
+    // the coarsest depth image carries the injected labels of src/main.cpp:257-259, which an estimate only renews when the annotation
+    // changed: whoever overwrites it through the library (rtdd_upload, rtdd_convert_to_float, rtdd_pyrup_depth) makes the next estimate inject again
+    if (p->levels > 0 && (inside(p->depth[p->levels - 1], scribble) || inside(p->depth[p->levels - 1], edited))) p->annotation_dirty = true;
 }
 
 static int alloc_image(rtdd_ctx *ctx, Image &im, int rows, int cols, int elem, int fill) {
@@ -239,7 +242,8 @@ static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, s
         DeviceGuard g(ctx->device);
         RTDD_HIP(ctx, hipMemcpy2DAsync(u8_copy, u8_copy_pitch, p->depth_u8.ptr, p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (rc == RTDD_OK && !ctx->healing) {
+    if (rc == RTDD_OK && !ctx->healing && ctx->opt.timeout_heal) {
+        prune_confirmed(ctx);
         if (ctx->pending.size() >= kMaxPendingOps) { ctx->pending.clear(); ctx->pending_overflow = true; }
         op.id = ++ctx->op_counter;
         if (op_id) *op_id = op.id;
@@ -458,6 +462,10 @@ int rtdd_pyrup_depth(rtdd_ctx *ctx, const float *src, size_t srcPitch, int rows,
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, src && dst && rows > 0 && cols > 0 && dstRows > 0 && dstCols > 0 && srcPitch >= (size_t)cols * 4 && dstPitch >= (size_t)dstCols * 4, "bad argument");
     DeviceGuard g(ctx->device);
+    // (as rtdd_index_to_weight: `src` may be the output of a logged solve whose persistent launch gave up -- the spelt-out cascade,
+    // solve -> pyrUp -> inject -> solve, queued asynchronously)
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
+    pyramid_note_write(ctx, dst, dst);
     return launch_pyrup_inject(ctx, src, srcPitch, rows, cols, dst, dstPitch, dstRows, dstCols, nullptr, 0, nullptr, 0);
 }
 
@@ -465,6 +473,7 @@ int rtdd_depth_to_u8(rtdd_ctx *ctx, const float *src, size_t srcPitch, uint8_t *
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, src && dst && rows > 0 && cols > 0 && srcPitch >= (size_t)cols * 4 && dstPitch >= (size_t)cols, "bad argument");
     DeviceGuard g(ctx->device);
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }     // (as rtdd_pyrup_depth)
     return launch_depth_to_u8(ctx, src, srcPitch, dst, dstPitch, rows, cols);
 }
 
@@ -472,6 +481,8 @@ int rtdd_upload(rtdd_ctx *ctx, void *dev, size_t devPitch, const void *host, siz
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, dev && host && rows >= 0 && devPitch >= widthBytes && hostPitch >= widthBytes, "bad argument");
     DeviceGuard g(ctx->device);
+    // the destination may be an input of a logged call that still has to be run again: settle first (this call synchronises anyway)
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     pyramid_note_write(ctx, dev, dev);
     RTDD_HIP(ctx, hipMemcpy2DAsync(dev, devPitch, host, hostPitch, widthBytes, rows, hipMemcpyHostToDevice, ctx->stream));
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));

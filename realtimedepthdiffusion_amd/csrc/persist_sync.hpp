@@ -14,6 +14,9 @@
 //   [kSyncLimit]     poll limit in 10 ns ticks of s_memrealtime (0 = kDefaultPollLimit).
 //   [kSyncFailedSeq] sequence number of the first solve whose copy-back kernel (k_finish / k_pyrup_inject) found the status word set and
 //                    therefore stored nothing: the host re-runs the pending calls from that one on (api.cpp heal_pending).  0 = none.
+//   [kSyncConfirmPtr] (two ints, an address) where the copy-back kernels report the sequence number of a solve whose result they DID publish:
+//                    a word in page-locked host memory, so that the host can drop confirmed calls from its log without synchronising
+//                    (api.cpp prune_confirmed).  Written by one lane, only while the status word is clear.
 //   [kSyncFlags ..]  one block counter per tile.  Monotonic over the life of the context: launch L's workgroups publish base_L + block
 //                    number, base_L handed in by the host (api.cpp prepare_persistent_launch), so nothing is zeroed between launches.
 #pragma once
@@ -23,7 +26,8 @@ namespace rtdd {
 
 // kSyncFlagStride: ints between the flags of consecutive tiles.  64 = one flag per 256 bytes (its own line, and neighbouring tiles on different memory channels): a tile's flag is stored once and polled
 // by up to 8 neighbours, all through memory (sc1); packed 32 to a line (round 2) every store and poll of 32 tiles met on one line: 1080p 1.17 -> 1.24 Tpx-it/s with one line each, +1.5 % more at 256 bytes.
-constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncNonLocal = 3 /* k_defocus_tile met windows beyond its region (effect_kernels.hip) */, kSyncFailedSeq = 4, kSyncFlags = 32, kSyncMaxTiles = 1024, kSyncFlagStride = 64;
+constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncNonLocal = 3 /* k_defocus_tile met windows beyond its region (effect_kernels.hip) */, kSyncFailedSeq = 4,
+              kSyncConfirmPtr = 6 /* two ints: the device address of the context's page-locked `confirmed sequence number` word */, kSyncFlags = 32, kSyncMaxTiles = 1024, kSyncFlagStride = 64;
 constexpr int kSyncWords = kSyncFlags + kSyncMaxTiles * kSyncFlagStride;              // size of sync_words in ints
 constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: legitimate waits are microseconds
 
@@ -33,7 +37,13 @@ constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: le
 // (src/GPUSolver.cu:311-314); here a failed solve leaves its INPUT in place so that the host can run it again.
 __device__ __forceinline__ bool solve_is_dead(int *sync_words, int seq, bool first) {
     if (!sync_words) return false;
-    if (__hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return false;
+    if (__hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (first && seq != 0) {                   // this solve's result is being published: tell the host (one lane, one posted write)
+            int *confirm = *(int *const *)(sync_words + kSyncConfirmPtr);
+            if (confirm) __hip_atomic_store(confirm, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return false;
+    }
     if (first && __hip_atomic_load(&sync_words[kSyncFailedSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
         __hip_atomic_store(&sync_words[kSyncFailedSeq], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;

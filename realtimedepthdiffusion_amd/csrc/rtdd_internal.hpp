@@ -58,6 +58,8 @@ struct Options {
     int debug_withhold_tile = 0;     // RTDD_OPT_DEBUG_WITHHOLD_TILE: tile number + 1 whose exchange flag is never published (0 = off)
     int debug_poll_limit_us = 0;     // RTDD_OPT_DEBUG_POLL_LIMIT_US: exchange poll limit (0 = default, 200 ms)
     int debug_force_status = 0;      // RTDD_OPT_DEBUG_FORCE_STATUS: one-shot value for the status word behind the next blocked launch
+    int timeout_heal = 1;            // RTDD_OPT_TIMEOUT_HEAL: 1 a timed-out persistent launch is healed (calls logged, run again); 0 it is reported
+    int rearm_after = 32;            // RTDD_OPT_PERSISTENT_REARM_AFTER: solves without persistence after the first heal, doubling with every further one
 };
 
 // One asynchronous call whose results the caller has not yet seen confirmed by a synchronising call: what check_persistent_status
@@ -85,6 +87,7 @@ struct PendingOp {
 };
 constexpr int kRestartSolve = -1000;      // internal status: the pending calls were healed inside a solve's residual check; that solve starts over
 constexpr size_t kMaxPendingOps = 4096;
+constexpr int kMaxRearms = 4;             // heals after which persistence stays off for the context's life
 
 }  // namespace rtdd
 
@@ -124,6 +127,11 @@ struct rtdd_ctx {
     bool healing = false;           // a replay is running: nothing is logged, a second timeout is final
     bool heal_warned = false;
     int heals = 0;                  // RTDD_OPT_TIMEOUT_HEALS
+    // opt.persistent is what the launchers read; persistent_wanted is what the caller asked for.  A heal switches opt.persistent off and
+    // suspends it for persist_suspend more solves (rearm_after, doubling with every heal; -1 after kMaxRearms heals: off for good)
+    int persistent_wanted = 1;
+    int persist_suspend = 0;        // RTDD_OPT_PERSISTENT_SUSPENDED
+    int *confirm_host = nullptr;    // page-locked: sequence number of the latest solve whose copy-back kernel published its result (persist_sync.hpp)
     unsigned long long op_counter = 0;
     int guard_seq = 0;              // sequence number the next guarded copy-back kernel reports when it finds the status word set
     bool persistent_used = false;   // a launch that can set the status word (sync_words[kSyncStatus]) happened since the last status check
@@ -236,6 +244,7 @@ void pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited)
 int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base);
 // in_solve: called from a residual check inside rtdd_solve_ex -- after a successful heal of the calls before it that solve starts over (kRestartSolve)
 int check_persistent_status(rtdd_ctx *ctx, bool in_solve = false);
+void prune_confirmed(rtdd_ctx *ctx);    // drop the logged calls a copy-back kernel has confirmed (no synchronisation)
 int settle_pending(rtdd_ctx *ctx);      // before a call changes what the logged calls ran on: synchronise + check (+ heal) while that state still exists
 // cascade_api.cpp: levels from_level .. 0 of an estimate (src/main.cpp:261-291); level_seq (optional) receives each level's solve sequence number
 int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq);

@@ -29,6 +29,12 @@
 #include "sweep_common.hpp"
 #include "sweep_diag.hpp"      // RTDD_STAMP / RTDD_TL / RTDD_XT: empty unless a diagnostic micro-benchmark asks for them
 
+// RTDD_MASKED_UPDATE (default 1): the update's last fma under an EXEC mask instead of a v_cndmask behind it, omega / gamma in VGPRs
+// (sweep_common.hpp masked_fmac4); 0 = the round-4 form, kept for A/B builds (scripts/build_variant.sh).
+#ifndef RTDD_MASKED_UPDATE
+#define RTDD_MASKED_UPDATE 1
+#endif
+
 namespace rtdd {
 
 

@@ -75,4 +75,35 @@ __device__ __forceinline__ float rcp_rn(float d) {
     return __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
 }
 
+// ---- the last operation of a pixel's update under an EXEC mask ----------------------------------------------------------------
+// x_{k+1} = fma(omega, t, x_{k-1}) overwrites x_{k-1}'s register -- for FREE pixels only; a Dirichlet pixel keeps its value, and its
+// register holds that value in both iterates (k_prepare stores it in both planes, sweep_tile_setup.inc enforces it on the tile).  So
+// the select of `(dirichlet ? x : v)` -- a v_cndmask_b32 with an SGPR-pair mask, half rate on gfx950 (4.4 cycles per wave-instruction
+// against 3.1 for v_fmac_f32 with three VGPRs and 4.3 for any fma with an SGPR operand: scripts/ubench/excp_probe.hip,
+// profiles/r05_excp_probe.txt) -- becomes the EXEC mask of the fma itself: s_mov_b64 exec (scalar unit) + v_fmac_f32 (full rate), omega
+// in a VGPR.  ONE asm statement per row so that the compiler can schedule nothing between the EXEC writes; EXEC is all ones on entry
+// and on exit: every thread of the (whole-wave) workgroup runs the sweeps, all control flow around them is wave-uniform.  An SALU
+// write of EXEC needs no wait state in front of a (non-DPP) VALU instruction on gfx9.
+__device__ __forceinline__ void masked_fmac4(float &o0, float &o1, float &o2, float &o3, float w, float t0, float t1, float t2, float t3,
+                                             unsigned long long m0, unsigned long long m1, unsigned long long m2, unsigned long long m3) {
+    asm("s_mov_b64 exec, %9\n\tv_fmac_f32_e32 %0, %4, %5\n\t"
+        "s_mov_b64 exec, %10\n\tv_fmac_f32_e32 %1, %4, %6\n\t"
+        "s_mov_b64 exec, %11\n\tv_fmac_f32_e32 %2, %4, %7\n\t"
+        "s_mov_b64 exec, %12\n\tv_fmac_f32_e32 %3, %4, %8\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+        : "v"(w), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+}
+// the same for the un-contracted update, (omega * t) + x_{k-1}: the product is formed outside, the addition is masked
+__device__ __forceinline__ void masked_add4(float &o0, float &o1, float &o2, float &o3, float p0, float p1, float p2, float p3,
+                                            unsigned long long m0, unsigned long long m1, unsigned long long m2, unsigned long long m3) {
+    asm("s_mov_b64 exec, %8\n\tv_add_f32_e32 %0, %4, %0\n\t"
+        "s_mov_b64 exec, %9\n\tv_add_f32_e32 %1, %5, %1\n\t"
+        "s_mov_b64 exec, %10\n\tv_add_f32_e32 %2, %6, %2\n\t"
+        "s_mov_b64 exec, %11\n\tv_add_f32_e32 %3, %7, %3\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+}
+
 }  // namespace rtdd
