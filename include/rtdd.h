@@ -114,10 +114,11 @@ enum rtdd_option {
     RTDD_OPT_TIMEOUT_HEALS = 14,    /* read only: how many times this context has healed a timed-out persistent launch (see RTDD_ERR_TIMEOUT) */
     RTDD_OPT_TIMEOUT_HEAL = 16,     /* 1 (default): heal as described at RTDD_ERR_TIMEOUT; 0: remember nothing, report the time-out */
     RTDD_OPT_PERSISTENT_REARM_AFTER = 17, /* solves run without persistence after the FIRST healed time-out before persistent launches are tried
-                                       again (default 32; doubles with every further time-out; after four time-outs persistence stays off;
+                                       again (default 64; doubles with every further time-out; after four time-outs persistence stays off;
                                        0: off for good at the first).  Setting RTDD_OPT_PERSISTENT to 1 explicitly re-arms at once */
     RTDD_OPT_PERSISTENT_SUSPENDED = 18, /* read only: 0 persistent launches are armed (or RTDD_OPT_PERSISTENT is 0 by the caller's choice); n > 0: suspended
                                        for n more solves after a time-out; -1: off for the rest of the context's life */
+    RTDD_OPT_PENDING_CALLS = 19,    /* read only: calls currently remembered for a replay (see RTDD_ERR_TIMEOUT): those still in flight */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),

@@ -162,10 +162,12 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
     // Persistence off, and suspended: rearm_after solves after the first heal, twice as many after every further one, for good after
     // kMaxRearms heals (an unchanged main.cpp on the drop-in shim can set no option: one scheduling accident on a shared GPU must not
     // cost it the persistent kernel until exit, and a GPU that stays shared must not cost it a 200 ms stall every few frames).
-    ctx->opt.persistent = 0;
-    ctx->heals++;
-    if (ctx->heals > kMaxRearms || ctx->opt.rearm_after <= 0) ctx->persist_suspend = -1;
-    else { const long long n = (long long)ctx->opt.rearm_after << (ctx->heals - 1); ctx->persist_suspend = n > (1 << 30) ? (1 << 30) : (int)n; }
+    if (!ctx->healing) {                            // (a second time-out while the calls are being run again is part of the same event)
+        ctx->opt.persistent = 0;
+        ctx->heals++;
+        if (ctx->heals > kMaxRearms || ctx->opt.rearm_after <= 0) ctx->persist_suspend = -1;
+        else { const long long n = (long long)ctx->opt.rearm_after << (ctx->heals - 1); ctx->persist_suspend = n > (1 << 30) ? (1 << 30) : (int)n; }
+    }
     if (ctx->healing || ctx->pending_overflow || !ctx->opt.timeout_heal) {
         std::string msg = kTimeoutText;
         msg += ctx->healing ? "; it happened again while the calls were being run again without persistence"
@@ -354,6 +356,7 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_TIMEOUT_HEAL: *value = ctx->opt.timeout_heal; break;
         case RTDD_OPT_PERSISTENT_REARM_AFTER: *value = ctx->opt.rearm_after; break;
         case RTDD_OPT_PERSISTENT_SUSPENDED: *value = ctx->persist_suspend; break;
+        case RTDD_OPT_PENDING_CALLS: prune_confirmed(ctx); *value = (int)ctx->pending.size(); break;
         case RTDD_OPT_DEFOCUS_LAST_PATH: *value = ctx->defocus_last_path; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }

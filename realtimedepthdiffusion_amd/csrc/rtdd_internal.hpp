@@ -59,7 +59,7 @@ struct Options {
     int debug_poll_limit_us = 0;     // RTDD_OPT_DEBUG_POLL_LIMIT_US: exchange poll limit (0 = default, 200 ms)
     int debug_force_status = 0;      // RTDD_OPT_DEBUG_FORCE_STATUS: one-shot value for the status word behind the next blocked launch
     int timeout_heal = 1;            // RTDD_OPT_TIMEOUT_HEAL: 1 a timed-out persistent launch is healed (calls logged, run again); 0 it is reported
-    int rearm_after = 32;            // RTDD_OPT_PERSISTENT_REARM_AFTER: solves without persistence after the first heal, doubling with every further one
+    int rearm_after = 64;            // RTDD_OPT_PERSISTENT_REARM_AFTER: solves without persistence after the first heal, doubling with every further one
 };
 
 // One asynchronous call whose results the caller has not yet seen confirmed by a synchronising call: what check_persistent_status

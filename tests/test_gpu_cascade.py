@@ -299,3 +299,56 @@ def test_full_size_dataset_pair_end_to_end(oracle, lut):
         assert np.array_equal(down(art), oracle.defocus(bgr, ref.depth[0], threads=min(8, oracle.max_threads())))
         c.GPUSimulateHaze(o, d, art, rows, cols)
         assert np.array_equal(down(art), oracle.haze(bgr, ref.depth[0], 1))          # bit-exact since round 3: one deterministic exp on both sides
+
+
+def test_the_spelt_out_cascade_heals_too(oracle, lut):
+    """the cascade spelt out through the C ABI -- solve(level 1) -> rtdd_pyrup_depth -> rtdd_convert_to_float -> solve(level 0)
+    -> rtdd_depth_to_u8, all queued without a synchronisation -- with level 1's persistent launch timing out.  k_finish stores nothing,
+    so rtdd_pyrup_depth would read level 1's INPUT and the heal would replay only the solves: a silently wrong map.  The calls that read
+    a solve's output without being logged now settle the log first; the result is the oracle's."""
+    rows, cols = 2160, 3840                                    # level 1 = 1080p: persistent (252 tiles); level 0 = 4K: launch per block
+    p0 = make_problem(rows, cols, seed=61)
+    r1, c1 = rows // 2, cols // 2
+    p1 = make_problem(r1, c1, seed=62)
+    # reference: level 1 (gated rule, level 1 of 2 is the coarsest -> un-gated) then pyrUp, injection, level 0, u8
+    d1 = oracle.solve(p1["depth"].copy(), p1["mask"], p1["gray"], 40, 1, 1, lut, 1, threads=oracle.max_threads())
+    d0 = oracle.pyrup_f32(d1, rows, cols, contract=1)
+    oracle.convert_to_float(p0["edited"], d0, p0["mask"])
+    d0 = oracle.solve(d0, p0["mask"], p0["gray"], 16, 0, 1, lut, 1, threads=oracle.max_threads())
+    want_u8 = oracle.depth_to_u8(d0)
+    with rt.Context(0) as c:
+        c.GPUAllocateDeviceMemory(rows, cols, 2); c.GPULoadWeights(0.4)
+        c.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 100 + 1)
+        g1, m1, x1 = up(p1["gray"]), up(p1["mask"]), up(p1["depth"])
+        g0, m0, e0 = up(p0["gray"]), up(p0["mask"]), up(p0["edited"])
+        x0 = up(np.zeros((rows, cols), np.float32)); u8 = up(np.zeros((rows, cols), np.uint8))
+        c.GPUMatrixFreeSolver(x1, m1, g1, r1, c1, 0.4, 40, 0.0, 1)
+        c.pyrup_depth(x1, r1, c1, x0, rows, cols)
+        c.GPUConvertToFloat(e0, x0, m0, rows, cols)
+        c.GPUMatrixFreeSolver(x0, m0, g0, rows, cols, 0.4, 16, 0.0, 0)
+        c.depth_to_u8(x0, u8, rows, cols)
+        c.synchronize()
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1
+        assert_bit_equal(down(x1), d1, "level 1 of the spelt-out cascade")
+        assert_bit_equal(down(x0), d0, "level 0 of the spelt-out cascade")
+        assert np.array_equal(down(u8), want_u8)
+
+
+def test_an_upload_into_the_coarsest_depth_image_makes_the_next_estimate_inject_again(oracle, lut):
+    """the injection of the coarsest level (src/main.cpp:257-259) is only renewed when the annotation changed; rtdd_upload /
+    rtdd_convert_to_float / rtdd_pyrup_depth INTO the coarsest RTDD_IMG_DEPTH through the library must count as such a change."""
+    rows, cols = 270, 480
+    bgr, ann = _bgr(rows, cols, 91)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=4)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        levels = c.pyramid_create(rows, cols)
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann))
+        ref.estimate(200); c.estimate_depth(200); c.synchronize()
+        ptr, pitch, lr, lc = c.pyramid_image(rt.IMG_DEPTH, levels - 1)
+        junk = np.full((lr, lc), 7.0, np.float32)
+        c._check(rt.lib().rtdd_upload(c._h, C.c_void_p(ptr), C.c_size_t(pitch), C.c_void_p(junk.ctypes.data), C.c_size_t(lc * 4), C.c_size_t(lc * 4), C.c_int(lr)))
+        ref.depth[levels - 1][...] = 7.0                       # what the reference's per-frame injection then restores at the labelled pixels
+        ref.estimate(200); c.estimate_depth(200); c.synchronize()
+        for l in range(levels):
+            assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, l), ref.depth[l], f"level {l} after an upload into the coarsest depth image")

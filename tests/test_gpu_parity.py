@@ -732,3 +732,107 @@ def test_a_second_time_out_during_the_replay_is_reported(oracle, lut):
         c.synchronize()                                                  # reported once
         c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 40, 0.0, 0); c.synchronize()
         assert_bit_equal(down(d), oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 40, 0, 0, lut, 1, threads=4), "the context works afterwards")
+
+
+def test_persistence_is_rearmed_after_a_heal_with_a_bounded_back_off(oracle, lut, capfd):
+    """One time-out must not cost an unchanged main.cpp the persistent kernel until exit: after a heal persistent
+    launches are suspended for RTDD_OPT_PERSISTENT_REARM_AFTER solves, then tried again; a second time-out doubles the wait, the
+    fifth switches persistence off for good.  Every result on the way is the oracle's."""
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=23)
+    m, g = up(p["mask"]), up(p["gray"])
+    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 24, 0, 0, lut, 1, threads=oracle.max_threads())
+
+    def solve(c):
+        d = up(p["depth"])
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 24, 0.0, 0); c.synchronize()
+        assert_bit_equal(down(d), want, "solve on the way")
+        return c.last_solve_info().persistent
+
+    with _fresh(rows, cols, True) as c:
+        c.set_option(rt.OPT_PERSISTENT_REARM_AFTER, 2)
+        assert solve(c) == 0 and c.get_option(rt.OPT_TIMEOUT_HEALS) == 1          # timed out, healed (the replay is not persistent)
+        assert c.get_option(rt.OPT_PERSISTENT) == 0 and c.get_option(rt.OPT_PERSISTENT_SUSPENDED) == 2
+        c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 0)                              # the GPU is no longer "shared"
+        assert solve(c) == 0 and c.get_option(rt.OPT_PERSISTENT_SUSPENDED) == 1
+        assert solve(c) == 0 and c.get_option(rt.OPT_PERSISTENT_SUSPENDED) == 0 and c.get_option(rt.OPT_PERSISTENT) == 1   # re-armed for the next one
+        assert solve(c) == 1 and c.get_option(rt.OPT_TIMEOUT_HEALS) == 1
+        # shared again: the back-off doubles (4, 8, 16), the fifth time-out is the last
+        c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 100 + 1)
+        for heals, wait in ((2, 4), (3, 8), (4, 16)):
+            assert solve(c) == 0 and c.get_option(rt.OPT_TIMEOUT_HEALS) == heals and c.get_option(rt.OPT_PERSISTENT_SUSPENDED) == wait
+            for _ in range(wait):
+                assert solve(c) == 0
+            assert c.get_option(rt.OPT_PERSISTENT) == 1
+        assert solve(c) == 0 and c.get_option(rt.OPT_TIMEOUT_HEALS) == 5 and c.get_option(rt.OPT_PERSISTENT_SUSPENDED) == -1
+        for _ in range(3):
+            assert solve(c) == 0
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 5 and c.get_option(rt.OPT_PERSISTENT) == 0
+        c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 0); c.set_option(rt.OPT_PERSISTENT, 1)      # said explicitly: armed at once
+        assert solve(c) == 1 and c.get_option(rt.OPT_PERSISTENT_SUSPENDED) == 0
+    assert capfd.readouterr().err.count("rtdd: persistent sweep kernel") == 1                # one warning per context
+
+
+def test_with_healing_switched_off_a_time_out_is_reported_and_nothing_is_remembered(oracle, lut):
+    """RTDD_OPT_TIMEOUT_HEAL = 0 (a host that cannot keep its buffers alive until an rtdd call has synchronised): no call is
+    logged, the time-out comes back as RTDD_ERR_TIMEOUT, the depth keeps the solve's input, and the context works afterwards."""
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=29)
+    m, g = up(p["mask"]), up(p["gray"])
+    with _fresh(rows, cols, True) as c:
+        c.set_option(rt.OPT_TIMEOUT_HEAL, 0)
+        d = up(p["depth"])
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 40, 0.0, 0)
+        assert c.get_option(rt.OPT_PENDING_CALLS) == 0
+        with pytest.raises(rt.RtddError) as e:
+            c.synchronize()
+        assert e.value.status == rt.RTDD_ERR_TIMEOUT and "RTDD_OPT_TIMEOUT_HEAL" in str(e.value), e.value
+        assert_bit_equal(down(d), p["depth"], "a reported time-out leaves the input")
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1 and c.get_option(rt.OPT_PERSISTENT) == 0
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 40, 0.0, 0); c.synchronize()
+        assert_bit_equal(down(d), oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 40, 0, 0, lut, 1, threads=oracle.max_threads()), "the context works afterwards")
+
+
+def test_confirmed_calls_leave_the_log_without_a_library_synchronisation(oracle, lut):
+    """The log of calls a heal would run again holds calls IN FLIGHT, not history (it kept the caller's pointers for up to 4096
+    calls until an rtdd-level synchronisation): the copy-back kernel of a solve reports its sequence number in page-locked memory, and
+    the next logging call drops everything up to it -- after a torch / hipDeviceSynchronize of the caller's own, too."""
+    import torch
+    rows, cols = 270, 480
+    p = make_problem(rows, cols, seed=31)
+    with _fresh(rows, cols, False) as c:
+        d, m, g = up(p["depth"]), up(p["mask"]), up(p["gray"])
+        rgb = up(np.zeros((rows, cols, 3), np.uint8)); art = up(np.zeros((rows, cols, 3), np.uint8))
+        for _ in range(40):
+            c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 8, 0.0, 0)
+            c.GPUSimulateHaze(rgb, d, art, rows, cols)
+        torch.cuda.synchronize()                              # not a library call
+        assert c.get_option(rt.OPT_PENDING_CALLS) <= 1        # (the haze behind the last solve: it leaves with the next confirmed solve)
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 8, 0.0, 0)
+        torch.cuda.synchronize()
+        assert c.get_option(rt.OPT_PENDING_CALLS) == 0
+        c.synchronize()
+        want = p["depth"].copy()
+        for _ in range(41):
+            want = oracle.solve(want, p["mask"], p["gray"], 8, 0, 0, lut, 1, threads=4)
+        assert_bit_equal(down(d), want, "41 chained solves")
+
+
+def test_set_stream_settles_the_log_on_the_old_stream(oracle, lut):
+    """rtdd_ctx_set_stream with an unconfirmed, timed-out solve queued on the old stream: the heal runs there, before anything is
+    queued on the new stream."""
+    import torch
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=37)
+    m, g = up(p["mask"]), up(p["gray"])
+    with _fresh(rows, cols, True) as c:
+        d = up(p["depth"])
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 40, 0.0, 0)
+        s2 = torch.cuda.Stream()
+        c.set_stream(s2.cuda_stream)
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1 and c.get_option(rt.OPT_PENDING_CALLS) == 0
+        want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 40, 0, 0, lut, 1, threads=oracle.max_threads())
+        assert_bit_equal(down(d), want, "healed on the old stream")
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 40, 0.0, 0); c.synchronize()
+        assert_bit_equal(down(d), oracle.solve(want, p["mask"], p["gray"], 40, 0, 0, lut, 1, threads=oracle.max_threads()), "next solve on the new stream")
+        c.set_stream(0)
