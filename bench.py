@@ -39,6 +39,9 @@ WORKLOADS = {
     "960x540_jacobi125": dict(rows=540, cols=960, iters=125),
     # BASELINE config 4: a fixed batch of 64 independent 1080p images (distinct seeds), image i on rank i % N
     "batch64_1080p": dict(rows=1080, cols=1920, iters=1000, batch=64),
+    # the same batch as whole ESTIMATES (5-level cascades, src/main.cpp:232-295): a rank's images form one batched pyramid, every level of all
+    # of them in the same launches (rtdd_estimate_depth_batch); image i on rank i % N
+    "batch64_1080p_estimate": dict(rows=1080, cols=1920, iters=1000, batch=64, estimate=True),
     # extensions (BASELINE configs 3 and 5): solve from the cold start to a residual max|J(x)-x| <= 1e-4; `iters` is the cap
     "4k_rbsor_1e-4": dict(rows=2160, cols=3840, iters=400000, method="sor_cycles", tolerance=1e-4),
     "1080p_rbsor_1e-4": dict(rows=1080, cols=1920, iters=400000, method="sor_cycles", tolerance=1e-4),
@@ -62,7 +65,25 @@ VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 # path: 362 VALU instructions per 2 sweeps x 12 pixels = 15.1; 4 fma for the sum, 3 for the divide, 1.5 for the tiny-numerator test, 6
 # for clamp + update + Dirichlet select, ~0.6 bookkeeping; the lane shifts are LDS-crossbar permutes since round 3 and no longer VALU
 # work: 16.3 before).  Halo redundancy is NOT counted: `achieved` is useful work.
-VALU_OPS = {"jacobi": 15.1, "rbgs": 15.0, "sor_cycles": 15.0}
+VALU_OPS = {"jacobi": 14.5, "rbgs": 15.0, "sor_cycles": 15.0}
+# (14.5 since round 5: 348 per sweep pair -- the Dirichlet select became the EXEC mask of the update's last fma; 15.1 in rounds 3-4, which
+# `frac_at_round4_count` keeps comparable.  The Jacobi figure is RECOUNTED from the built object at run time where llvm-objdump is there
+# (scripts/isa_count.py: the fall-through path of the sweep-pair loop of k_sweep_blocked<32,1024,3,true,true>); the constant is the fallback
+# and tests/test_isa_hazards.py keeps the two equal.)
+VALU_OPS_ROUND4 = 15.1
+_valu_ops_source = {}
+
+
+def jacobi_valu_ops():
+    if "v" not in _valu_ops_source:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import isa_count
+            c = isa_count.sweep_pair()
+            _valu_ops_source.update(v=c["per_pixel_sweep"], src=f"counted now in the built sweep_blocked.o: {c['valu']} VALU instructions per sweep pair x 12 pixels (scripts/isa_count.py)")
+        except Exception as e:                      # no llvm-objdump / no object on this box
+            _valu_ops_source.update(v=VALU_OPS["jacobi"], src=f"recorded constant (the built object could not be disassembled here: {type(e).__name__})")
+    return _valu_ops_source["v"], _valu_ops_source["src"]
 # What the sweep's instruction MIX can issue at: the kernel's own hot block replayed as a micro-benchmark (scripts/ubench/gen_block_bench.py,
 # profiles/r03_block_replay.txt) issues at 2.66 cycles per wave-instruction and SIMD with every CU busy at 4 waves per SIMD (2.27 with one
 # CU busy: the chip clocks down under load) -- clamp, compare and select forms run at half rate -- against the 2 cycles `peak` assumes.
@@ -167,6 +188,13 @@ def estimate_ms(rt, ctx, p, rows, cols, dev, n=20):
         ctx.estimate_depth(1000)
     ctx.synchronize()
     ms = (time.perf_counter() - t) / n * 1e3
+    # like for like with the reference's frame (src/main.cpp:239-259 rebuilds the annotation pyramid and re-injects the coarsest level
+    # EVERY frame): the same estimates with the annotation declared changed in front of each
+    t = time.perf_counter()
+    for _ in range(n):
+        ctx.pyramid_annotation_changed(); ctx.estimate_depth(1000)
+    ctx.synchronize()
+    ms_ann = (time.perf_counter() - t) / n * 1e3
     pxit = sum((rows >> l) * (cols >> l) * int(1000 / 2 ** (P - 1 - l)) for l in range(P))
     kernels = []
     for l in range(1):                          # what the finest level ran (rtdd_last_solve_info reports the last solve: level 0)
@@ -196,11 +224,65 @@ def estimate_ms(rt, ctx, p, rows, cols, dev, n=20):
     for h in [scr, ed] + outs:
         h.free()
     h2d, d2h = rows * cols * 4, rows * cols
-    return {"what": f"{cols}x{rows} {P}-level cascade, {pxit / 1e6:.1f} Mpixel-iterations, device-resident", "ms": ms,
+    return {"what": f"{cols}x{rows} {P}-level cascade, {pxit / 1e6:.1f} Mpixel-iterations, device-resident, annotation unchanged between estimates: the annotation pyramid is NOT rebuilt "
+                    "(ms_annotation_changed: rebuilt every estimate, as src/main.cpp:239-259 does)", "ms": ms, "ms_annotation_changed": ms_ann,
             "Mpixel_iterations_per_s": pxit / ms / 1e3, "finest_level": kernels[0],
             "ms_end_to_end": ms_e2e, "end_to_end_is": f"src/main.cpp:234-293 as the reference clocks it: H2D of scribble + edited ({h2d / 1e6:.1f} MB, page-locked), annotation pyramid, cascade, "
                                                       f"D2H of the u8 map ({d2h / 1e6:.1f} MB), host waits for every frame",
             "live_ms_per_frame": ms_live, "live_fps": 1e3 / ms_live, "live_is": "the same frames, two in flight: copies on a second stream overlap the other frame's arithmetic (rtdd_live_submit)"}
+
+
+def batch_estimates(rt, dev, rows=1080, cols=1920, images=64, reps=3):
+    """BASELINE configs[3] on ONE GPU as estimates: `images` independent images, every pyramid level of all of them in the same launches
+    (rtdd_estimate_depth_batch) against the same estimates one after the other (rtdd_pyramid_select + rtdd_estimate_depth).  Images are
+    device-resident and warm-started (fixed sweep counts: the work per estimate does not depend on the start)."""
+    import numpy as np
+    import torch
+    from realtimedepthdiffusion_amd.synth import make_problem
+    ctx = rt.Context(int(dev.split(":")[1])); ctx.set_stream(torch.cuda.current_stream().cuda_stream); ctx.GPULoadWeights(0.4)
+    P = ctx.pyramid_create_batch(rows, cols, images)
+    for b in range(images):
+        p = make_problem(rows, cols, seed=1234 + b)
+        ctx.pyramid_select(b)
+        ctx.pyramid_set_image(rt.device_image(np.repeat(p["gray"][..., None], 3, 2), dev))
+        ctx.pyramid_set_annotation(rt.device_image(np.where(p["mask"] == 255, p["edited"][..., 0], 32).astype(np.uint8), dev))
+    ctx.estimate_depth_batch(1000); ctx.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        ctx.estimate_depth_batch(1000)
+    ctx.synchronize()
+    ms_b = (time.perf_counter() - t) / reps * 1e3
+    t = time.perf_counter()
+    for _ in range(reps):
+        for b in range(images):
+            ctx.pyramid_select(b); ctx.estimate_depth(1000)
+    ctx.synchronize()
+    ms_s = (time.perf_counter() - t) / reps * 1e3
+    ctx.close()
+    pxit = sum((rows >> l) * (cols >> l) * int(1000 / 2 ** (P - 1 - l)) for l in range(P)) * images
+    return {"what": f"{images} independent {cols}x{rows} images, {P}-level cascades ({pxit / 1e6:.0f} Mpixel-iterations), device-resident, one GPU",
+            "batched_ms": ms_b, "batched_estimates_per_s": images / ms_b * 1e3, "batched_ms_per_estimate": ms_b / images,
+            "sequential_ms": ms_s, "sequential_estimates_per_s": images / ms_s * 1e3, "speedup": ms_s / ms_b,
+            "Mpixel_iterations_per_s": pxit / ms_b / 1e3}
+
+
+def sustained(step, sync, px_iter_per_step, seconds=3.0, window=0.5):
+    """>= `seconds` of back-to-back steps (the headline's solve), the rate per `window`: the clocks settle in the first windows, and a
+    sampler that looks every few seconds sees a busy GPU.  Reported, never `value`."""
+    rates, n_total = [], 0
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < window:
+            for _ in range(8):
+                step()
+            n += 8
+            sync()
+        rates.append(n * px_iter_per_step / (time.perf_counter() - t0) / 1e6)
+        n_total += n
+    return {"seconds": seconds, "window_s": window, "steps": n_total, "unit": "Mpixel-iterations/s", "mean": sum(rates) / len(rates), "min": min(rates), "max": max(rates),
+            "first_window": rates[0], "last_window": rates[-1], "windows": [round(r, 1) for r in rates],
+            "what": "the headline's solve back to back (each group of 8 solves synchronised), rate per window: DVFS settling is the drift from the first windows to the last"}
 
 
 def photo_problem(rows, cols):
@@ -246,9 +328,15 @@ def valu_roofline(px_sweeps_per_s, method):
     ops = VALU_OPS.get(method)
     if ops is None:
         return None
+    src = "recorded constant"
+    if method == "jacobi":
+        ops, src = jacobi_valu_ops()
     achieved = ops * px_sweeps_per_s / 1e12
-    return {"achieved": achieved, "peak": VALU_PEAK_TOPS, "frac": achieved / VALU_PEAK_TOPS, "ops_per_pixel_sweep": ops,
-            "mix_issue_cycles_measured": VALU_MIX_CYCLES, "frac_of_mix_issue_rate": achieved / VALU_PEAK_TOPS * VALU_MIX_CYCLES / 2.0}
+    r = {"achieved": achieved, "peak": VALU_PEAK_TOPS, "frac": achieved / VALU_PEAK_TOPS, "ops_per_pixel_sweep": ops, "ops_source": src,
+         "mix_issue_cycles_measured": VALU_MIX_CYCLES, "frac_of_mix_issue_rate": achieved / VALU_PEAK_TOPS * VALU_MIX_CYCLES / 2.0}
+    if method == "jacobi":
+        r["frac_at_round4_count"] = VALU_OPS_ROUND4 * px_sweeps_per_s / 1e12 / VALU_PEAK_TOPS      # the same throughput priced at rounds 3-4's 15.1 operations
+    return r
 
 
 def sweep_4k(rt, dev, steps=10, rows=2160, cols=3840, iters=1000, name="4k_jacobi1000"):
@@ -430,7 +518,8 @@ def main():
         problems = [make_problem(rows, cols, seed=1234 + i) for i in my_images]
         ctx = rt.Context(local)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        ctx.GPUAllocateDeviceMemory(rows, cols, 1)
+        if not w.get("estimate"):
+            ctx.GPUAllocateDeviceMemory(rows, cols, 1)
         ctx.GPULoadWeights(0.4)
         if args.sweep_kernel: ctx.set_option(rt.OPT_SWEEP_KERNEL, args.sweep_kernel)
         if args.temporal_depth: ctx.set_option(rt.OPT_TEMPORAL_DEPTH, args.temporal_depth)
@@ -438,11 +527,24 @@ def main():
         if args.tile: ctx.set_option(rt.OPT_TILE, args.tile)
         if args.persistent >= 0: ctx.set_option(rt.OPT_PERSISTENT, args.persistent)
         elif share_gpu and world > 1: ctx.set_option(rt.OPT_PERSISTENT, 0)      # ranks sharing one GPU are not co-resident: no persistent launches
-        masks = [rt.device_image(p["mask"], dev) for p in problems]; grays = [rt.device_image(p["gray"], dev) for p in problems]
-        # one pristine initial-depth image per image and step, uploaded before the clock starts
-        depths = [[rt.device_image(p["depth"], dev) for p in problems] for _ in range(args.steps + args.warmup)]
+        if w.get("estimate"):
+            # this rank's images as ONE batched pyramid; a step = the whole estimate of every one of them (warm-started: the sweep counts are fixed)
+            levels_ = ctx.pyramid_create_batch(rows, cols, len(problems))
+            for b, p in enumerate(problems):
+                ctx.pyramid_select(b)
+                ctx.pyramid_set_image(rt.device_image(np.repeat(p["gray"][..., None], 3, 2), dev))
+                ctx.pyramid_set_annotation(rt.device_image(np.where(p["mask"] == 255, p["edited"][..., 0], 32).astype(np.uint8), dev))
+            masks = grays = []; depths = [[] for _ in range(args.steps + args.warmup)]
+            est_px_iter = sum((rows >> l) * (cols >> l) * int(iters / 2 ** (levels_ - 1 - l)) for l in range(levels_))
+        else:
+            masks = [rt.device_image(p["mask"], dev) for p in problems]; grays = [rt.device_image(p["gray"], dev) for p in problems]
+            # one pristine initial-depth image per image and step, uploaded before the clock starts
+            depths = [[rt.device_image(p["depth"], dev) for p in problems] for _ in range(args.steps + args.warmup)]
 
         def step(i):
+            if w.get("estimate"):
+                ctx.estimate_depth_batch(iters)
+                return
             for k in range(len(problems)):
                 d, m, g = depths[i][k], masks[k], grays[k]
                 if method == "rbgs":
@@ -463,7 +565,7 @@ def main():
     # Untimed, before the W warm-up steps: ~0.15 s of the same solve on a scratch image, so that a GPU that has been idle (a fresh box) has
     # ramped its clocks before anything is measured -- 8 ms of warm-up steps alone leave the first timed steps up to 8 % slow.
     if ctx and not args.no_clock_ramp:
-        scratch = [rt.device_image(p["depth"], dev) for p in problems]
+        scratch = [] if w.get("estimate") else [rt.device_image(p["depth"], dev) for p in problems]
         depths.append(scratch)
         t_ramp = time.perf_counter()
         while time.perf_counter() - t_ramp < 0.15:
@@ -491,6 +593,8 @@ def main():
         px_iter_per_image = rows * cols * per * sum(e[0] for e in executed) / len(executed)
     else:
         px_iter_per_image = rows * cols * iters
+    if w.get("estimate"):
+        px_iter_per_image = 0 if dry else est_px_iter
     algo_bytes = ALGO_BYTES[method]
     agg_dev = dev if tbackend == "nccl" else "cpu"
     units, elapsed, thr = shard.aggregate(args.steps * len(my_images) * px_iter_per_image, elapsed, dist, agg_dev, tgroup)   # SUM of units, MAX of time
@@ -507,6 +611,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not dry else "none (--dry-run: no GPU work)",
         "config": {"workload": (f"{args.workload}: one {cols}x{rows} image per GPU, 1 level, {iters} Chebyshev-Jacobi sweeps (BASELINE configs[1])" if default_line else
+                                f"{args.workload}: {batch} independent {cols}x{rows} images, whole coarse-to-fine estimates ({iters} sweeps at the coarsest level, halving per level), a rank's images in the same launches, image i on rank i % {world} (BASELINE configs[3] as estimates)" if w.get("estimate") else
                                 f"{args.workload}: {batch} independent {cols}x{rows} images x {iters} Chebyshev-Jacobi sweeps, image i on rank i % {world}, one stream per GPU" + (" (BASELINE configs[3])" if args.workload == "batch64_1080p" else "") if batch else
                                 f"{args.workload} ({method})"),
                    "images_per_step": n_images, "images_this_rank": len(my_images), "sweeps_per_launch": sweeps_per_launch,
@@ -554,7 +659,12 @@ def main():
                 out["roofline"]["counters_source"] = k.get("source")
         except (OSError, ValueError, KeyError):
             pass
-    if args.verify and not dry:
+    if w.get("estimate") and not dry:
+        out["estimates_per_s"] = batch * args.steps / elapsed if batch else None
+        out.pop("roofline", None)              # (a chain of five levels' kernels: the per-kernel roofline is the single-level workloads')
+    if args.verify and not dry and w.get("estimate"):
+        out["verified"] = {"against": "not available for estimate workloads here: tests/test_gpu_batch.py compares every level of every image with the single-image path and the oracle"}
+    elif args.verify and not dry:
         # the checker (outside the timed region): each rank's results of the LAST step against the oracle on the host cores
         import hashlib
         import oracle
@@ -577,6 +687,15 @@ def main():
     if executed:
         out["config"]["converged"] = {"tolerance": tolerance, "iterations": [e[0] for e in executed], "unit": "cycles" if method == "multigrid" else "sweeps",
                                       "residual": max(e[1] for e in executed), "start": "cold (depth 255 + labels)"}
+    if ctx and rank == 0 and world == 1 and default_line and not args.no_estimate:          # outside the timed region: the same solve for >= 3 s
+        scratch_i = len(depths); depths.append([rt.device_image(p["depth"], dev) for p in problems])
+        out["sustained"] = sustained(lambda: step(scratch_i), ctx.synchronize, len(my_images) * px_iter_per_image)
+        depths.pop()
+    # which numbers of this line were measured by THIS run and which are recordings read from committed files
+    out["measured_live"] = ["value", "ms_per_step", "roofline.launch_us (HIP events on the launch stream)", "roofline.achieved / frac (launch_us x the VALU count of the built object)",
+                            "sustained", "estimate*", "batch64_1080p_estimate", "sweep_4k / sweep_8k value and launch_us", "effects", "cpu_baseline"]
+    out["recorded"] = ["roofline.traffic", "roofline.hbm_counter_frac", "roofline.valu_issue_frac_counted", "sweep_4k.traffic", "sweep_8k.traffic (rocprofv3 --pmc passes of the same command: counters_source)",
+                       "roofline.mix_issue_cycles_measured (profiles/r03_block_replay.txt)"]
     if ctx: ctx.close()
     if not dry and rank == 0 and world == 1 and default_line and not args.no_estimate:      # outside the timed region
         c2 = rt.Context(local); c2.set_stream(torch.cuda.current_stream().cuda_stream); c2.GPULoadWeights(0.4)
@@ -586,6 +705,7 @@ def main():
         out["sweep_4k"] = sweep_4k(rt, dev)                                      # the north star's 4K stencil sweep
         out["sweep_8k"] = sweep_4k(rt, dev, steps=5, rows=4320, cols=7680, iters=200, name="8k_jacobi200")   # HBM-resident (564 MB working set)
         out["effects"] = effects(rt, dev)
+        out["batch64_1080p_estimate"] = batch_estimates(rt, dev)                 # BASELINE configs[3] at N = 1, as whole estimates
     if not dry and rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(rows, cols, method)
     if dist is not None:

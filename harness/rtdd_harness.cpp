@@ -161,6 +161,7 @@ struct Job {
     int iters = 1000;
     std::string refine;           // "" | "sor" | "mg": rtdd_refine_depth after every estimate
     float tolerance = 1e-4f;
+    bool sequential = false;      // --sequential: a --batch as one estimate after the other (default: rtdd_estimate_depth_batch, all images in the same launches)
 };
 
 // One GPU: context + stream + device staging, runs `count` estimates; keeps the last result on the host.
@@ -183,6 +184,45 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
     rtdd_ctx_set_stream(ctx, own.stream);
     const int rows = job.bgr.h, cols = job.bgr.w;
     CK(rtdd_load_weights(ctx, 0.4f));                                   // main.cpp:152-155
+    // --batch B without an effect or a refinement: this device's images as ONE batched pyramid -- every level of all of them in the same
+    // launches (rtdd_estimate_depth_batch: the coarse levels of one 1080p image use a quarter of the chip)
+    const bool batched = !live && count > 1 && !job.sequential && job.effect.empty() && job.refine.empty();
+    if (batched) {
+        CK(rtdd_pyramid_create_batch(ctx, rows, cols, count));
+        if (hipMalloc((void **)&own.d_bgr, (size_t)rows * cols * 3) != hipSuccess || hipMalloc((void **)&own.d_ann, (size_t)rows * cols) != hipSuccess) { std::printf("device %d: out of memory\n", device); return RTDD_ERR_NOMEM; }
+        auto t0 = std::chrono::steady_clock::now();
+        for (int n = 0; n < count; n++) {                               // every image is independent: its own upload, annotation and strokes
+            void *ps, *pe; size_t pis, pie;
+            CK(rtdd_pyramid_select(ctx, n));
+            CK(rtdd_upload(ctx, own.d_bgr, (size_t)cols * 3, job.bgr.px.data(), (size_t)cols * 3, (size_t)cols * 3, rows));
+            CK(rtdd_pyramid_set_image(ctx, own.d_bgr, (size_t)cols * 3));
+            if (job.has_ann) {
+                CK(rtdd_upload(ctx, own.d_ann, cols, job.ann.px.data(), cols, cols, rows));
+                CK(rtdd_pyramid_set_annotation(ctx, own.d_ann, cols));
+            }
+            CK(rtdd_pyramid_image(ctx, RTDD_IMG_SCRIBBLE, 0, &ps, &pis, nullptr, nullptr));
+            CK(rtdd_pyramid_image(ctx, RTDD_IMG_EDITED, 0, &pe, &pie, nullptr, nullptr));
+            for (const Paint &p : job.paints) CK(rtdd_paint_image(ctx, p.x, p.y, p.label, p.radius, (uint8_t *)pe, pie, (uint8_t *)ps, pis, rows, cols));
+        }
+        CK(rtdd_estimate_depth_batch(ctx, job.iters));                  // main.cpp:239-291, for every image
+        depth_u8->resize((size_t)rows * cols);
+        for (int n = 0; n < count; n++) {
+            void *pu; size_t piu;
+            CK(rtdd_pyramid_select(ctx, n));
+            CK(rtdd_pyramid_image(ctx, RTDD_IMG_DEPTH_U8, 0, &pu, &piu, nullptr, nullptr));
+            CK(rtdd_download(ctx, depth_u8->data(), cols, pu, piu, cols, rows));      // main.cpp:291 (synchronises)
+            if (every_map) every_map->push_back(*depth_u8);
+        }
+        *ms_per_estimate = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / count;
+        if (annotated) {
+            void *pe; size_t pie;
+            CK(rtdd_pyramid_select(ctx, 0));
+            CK(rtdd_pyramid_image(ctx, RTDD_IMG_EDITED, 0, &pe, &pie, nullptr, nullptr));
+            annotated->resize((size_t)rows * cols * 3); CK(rtdd_download(ctx, annotated->data(), (size_t)cols * 3, pe, pie, (size_t)cols * 3, rows));
+        }
+        CK(rtdd_ctx_synchronize(ctx));
+        return RTDD_OK;
+    }
     CK(rtdd_pyramid_create(ctx, rows, cols));                           // main.cpp:92-149
     if (hipMalloc((void **)&own.d_bgr, (size_t)rows * cols * 3) != hipSuccess || hipMalloc((void **)&own.d_ann, (size_t)rows * cols) != hipSuccess) { std::printf("device %d: out of memory\n", device); return RTDD_ERR_NOMEM; }
     unsigned char *d_bgr = own.d_bgr, *d_ann = own.d_ann;
@@ -279,7 +319,7 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
 
 int main(int argc, const char *argv[]) {
     if (argc == 1) { std::printf("Usage: rtdd_harness -i image.ppm [-a annotation.pgm] [-o prefix] [--effect defocus|desaturation|haze] [--iters N] [--refine sor|mg|auto [--tolerance T]]\n"
-                                 "                    [--paint x,y,label,radius]... [--live N [--paint-at frame:x,y,label,radius]...] [--devices D --batch B [--write-all]] [--png]\n"
+                                 "                    [--paint x,y,label,radius]... [--live N [--paint-at frame:x,y,label,radius]...] [--devices D --batch B [--sequential] [--write-all]] [--png]\n"
                                  "       rtdd_harness --convert in.(png|ppm|pgm) out.(png|ppm|pgm)       (8-bit PNG <-> PNM, no GPU)\n"); return 0; }
     if (argc == 4 && !std::strcmp(argv[1], "--convert")) {               // file format conversion only (no GPU): PNG <-> PNM
         Pnm im;
@@ -302,6 +342,7 @@ int main(int argc, const char *argv[]) {
         else if (!std::strcmp(argv[i], "--devices")) devices = std::atoi(next());
         else if (!std::strcmp(argv[i], "--batch")) batch = std::atoi(next());
         else if (!std::strcmp(argv[i], "--live")) live = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--sequential")) job.sequential = true;      // a --batch one estimate after the other (the round-4 behaviour)
         else if (!std::strcmp(argv[i], "--write-all")) write_all = true;           // every estimate of a --batch: <out>DepthMap_<b>.pgm|png
         else if (!std::strcmp(argv[i], "--png")) png = true;                       // DepthMap.png / ArtisticEffect.png like the reference
         else if (!std::strcmp(argv[i], "--paint")) { Paint p{0, 0, 0, 0, -1}; if (std::sscanf(next(), "%d,%d,%d,%d", &p.x, &p.y, &p.label, &p.radius) == 4) job.paints.push_back(p); }

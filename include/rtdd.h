@@ -270,6 +270,16 @@ enum rtdd_pyramid_image_kind {
 int rtdd_pyramid_levels(int rows, int cols);             /* src/main.cpp:95 */
 int rtdd_pyramid_create(rtdd_ctx *ctx, int rows, int cols);   /* main.cpp:92-155 minus I/O: images, depth := 255, rtdd_allocate */
 int rtdd_pyramid_destroy(rtdd_ctx *ctx);
+/* Batched estimates (BASELINE configs[3]: independent images, several per GPU).  The coarse levels of one image occupy a fraction of the
+ * chip -- 120 x 67 and 240 x 135 are 0.7 of a 1080p estimate's time on ~135 of 512 workgroup slots -- so `images` pyramids of ONE size on one
+ * context run every level of all images in the same launches (blockIdx.z = image): rtdd_estimate_depth_batch.  rtdd_pyramid_select
+ * says which image rtdd_pyramid_set_image / _set_annotation / _image (and rtdd_download of what it returns), rtdd_estimate_depth and
+ * rtdd_refine_depth address (0 after creation).  Every image's maps are bit for bit those of a single-image pyramid.  Live frames
+ * (rtdd_live_submit) need a single-image pyramid. */
+int rtdd_pyramid_create_batch(rtdd_ctx *ctx, int rows, int cols, int images);
+int rtdd_pyramid_select(rtdd_ctx *ctx, int index);
+int rtdd_pyramid_batch(rtdd_ctx *ctx);                   /* the number of images of the context's pyramid (0: none) */
+int rtdd_estimate_depth_batch(rtdd_ctx *ctx, int maxIterations);   /* rtdd_estimate_depth for every image of the batch; asynchronous */
 /* image: DEVICE pointer to an interleaved BGR u8 image; builds the gray pyramid, edited[0] := image, scribble[0] := 0 */
 int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch);
 /* annotation: DEVICE pointer to a 1-channel u8 map; decode rule of src/main.cpp:160-168 (value != 32 -> label, mask 255) */

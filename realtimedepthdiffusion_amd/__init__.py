@@ -45,6 +45,7 @@ C_ABI_SYMBOLS = [
     "rtdd_pyramid_set_annotation", "rtdd_pyramid_image", "rtdd_pyramid_annotation_changed", "rtdd_estimate_depth", "rtdd_refine_depth", "rtdd_bgr2gray", "rtdd_pyrdown_gray",
     "rtdd_pyrup_depth", "rtdd_depth_to_u8", "rtdd_upload", "rtdd_download",
     "rtdd_live_submit", "rtdd_live_wait", "rtdd_live_pending", "rtdd_host_alloc", "rtdd_host_free",
+    "rtdd_pyramid_create_batch", "rtdd_pyramid_select", "rtdd_pyramid_batch", "rtdd_estimate_depth_batch",
 ]
 IMG_ORIGINAL, IMG_GRAY, IMG_SCRIBBLE, IMG_EDITED, IMG_DEPTH, IMG_DEPTH_U8, IMG_ARTISTIC = range(7)
 # Itanium-mangled names of the reference's ten free functions
@@ -272,6 +273,17 @@ class Context:
     def pyramid_create(self, rows, cols):
         self._check(lib().rtdd_pyramid_create(self._h, C.c_int(rows), C.c_int(cols)))
         return int(lib().rtdd_pyramid_levels(C.c_int(rows), C.c_int(cols)))
+
+    def pyramid_create_batch(self, rows, cols, images):
+        """`images` pyramids of one size on this context (rtdd_estimate_depth_batch runs them in the same launches)."""
+        self._check(lib().rtdd_pyramid_create_batch(self._h, C.c_int(rows), C.c_int(cols), C.c_int(images)))
+        return int(lib().rtdd_pyramid_levels(C.c_int(rows), C.c_int(cols)))
+
+    def pyramid_select(self, index):
+        self._check(lib().rtdd_pyramid_select(self._h, C.c_int(index)))
+
+    def estimate_depth_batch(self, maxIterations=1000):
+        self._check(lib().rtdd_estimate_depth_batch(self._h, C.c_int(maxIterations)))
 
     def pyramid_destroy(self):
         self._check(lib().rtdd_pyramid_destroy(self._h))

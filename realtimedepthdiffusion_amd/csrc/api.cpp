@@ -402,22 +402,26 @@ int rtdd_allocate(rtdd_ctx *ctx, int rows, int cols, int levels) {
     { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_levels(ctx);
+    const int images = ctx->alloc_images > 0 ? ctx->alloc_images : 1;
+    ctx->alloc_images = 1;                         // (one shot: rtdd_pyramid_create_batch sets it for the call it makes)
     ctx->levels.resize(levels);
     for (int l = 0; l < levels; l++) {
         Level &L = ctx->levels[l];
         L.rows = (int)(rows / powf(2, l));          // src/GPUSolver.cu:42-43 (float divide, truncation)
         L.cols = (int)(cols / powf(2, l));
         L.elems = plane_elems(L.rows > 0 ? L.rows : 1, L.cols > 0 ? L.cols : 1);
+        const size_t all = L.elems * (size_t)images;           // (a batched pyramid: every plane once per image, Level::view)
         for (auto &p : L.plane) {
-            hipError_t e = hipMalloc((void **)&p, L.elems * sizeof(float));
+            hipError_t e = hipMalloc((void **)&p, all * sizeof(float));
             if (e != hipSuccess) { free_levels(ctx); return fail(ctx, e == hipErrorOutOfMemory ? RTDD_ERR_NOMEM : RTDD_ERR_HIP, "hipMalloc(plane)", e); }
         }
-        hipError_t e = hipMalloc((void **)&L.meta, L.elems * sizeof(uint32_t));
+        hipError_t e = hipMalloc((void **)&L.meta, all * sizeof(uint32_t));
         if (e != hipSuccess) { free_levels(ctx); return fail(ctx, e == hipErrorOutOfMemory ? RTDD_ERR_NOMEM : RTDD_ERR_HIP, "hipMalloc(meta)", e); }
         // guard cells are read (never used); give them a defined value once
-        for (auto &p : L.plane) RTDD_HIP(ctx, hipMemsetAsync(p, 0, L.elems * sizeof(float), ctx->stream));
-        RTDD_HIP(ctx, hipMemsetAsync(L.meta, 0, L.elems * sizeof(uint32_t), ctx->stream));
+        for (auto &p : L.plane) RTDD_HIP(ctx, hipMemsetAsync(p, 0, all * sizeof(float), ctx->stream));
+        RTDD_HIP(ctx, hipMemsetAsync(L.meta, 0, all * sizeof(uint32_t), ctx->stream));
     }
+    ctx->levels_images = images;
     ctx->maxLevel = levels - 1;                    // :51
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the reference syncs here (:52)
     return RTDD_OK;
@@ -608,7 +612,7 @@ struct Solve {
 // one attempt: stage + edge weights, the sweeps, the (guarded) copy-back
 static int solve_once(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
                       const uint8_t *gray, size_t grayPitch, int rows, int cols, int level, const rtdd_solve_params *params, int seq) {
-    const Level &L = ctx->levels[level];
+    const Level L = ctx->levels[level].view(ctx->batch.first);      // (the first image of the batch in progress: image 0 of 1 unless cascade_api.cpp says otherwise)
     const size_t ip = plane_pitch(cols);
     const bool prof = ctx->profile_on;
     hipEvent_t *ev = ctx->ev + 4 * (ctx->prof_pending % rtdd_ctx::kProfSlots);
@@ -663,6 +667,9 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
             "relaxation must be in [0,2) or RTDD_RELAXATION_AUTO");
     int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
     if (rc != RTDD_OK) return rc;
+    REQUIRE(ctx, ctx->batch.first >= 0 && ctx->batch.n >= 1 && ctx->batch.first + ctx->batch.n <= ctx->levels_images, "the batch exceeds what the context's levels were allocated for");
+    REQUIRE(ctx, ctx->batch.n == 1 || (params->method == RTDD_METHOD_CHEBYSHEV_JACOBI && params->tolerance <= 0.0f && ctx->opt.sweep_kernel != 1),
+            "a batched solve runs the reference's scheme with the temporally blocked kernel only");
     DeviceGuard g(ctx->device);
     if (ctx->solve_seq >= (1 << 30)) {              // (once in 10^9 solves) the sequence numbers start over: nothing may be left that compares against them
         if (!ctx->healing) { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }

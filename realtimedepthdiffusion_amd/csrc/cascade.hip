@@ -90,10 +90,12 @@ __global__ __launch_bounds__(256) void k_pyrup_inject(const float *__restrict__ 
                                                       float *__restrict__ dst, size_t dp, int drows, int dcols,
                                                       const uint8_t *__restrict__ edited, size_t ep,
                                                       const uint8_t *__restrict__ mask, size_t mp,
-                                                      float *__restrict__ coarse_out, size_t cp, int *sync_words, int seq) {
+                                                      float *__restrict__ coarse_out, size_t cp, int *sync_words, int seq,
+                                                      size_t zSrc, size_t zDst, size_t zEdited, size_t zMask, size_t zCoarse) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + wave_id();
-    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;    // (persist_sync.hpp: the coarse solve gave up)
+    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0)) return;    // (persist_sync.hpp: the coarse solve gave up)
     if (x >= dcols || y >= drows) return;
+    RTDD_Z(src, zSrc); RTDD_Z(dst, zDst); if (mask) { RTDD_Z(edited, zEdited); RTDD_Z(mask, zMask); } if (coarse_out) RTDD_Z(coarse_out, zCoarse);
     // the estimate driver reads the coarse level straight from the solver's plane; the caller-visible coarse depth image (the
     // solver's copy-back, src/GPUSolver.cu:311-312) is written here on the side: fine pixel (2c, 2r) stores coarse pixel (c, r)
     // (the fine level is at least twice the coarse one in both directions, so every coarse pixel has one)
@@ -136,10 +138,12 @@ __global__ __launch_bounds__(256) void k_pyrup_inject4(const float *__restrict__
                                                        float *__restrict__ dst, size_t dp, int drows, int dcols,
                                                        const uint8_t *__restrict__ edited, size_t ep,
                                                        const uint8_t *__restrict__ mask, size_t mp,
-                                                       float *__restrict__ coarse_out, size_t cp, int *sync_words, int seq) {
+                                                       float *__restrict__ coarse_out, size_t cp, int *sync_words, int seq,
+                                                       size_t zSrc, size_t zDst, size_t zEdited, size_t zMask, size_t zCoarse) {
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + wave_id();
-    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;
+    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0)) return;
     if (x0 >= dcols || y >= drows) return;
+    RTDD_Z(src, zSrc); RTDD_Z(dst, zDst); if (mask) { RTDD_Z(edited, zEdited); RTDD_Z(mask, zMask); } if (coarse_out) RTDD_Z(coarse_out, zCoarse);
     const int c0 = x0 >> 1, cy = y >> 1;
     const int ci[4] = {clamp_abs(c0 - 1, cols), clamp_abs(c0, cols), clamp_abs(c0 + 1, cols), clamp_abs(c0 + 2, cols)};
     // horizontal pass of one source row for the four outputs (k = x0 .. x0 + 3: even, odd, even, odd)
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256) void k_fill_f32(float *__restrict__ dst, size_
     ((float *)((char *)dst + (size_t)y * dp))[x] = v;
 }
 
-static inline dim3 grid64x4(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
+static inline dim3 grid64x4(int rows, int cols, int images = 1) { return dim3((cols + 63) / 64, (rows + 3) / 4, images); }
 
 int launch_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, uint8_t *gray, size_t gp, int rows, int cols) {
     hipLaunchKernelGGL(k_bgr2gray, grid64x4(rows, cols), dim3(256), 0, ctx->stream, bgr, bp, gray, gp, rows, cols);
@@ -242,20 +246,22 @@ int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, in
     return RTDD_OK;
 }
 int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
-                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out, size_t cp, bool guarded) {
+                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out, size_t cp, bool guarded, const PyrupBatch *pb) {
+    static const PyrupBatch one;
+    const PyrupBatch &Z = pb ? *pb : one;
     int *sw = guarded ? ctx->sync_words : nullptr;
     const int seq = ctx->guard_seq;
     if (coarse_out && (drows < 2 * rows || dcols < 2 * cols)) return fail(ctx, RTDD_ERR_INVALID, "pyrUp: the fine level must be at least twice the coarse one");
     const bool doubling = drows == 2 * rows && dcols == 2 * cols && dcols % 4 == 0 && rows >= 2 && cols >= 2;
-    const bool aligned = (uintptr_t)dst % 16 == 0 && dp % 16 == 0 && (!mask || ((uintptr_t)mask % 4 == 0 && mp % 4 == 0 && (uintptr_t)edited % 4 == 0 && ep % 4 == 0));
+    const bool aligned = (uintptr_t)dst % 16 == 0 && dp % 16 == 0 && Z.dst % 16 == 0 && (!mask || ((uintptr_t)mask % 4 == 0 && mp % 4 == 0 && (uintptr_t)edited % 4 == 0 && ep % 4 == 0 && Z.mask % 4 == 0 && Z.edited % 4 == 0));
     if (doubling && aligned) {          // four pixels per thread
-        if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject4<true>, grid64x4(drows, dcols / 4), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
-        else hipLaunchKernelGGL(k_pyrup_inject4<false>, grid64x4(drows, dcols / 4), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
+        if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject4<true>, grid64x4(drows, dcols / 4, Z.n), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq, Z.src, Z.dst, Z.edited, Z.mask, Z.coarse);
+        else hipLaunchKernelGGL(k_pyrup_inject4<false>, grid64x4(drows, dcols / 4, Z.n), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq, Z.src, Z.dst, Z.edited, Z.mask, Z.coarse);
         RTDD_LAUNCH_CHECK(ctx, "k_pyrup_inject4");
         return RTDD_OK;
     }
-    if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject<true>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
-    else hipLaunchKernelGGL(k_pyrup_inject<false>, grid64x4(drows, dcols), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq);
+    if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_pyrup_inject<true>, grid64x4(drows, dcols, Z.n), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq, Z.src, Z.dst, Z.edited, Z.mask, Z.coarse);
+    else hipLaunchKernelGGL(k_pyrup_inject<false>, grid64x4(drows, dcols, Z.n), dim3(256), 0, ctx->stream, src, sp, rows, cols, dst, dp, drows, dcols, edited, ep, mask, mp, coarse_out, cp, sw, seq, Z.src, Z.dst, Z.edited, Z.mask, Z.coarse);
     RTDD_LAUNCH_CHECK(ctx, "k_pyrup_inject");
     return RTDD_OK;
 }

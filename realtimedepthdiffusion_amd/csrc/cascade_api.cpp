@@ -12,6 +12,10 @@ struct Image {
     void *ptr = nullptr;
     size_t pitch = 0;
     int rows = 0, cols = 0, elem = 1;
+    // a batched pyramid (rtdd_pyramid_create_batch) holds every image `images` times, copy b `stride` bytes behind copy b - 1
+    size_t stride = 0;
+    int images = 1;
+    void *at(int b) const { return ptr ? (char *)ptr + (size_t)b * stride : nullptr; }
 };
 
 struct Pyramid {
@@ -21,7 +25,8 @@ struct Pyramid {
     // The coarse annotation levels and the coarsest level's injection depend on the annotation only (src/main.cpp:249-259;
     // GPUPyrDownAnnotation only ever adds, SURVEY A.8, and the solver never moves a Dirichlet pixel): they are brought up to date
     // by the first estimate after the annotation changed, not by every estimate.
-    bool annotation_dirty = true;
+    bool annotation_dirty = true;         // (of ANY image of a batch: bringing an up-to-date image up to date again changes nothing)
+    int images = 1, sel = 0;              // batch size; the image the single-image entry points address (rtdd_pyramid_select)
     struct Live *live = nullptr;          // rtdd_live_submit's second stream, staging images and events (created on first use)
 };
 
@@ -38,7 +43,7 @@ struct Live {
 };
 
 static bool inside(const Image &im, const void *p) {
-    return im.ptr && (const char *)p >= (const char *)im.ptr && (const char *)p < (const char *)im.ptr + im.pitch * (size_t)(im.rows > 0 ? im.rows : 1);
+    return im.ptr && (const char *)p >= (const char *)im.ptr && (const char *)p < (const char *)im.ptr + im.stride * (size_t)im.images;
 }
 
 // called by the entry points that write an annotation image: is it one of this context's pyramid?
@@ -52,11 +57,12 @@ void pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited)
     if (p->levels > 0 && (inside(p->depth[p->levels - 1], scribble) || inside(p->depth[p->levels - 1], edited))) p->annotation_dirty = true;
 }
 
-static int alloc_image(rtdd_ctx *ctx, Image &im, int rows, int cols, int elem, int fill) {
-    im.rows = rows; im.cols = cols; im.elem = elem;
+static int alloc_image(rtdd_ctx *ctx, Image &im, int rows, int cols, int elem, int fill, int images = 1) {
+    im.rows = rows; im.cols = cols; im.elem = elem; im.images = images;
     im.pitch = ((size_t)cols * elem + 511) / 512 * 512;       // like cudaMallocPitch: rows padded to 512 B
-    RTDD_HIP(ctx, hipMalloc(&im.ptr, im.pitch * (size_t)(rows > 0 ? rows : 1)));
-    RTDD_HIP(ctx, hipMemsetAsync(im.ptr, fill, im.pitch * (size_t)(rows > 0 ? rows : 1), ctx->stream));
+    im.stride = im.pitch * (size_t)(rows > 0 ? rows : 1);
+    RTDD_HIP(ctx, hipMalloc(&im.ptr, im.stride * (size_t)images));
+    RTDD_HIP(ctx, hipMemsetAsync(im.ptr, fill, im.stride * (size_t)images, ctx->stream));
     return RTDD_OK;
 }
 
@@ -106,9 +112,23 @@ int rtdd_pyramid_levels(int rows, int cols) {
     return (int)(log2((double)((m / 45) > 1 ? (m / 45) : 1)) + 1);          // src/main.cpp:95 (integer /45)
 }
 
-int rtdd_pyramid_create(rtdd_ctx *ctx, int rows, int cols) {
+int rtdd_pyramid_create(rtdd_ctx *ctx, int rows, int cols) { return rtdd_pyramid_create_batch(ctx, rows, cols, 1); }
+
+int rtdd_pyramid_batch(rtdd_ctx *ctx) { return ctx && ctx->pyr ? ctx->pyr->images : 0; }
+
+int rtdd_pyramid_select(rtdd_ctx *ctx, int index) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
+    REQUIRE(ctx, index >= 0 && index < ctx->pyr->images, "image index outside the batch");
+    REQUIRE(ctx, !ctx->pyr->live || ctx->pyr->live->submitted == ctx->pyr->live->waited, "live frames are in flight");
+    ctx->pyr->sel = index;
+    return RTDD_OK;
+}
+
+int rtdd_pyramid_create_batch(rtdd_ctx *ctx, int rows, int cols, int images) {
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, rows > 0 && cols > 0, "rows and cols must be positive");
+    REQUIRE(ctx, images >= 1 && images <= 4096, "the batch must hold 1..4096 images");
     DeviceGuard g(ctx->device);
     { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -116,22 +136,24 @@ int rtdd_pyramid_create(rtdd_ctx *ctx, int rows, int cols) {
     Pyramid *p = new (std::nothrow) Pyramid();
     if (!p) return fail(ctx, RTDD_ERR_NOMEM, "pyramid");
     ctx->pyr = p;
-    p->rows = rows; p->cols = cols; p->levels = rtdd_pyramid_levels(rows, cols);
+    p->rows = rows; p->cols = cols; p->levels = rtdd_pyramid_levels(rows, cols); p->images = images;
     p->gray.resize(p->levels); p->scribble.resize(p->levels); p->edited.resize(p->levels); p->depth.resize(p->levels);
     int rc;
-    if ((rc = alloc_image(ctx, p->original, rows, cols, 3, 0)) != RTDD_OK) return rc;
-    if ((rc = alloc_image(ctx, p->artistic, rows, cols, 3, 0)) != RTDD_OK) return rc;
-    if ((rc = alloc_image(ctx, p->depth_u8, rows, cols, 1, 255)) != RTDD_OK) return rc;
+    if ((rc = alloc_image(ctx, p->original, rows, cols, 3, 0, images)) != RTDD_OK) return rc;
+    if ((rc = alloc_image(ctx, p->artistic, rows, cols, 3, 0, images)) != RTDD_OK) return rc;
+    if ((rc = alloc_image(ctx, p->depth_u8, rows, cols, 1, 255, images)) != RTDD_OK) return rc;
     int gr = rows, gc = cols;
     for (int l = 0; l < p->levels; l++) {
         const int lr = (int)(rows / powf(2, l)), lc = (int)(cols / powf(2, l));   // src/main.cpp:103,129
-        if ((rc = alloc_image(ctx, p->gray[l], gr, gc, 1, 0)) != RTDD_OK) return rc;          // ceil chain
-        if ((rc = alloc_image(ctx, p->scribble[l], lr, lc, 1, 0)) != RTDD_OK) return rc;      // :132-133
-        if ((rc = alloc_image(ctx, p->edited[l], lr, lc, 3, 0)) != RTDD_OK) return rc;        // :130-131
-        if ((rc = alloc_image(ctx, p->depth[l], lr, lc, 4, 0)) != RTDD_OK) return rc;
-        if (lr > 0 && lc > 0 && (rc = launch_fill_f32(ctx, (float *)p->depth[l].ptr, p->depth[l].pitch, lr, lc, 255.0f)) != RTDD_OK) return rc;   // :136
+        if ((rc = alloc_image(ctx, p->gray[l], gr, gc, 1, 0, images)) != RTDD_OK) return rc;          // ceil chain
+        if ((rc = alloc_image(ctx, p->scribble[l], lr, lc, 1, 0, images)) != RTDD_OK) return rc;      // :132-133
+        if ((rc = alloc_image(ctx, p->edited[l], lr, lc, 3, 0, images)) != RTDD_OK) return rc;        // :130-131
+        if ((rc = alloc_image(ctx, p->depth[l], lr, lc, 4, 0, images)) != RTDD_OK) return rc;
+        for (int b = 0; b < images; b++)
+            if (lr > 0 && lc > 0 && (rc = launch_fill_f32(ctx, (float *)p->depth[l].at(b), p->depth[l].pitch, lr, lc, 255.0f)) != RTDD_OK) return rc;   // :136
         gr = (gr + 1) / 2; gc = (gc + 1) / 2;
     }
+    ctx->alloc_images = images;
     rc = rtdd_allocate(ctx, rows, cols, p->levels);                          // :149 (syncs)
     return rc;
 }
@@ -152,25 +174,26 @@ int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch) {
     REQUIRE(ctx, bgr && pitch >= (size_t)p->cols * 3, "bad image");
     DeviceGuard g(ctx->device);
     { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }    // (a new image resets the warm-start state a logged estimate ran on)
-    RTDD_HIP(ctx, hipMemcpy2DAsync(p->original.ptr, p->original.pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
-    RTDD_HIP(ctx, hipMemcpy2DAsync(p->edited[0].ptr, p->edited[0].pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));   // :158
+    const int b = p->sel;                          // (a batched pyramid: the selected image)
+    RTDD_HIP(ctx, hipMemcpy2DAsync(p->original.at(b), p->original.pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+    RTDD_HIP(ctx, hipMemcpy2DAsync(p->edited[0].at(b), p->edited[0].pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));   // :158
     // A new image is a new problem (the reference loads one image per process, src/main.cpp:93): everything an estimate carries
     // over to the next one -- the depth pyramid it warm-starts from (:136) and the coarse annotation levels, which
     // GPUPyrDownAnnotation only ever adds to -- goes back to its initial state.
     p->annotation_dirty = true;
     for (int l = 0; l < p->levels; l++) {
-        if (p->scribble[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->scribble[l].ptr, 0, p->scribble[l].pitch * p->scribble[l].rows, ctx->stream));
-        if (l > 0 && p->edited[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->edited[l].ptr, 0, p->edited[l].pitch * p->edited[l].rows, ctx->stream));
+        if (p->scribble[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->scribble[l].at(b), 0, p->scribble[l].pitch * p->scribble[l].rows, ctx->stream));
+        if (l > 0 && p->edited[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->edited[l].at(b), 0, p->edited[l].pitch * p->edited[l].rows, ctx->stream));
         if (p->depth[l].rows > 0 && p->depth[l].cols > 0) {
-            const int rc_ = launch_fill_f32(ctx, (float *)p->depth[l].ptr, p->depth[l].pitch, p->depth[l].rows, p->depth[l].cols, 255.0f);
+            const int rc_ = launch_fill_f32(ctx, (float *)p->depth[l].at(b), p->depth[l].pitch, p->depth[l].rows, p->depth[l].cols, 255.0f);
             if (rc_ != RTDD_OK) return rc_;
         }
     }
-    int rc = launch_bgr2gray(ctx, (const uint8_t *)p->original.ptr, p->original.pitch, (uint8_t *)p->gray[0].ptr, p->gray[0].pitch, p->rows, p->cols);
+    int rc = launch_bgr2gray(ctx, (const uint8_t *)p->original.at(b), p->original.pitch, (uint8_t *)p->gray[0].at(b), p->gray[0].pitch, p->rows, p->cols);
     // the gray pyramid depends on the image only: built once here instead of once per estimate (:241-247)
     for (int l = 1; l < p->levels && rc == RTDD_OK; l++)
-        rc = launch_pyrdown_u8(ctx, (const uint8_t *)p->gray[l - 1].ptr, p->gray[l - 1].pitch, p->gray[l - 1].rows, p->gray[l - 1].cols,
-                               (uint8_t *)p->gray[l].ptr, p->gray[l].pitch);
+        rc = launch_pyrdown_u8(ctx, (const uint8_t *)p->gray[l - 1].at(b), p->gray[l - 1].pitch, p->gray[l - 1].rows, p->gray[l - 1].cols,
+                               (uint8_t *)p->gray[l].at(b), p->gray[l].pitch);
     return rc;
 }
 
@@ -181,8 +204,8 @@ int rtdd_pyramid_set_annotation(rtdd_ctx *ctx, const uint8_t *annotation, size_t
     REQUIRE(ctx, annotation && pitch >= (size_t)p->cols, "bad annotation");
     DeviceGuard g(ctx->device);
     p->annotation_dirty = true;
-    return launch_decode_annotation(ctx, (const uint8_t *)p->original.ptr, p->original.pitch, annotation, pitch,
-                                    (uint8_t *)p->edited[0].ptr, p->edited[0].pitch, (uint8_t *)p->scribble[0].ptr, p->scribble[0].pitch, p->rows, p->cols);
+    return launch_decode_annotation(ctx, (const uint8_t *)p->original.at(p->sel), p->original.pitch, annotation, pitch,
+                                    (uint8_t *)p->edited[0].at(p->sel), p->edited[0].pitch, (uint8_t *)p->scribble[0].at(p->sel), p->scribble[0].pitch, p->rows, p->cols);
 }
 
 int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *pitch, int *rows, int *cols) {
@@ -202,7 +225,7 @@ int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *p
         default: break;
     }
     REQUIRE(ctx, im != nullptr, "no such pyramid image");
-    if (ptr) *ptr = im->ptr;
+    if (ptr) *ptr = im->at(p->sel);
     if (pitch) *pitch = im->pitch;
     if (rows) *rows = im->rows;
     if (cols) *cols = im->cols;
@@ -216,31 +239,40 @@ int rtdd_pyramid_annotation_changed(rtdd_ctx *ctx) {
     return RTDD_OK;
 }
 
-static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, size_t u8_copy_pitch, unsigned long long *op_id) {
+// first, n: the images of the context's (batched) pyramid the estimate covers -- the selected one, or all of them in the same launches
+static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, size_t u8_copy_pitch, unsigned long long *op_id, bool whole_batch = false) {
     if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
     REQUIRE(ctx, maxIterations >= 0, "maxIterations must be >= 0");
     Pyramid *p = ctx->pyr;
     const int P = p->levels;
+    const int first = whole_batch ? 0 : p->sel, n = whole_batch ? p->images : 1;
     int rc = RTDD_OK;
     if (p->annotation_dirty) {
+        // every image of the batch in one launch per step, whatever the estimate covers: the flag is one for the whole batch, and the
+        // down-sampling only ever adds (an up-to-date image stays as it is)
+        DeviceGuard g(ctx->device);
+        const int all = p->images;
         for (int l = 1; l < P && rc == RTDD_OK; l++)                           // src/main.cpp:249-253
-            rc = rtdd_pyrdown_annotation(ctx, (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch,
-                                         (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch, p->edited[l - 1].rows, p->edited[l - 1].cols,
-                                         (uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch, (uint8_t *)p->edited[l].ptr, p->edited[l].pitch,
-                                         p->edited[l].rows, p->edited[l].cols);
+            if (p->edited[l].rows > 0 && p->edited[l].cols > 0)
+                rc = launch_pyrdown_annotation(ctx, (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch,
+                                               (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch, p->edited[l - 1].rows, p->edited[l - 1].cols,
+                                               (uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch, (uint8_t *)p->edited[l].ptr, p->edited[l].pitch,
+                                               p->edited[l].rows, p->edited[l].cols, all, p->scribble[l - 1].stride, p->edited[l - 1].stride, p->scribble[l].stride, p->edited[l].stride);
         if (rc != RTDD_OK) return rc;
-        rc = rtdd_convert_to_float(ctx, (const uint8_t *)p->edited[P - 1].ptr, p->edited[P - 1].pitch, (float *)p->depth[P - 1].ptr, p->depth[P - 1].pitch,
-                                   (const uint8_t *)p->scribble[P - 1].ptr, p->scribble[P - 1].pitch, p->edited[P - 1].rows, p->edited[P - 1].cols);   // :257-259
+        if (p->edited[P - 1].rows > 0 && p->edited[P - 1].cols > 0)
+            rc = launch_convert(ctx, (const uint8_t *)p->edited[P - 1].ptr, p->edited[P - 1].pitch, (float *)p->depth[P - 1].ptr, p->depth[P - 1].pitch,
+                                (const uint8_t *)p->scribble[P - 1].ptr, p->scribble[P - 1].pitch, p->edited[P - 1].rows, p->edited[P - 1].cols,
+                                all, p->edited[P - 1].stride, p->depth[P - 1].stride, p->scribble[P - 1].stride);   // :257-259
         if (rc != RTDD_OK) return rc;
-        p->annotation_dirty = false;                                           // (the two calls above marked it themselves: they write pyramid images)
+        p->annotation_dirty = false;
     }
     PendingOp op;
     op.kind = PendingOp::kEstimate; op.opt = ctx->opt; op.maxIterations = maxIterations;
-    op.u8_copy = u8_copy; op.u8_copy_pitch = u8_copy_pitch;
-    rc = estimate_levels(ctx, maxIterations, P - 1, op.level_seq);
+    op.u8_copy = u8_copy; op.u8_copy_pitch = u8_copy_pitch; op.batch_first = first; op.batch_n = n;
+    rc = estimate_levels(ctx, maxIterations, P - 1, op.level_seq, first, n);
     if (rc == RTDD_OK && u8_copy) {
         DeviceGuard g(ctx->device);
-        RTDD_HIP(ctx, hipMemcpy2DAsync(u8_copy, u8_copy_pitch, p->depth_u8.ptr, p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+        RTDD_HIP(ctx, hipMemcpy2DAsync(u8_copy, u8_copy_pitch, p->depth_u8.at(first), p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (rc == RTDD_OK && !ctx->healing && ctx->opt.timeout_heal) {
         prune_confirmed(ctx);
@@ -255,6 +287,11 @@ static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, s
 int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
     if (!ctx) return RTDD_ERR_INVALID;
     return estimate_submit(ctx, maxIterations, nullptr, 0, nullptr);
+}
+
+int rtdd_estimate_depth_batch(rtdd_ctx *ctx, int maxIterations) {
+    if (!ctx) return RTDD_ERR_INVALID;
+    return estimate_submit(ctx, maxIterations, nullptr, 0, nullptr, /*whole_batch=*/true);
 }
 
 // ---- live mode ---------------------------------------------------------------------------------------------------------------------
@@ -334,6 +371,7 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
     REQUIRE(ctx, (hostScribble == nullptr) == (hostEdited == nullptr), "scribble and edited images come together (or neither: the annotation is unchanged)");
     REQUIRE(ctx, !hostScribble || (scribblePitch >= (size_t)p->cols && editedPitch >= (size_t)p->cols * 3), "pitch smaller than a row");
     REQUIRE(ctx, hostDepthU8 && depthPitch >= (size_t)p->cols && maxIterations >= 0, "bad output buffer or iteration count");
+    REQUIRE(ctx, p->images == 1, "live frames run on a single-image pyramid (rtdd_pyramid_create)");
     DeviceGuard g(ctx->device);
     int rc = live_create(ctx);
     if (rc != RTDD_OK) return rc;
@@ -368,14 +406,16 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
 
 namespace rtdd {
 
-int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq) {
+int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq, int first, int n) {
     Pyramid *p = ctx->pyr;
     if (!p) return fail(ctx, RTDD_ERR_STATE, "the pyramid is gone");
+    if (first < 0 || n < 1 || first + n > p->images) return fail(ctx, RTDD_ERR_INVALID, "images outside the pyramid's batch");
     const int P = p->levels;
     if (from_level > P - 1) from_level = P - 1;
     int rc = RTDD_OK;
     const bool was_in = ctx->in_estimate;
     ctx->in_estimate = true;
+    const Batch no_batch;
     for (int l = from_level; l >= 0 && rc == RTDD_OK; l--) {                   // src/main.cpp:261-288
         const int iters = (int)(maxIterations / powf(2.0, (P - 1) - l));       // :263
         const bool solved = p->depth[l].rows > 0 && p->depth[l].cols > 0;
@@ -383,35 +423,44 @@ int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level
         // kernel (which reads the result plane directly and writes depth[l] on the side); at the finest level the copy-back also
         // writes the u8 map (:290).  Same values in the same buffers (tests/test_gpu_cascade.py compares every level's image).
         ctx->defer_finish = solved && l > 0;
-        ctx->finish_u8 = l == 0 ? (uint8_t *)p->depth_u8.ptr : nullptr; ctx->finish_u8_pitch = p->depth_u8.pitch;
+        ctx->finish_u8 = l == 0 ? (uint8_t *)p->depth_u8.at(first) : nullptr; ctx->finish_u8_pitch = p->depth_u8.pitch;
         if (solved) {
-            rc = rtdd_matrix_free_solver(ctx, (float *)p->depth[l].ptr, p->depth[l].pitch, (const uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch,
-                                         (const uint8_t *)p->gray[l].ptr, p->gray[l].pitch, p->depth[l].rows, p->depth[l].cols, 0.4f, iters, 1e-5f, l);
+            // the level of images first .. first + n - 1 in the same launches (blockIdx.z = image: Batch, rtdd_internal.hpp)
+            ctx->batch.n = n; ctx->batch.first = first;
+            ctx->batch.depth = p->depth[l].stride; ctx->batch.scribble = p->scribble[l].stride; ctx->batch.gray = p->gray[l].stride; ctx->batch.u8 = p->depth_u8.stride;
+            rc = rtdd_matrix_free_solver(ctx, (float *)p->depth[l].at(first), p->depth[l].pitch, (const uint8_t *)p->scribble[l].at(first), p->scribble[l].pitch,
+                                         (const uint8_t *)p->gray[l].at(first), p->gray[l].pitch, p->depth[l].rows, p->depth[l].cols, 0.4f, iters, 1e-5f, l);
+            ctx->batch = no_batch;
             if (level_seq && l < 32) level_seq[l] = ctx->solve_seq;
         }
         const bool deferred = ctx->defer_finish;
         ctx->defer_finish = false; ctx->finish_u8 = nullptr;
         if (rc == RTDD_OK && l > 0) {
             DeviceGuard g(ctx->device);
-            const float *src = (const float *)p->depth[l].ptr; size_t sp = p->depth[l].pitch;
+            const float *src = (const float *)p->depth[l].at(first); size_t sp = p->depth[l].pitch;
             float *coarse_out = nullptr;
+            PyrupBatch pb;
+            pb.n = n; pb.src = p->depth[l].stride; pb.dst = p->depth[l - 1].stride; pb.edited = p->edited[l - 1].stride; pb.mask = p->scribble[l - 1].stride; pb.coarse = p->depth[l].stride;
             if (deferred) {                                                     // the level's result is still in the solver's plane
                 const size_t ip = plane_pitch(p->depth[l].cols);
-                src = ctx->levels[l].P(ctx->deferred_plane, ip); sp = ip * sizeof(float);
-                coarse_out = (float *)p->depth[l].ptr;
+                const Level Lv = ctx->levels[l].view(first);
+                src = Lv.P(ctx->deferred_plane, ip); sp = ip * sizeof(float); pb.src = Lv.elems * sizeof(float);
+                coarse_out = (float *)p->depth[l].at(first);
             }
             // guarded like k_finish: when level l's sweeps gave up it stores nothing, depth[l] keeps level l's input and the level can be run again
             rc = launch_pyrup_inject(ctx, src, sp, p->depth[l].rows, p->depth[l].cols,
-                                     (float *)p->depth[l - 1].ptr, p->depth[l - 1].pitch, p->depth[l - 1].rows, p->depth[l - 1].cols,
-                                     (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch,
-                                     (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch, coarse_out, p->depth[l].pitch, /*guarded=*/solved);     // :272-283
+                                     (float *)p->depth[l - 1].at(first), p->depth[l - 1].pitch, p->depth[l - 1].rows, p->depth[l - 1].cols,
+                                     (const uint8_t *)p->edited[l - 1].at(first), p->edited[l - 1].pitch,
+                                     (const uint8_t *)p->scribble[l - 1].at(first), p->scribble[l - 1].pitch, coarse_out, p->depth[l].pitch, /*guarded=*/solved, &pb);     // :272-283
         }
     }
     ctx->in_estimate = was_in;
     if (rc != RTDD_OK) return rc;
     if (p->depth[0].rows > 0 && p->depth[0].cols > 0) return RTDD_OK;         // the u8 map left the solver's copy-back (above)
     DeviceGuard g(ctx->device);
-    return launch_depth_to_u8(ctx, (const float *)p->depth[0].ptr, p->depth[0].pitch, (uint8_t *)p->depth_u8.ptr, p->depth_u8.pitch, p->rows, p->cols);   // :290
+    for (int b = first; b < first + n && rc == RTDD_OK; b++)                    // (an image too small for a finest level: nothing above ran either)
+        rc = launch_depth_to_u8(ctx, (const float *)p->depth[0].at(b), p->depth[0].pitch, (uint8_t *)p->depth_u8.at(b), p->depth_u8.pitch, p->rows, p->cols);   // :290
+    return rc;
 }
 
 int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
@@ -420,9 +469,9 @@ int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
     int from = -1;                                  // the level whose solve gave up; an estimate queued behind the failed call: every level
     for (int l = 0; l < 32; l++) if (failed_seq != 0 && op.level_seq[l] == failed_seq) from = l;
     if (from < 0) for (int l = 31; l >= 0 && from < 0; l--) if (op.level_seq[l] != 0) from = l;
-    int rc = from >= 0 ? estimate_levels(ctx, op.maxIterations, from, nullptr) : RTDD_OK;
+    int rc = from >= 0 ? estimate_levels(ctx, op.maxIterations, from, nullptr, op.batch_first, op.batch_n) : RTDD_OK;
     if (rc == RTDD_OK && op.u8_copy)
-        RTDD_HIP(ctx, hipMemcpy2DAsync(op.u8_copy, op.u8_copy_pitch, p->depth_u8.ptr, p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+        RTDD_HIP(ctx, hipMemcpy2DAsync(op.u8_copy, op.u8_copy_pitch, p->depth_u8.at(op.batch_first), p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
     return rc;
 }
 
@@ -437,10 +486,12 @@ int rtdd_refine_depth(rtdd_ctx *ctx, const rtdd_solve_params *params, rtdd_solve
     Pyramid *p = ctx->pyr;
     // the u8 map is written by the solve's own copy-back (k_finish: the same rounding as k_depth_to_u8), so that a solve that has to be
     // run again after a timed-out persistent launch brings the map with it
-    ctx->finish_u8 = (uint8_t *)p->depth_u8.ptr; ctx->finish_u8_pitch = p->depth_u8.pitch;
-    const int rc = rtdd_solve_ex(ctx, (float *)p->depth[0].ptr, p->depth[0].pitch, (const uint8_t *)p->scribble[0].ptr, p->scribble[0].pitch,
-                                 (const uint8_t *)p->gray[0].ptr, p->gray[0].pitch, p->rows, p->cols, 0, params, info);
-    ctx->finish_u8 = nullptr;
+    const int b = p->sel;
+    ctx->finish_u8 = (uint8_t *)p->depth_u8.at(b); ctx->finish_u8_pitch = p->depth_u8.pitch;
+    ctx->batch = Batch(); ctx->batch.first = b;
+    const int rc = rtdd_solve_ex(ctx, (float *)p->depth[0].at(b), p->depth[0].pitch, (const uint8_t *)p->scribble[0].at(b), p->scribble[0].pitch,
+                                 (const uint8_t *)p->gray[0].at(b), p->gray[0].pitch, p->rows, p->cols, 0, params, info);
+    ctx->finish_u8 = nullptr; ctx->batch = Batch();
     return rc;
 }
 

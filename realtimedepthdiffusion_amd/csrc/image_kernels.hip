@@ -7,10 +7,11 @@ namespace rtdd {
 
 // convert (K5) -- /root/reference/src/GPUImageProcessing.cu:8-21
 __global__ __launch_bounds__(256) void k_convert(const uint8_t *__restrict__ src, size_t srcPitch, float *__restrict__ dst, size_t dstPitch,
-                                                 const uint8_t *__restrict__ mask, size_t maskPitch, int rows, int cols) {
+                                                 const uint8_t *__restrict__ mask, size_t maskPitch, int rows, int cols, size_t zSrc, size_t zDst, size_t zMask) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
+    RTDD_Z(src, zSrc); RTDD_Z(dst, zDst); RTDD_Z(mask, zMask);
     if (mask[(size_t)y * maskPitch + x] == 255)
         ((float *)((char *)dst + (size_t)y * dstPitch))[x] = (float)src[(size_t)y * srcPitch + 3 * x];
 }
@@ -19,10 +20,11 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *__restrict__ src
 // overwrite earlier ones; nothing is ever cleared; channels 1,2 of the coarse image untouched.
 __global__ __launch_bounds__(256) void k_pyrdown_annotation(const uint8_t *__restrict__ ps, size_t psp, const uint8_t *__restrict__ pe, size_t pep,
                                                             int prows, int pcols, uint8_t *__restrict__ cs, size_t csp,
-                                                            uint8_t *__restrict__ ce, size_t cep, int crows, int ccols) {
+                                                            uint8_t *__restrict__ ce, size_t cep, int crows, int ccols, size_t zPs, size_t zPe, size_t zCs, size_t zCe) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + wave_id();
     if (x >= ccols || y >= crows) return;
+    RTDD_Z(ps, zPs); RTDD_Z(pe, zPe); RTDD_Z(cs, zCs); RTDD_Z(ce, zCe);
     int hit = -1;
 #pragma unroll
     for (int j = -1; j <= 0; j++)
@@ -50,18 +52,18 @@ __global__ __launch_bounds__(256) void k_paint(int x0, int y0, int x1, int y1, i
     scribble[(size_t)y * scribblePitch + x] = 255;
 }
 
-static inline dim3 grid64x4(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
+static inline dim3 grid64x4(int rows, int cols, int images = 1) { return dim3((cols + 63) / 64, (rows + 3) / 4, images); }
 
 int launch_convert(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, float *dst, size_t dstPitch,
-                   const uint8_t *mask, size_t maskPitch, int rows, int cols) {
-    hipLaunchKernelGGL(k_convert, grid64x4(rows, cols), dim3(256), 0, ctx->stream, src, srcPitch, dst, dstPitch, mask, maskPitch, rows, cols);
+                   const uint8_t *mask, size_t maskPitch, int rows, int cols, int images, size_t zSrc, size_t zDst, size_t zMask) {
+    hipLaunchKernelGGL(k_convert, grid64x4(rows, cols, images), dim3(256), 0, ctx->stream, src, srcPitch, dst, dstPitch, mask, maskPitch, rows, cols, zSrc, zDst, zMask);
     RTDD_LAUNCH_CHECK(ctx, "k_convert");
     return RTDD_OK;
 }
 
 int launch_pyrdown_annotation(rtdd_ctx *ctx, const uint8_t *ps, size_t psp, const uint8_t *pe, size_t pep, int prows, int pcols,
-                              uint8_t *cs, size_t csp, uint8_t *ce, size_t cep, int crows, int ccols) {
-    hipLaunchKernelGGL(k_pyrdown_annotation, grid64x4(crows, ccols), dim3(256), 0, ctx->stream, ps, psp, pe, pep, prows, pcols, cs, csp, ce, cep, crows, ccols);
+                              uint8_t *cs, size_t csp, uint8_t *ce, size_t cep, int crows, int ccols, int images, size_t zPs, size_t zPe, size_t zCs, size_t zCe) {
+    hipLaunchKernelGGL(k_pyrdown_annotation, grid64x4(crows, ccols, images), dim3(256), 0, ctx->stream, ps, psp, pe, pep, prows, pcols, cs, csp, ce, cep, crows, ccols, zPs, zPe, zCs, zCe);
     RTDD_LAUNCH_CHECK(ctx, "k_pyrdown_annotation");
     return RTDD_OK;
 }

@@ -57,8 +57,8 @@ __device__ __forceinline__ bool solve_is_dead(int *sync_words, int seq, bool fir
 // workgroup barrier; ONE lane stores the flag (agent-scope atomic); 8 lanes poll the neighbours' flags relaxed with s_sleep;
 // ONE agent acquire; barrier; plain vector loads.
 template <bool ACQUIRE = true>
-__device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, int tid, int tile_id, int bx, int by, int gx, int gy, int value) {
-    int *flags = sync_words + kSyncFlags;
+__device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, int tid, int tile_id, int bx, int by, int gx, int gy, int value, int tile_base = 0) {
+    int *flags = sync_words + kSyncFlags + tile_base * kSyncFlagStride;      // (tile_base: a batched launch gives every image's tiles flags of their own)
     if (tid == 0 && __hip_atomic_load(&sync_words[kSyncWithhold], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tile_id + 1)
         __hip_atomic_store(&flags[tile_id * kSyncFlagStride], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // Lane i (of 9, i != 4) of wave 0 polls neighbour (i%3-1, i/3-1).  A poll is a round trip to memory (the flag was stored sc1: it is in

@@ -39,7 +39,25 @@ struct Level {
     // views at row 0 (after the guard rows)
     float *P(int i, size_t ip) const { return plane[i] + (size_t)kGuardRows * ip; }
     uint32_t *M(size_t ip) const { return meta + (size_t)kGuardRows * ip; }
+    // A context created for a batch of images (rtdd_pyramid_create_batch) allocates every plane `images` times over, image b's copy
+    // `elems` elements behind image b - 1's: view(b) is the level as image b sees it.
+    Level view(int b) const {
+        Level v = *this;
+        for (auto &q : v.plane) if (q) q += (size_t)b * elems;
+        if (v.meta) v.meta += (size_t)b * elems;
+        return v;
+    }
 };
+
+// The images a batched launch covers (rtdd_estimate_depth_batch; BASELINE configs[3]: independent images on one GPU): blockIdx.z = image
+// index - first.  Every kernel on the estimate's path takes, next to each image pointer, the BYTE stride between consecutive images of
+// that argument (0 and gridDim.z = 1 for everything else).  Planes of the solver: Level::elems * 4.
+struct Batch {
+    int n = 1;                            // images per launch
+    int first = 0;                        // the first one's index in the context's batched allocations
+    size_t depth = 0, scribble = 0, gray = 0, u8 = 0;     // byte strides of the caller-side arguments of the solve in progress
+};
+#define RTDD_Z(ptr, stride) ptr = (decltype(ptr))((const char *)(ptr) + (size_t)blockIdx.z * (size_t)(stride))
 
 struct Options {
     int fp_contract = 1;
@@ -78,6 +96,7 @@ struct PendingOp {
     // kEstimate
     int maxIterations = 0;
     int level_seq[32] = {};               // sequence number of level l's solve (0: the level is empty)
+    int batch_first = 0, batch_n = 1;     // the images of the context's batched pyramid the estimate covers
     uint8_t *u8_copy = nullptr; size_t u8_copy_pitch = 0;   // live mode: the u8 map is copied here (device) behind the estimate
     unsigned long long id = 0;            // position in the context's call order (live mode drops the confirmed prefix of the log)
     // kDefocus / kDesaturate / kHaze: a depth effect queued BEHIND an unconfirmed solve (it may have read that solve's input instead of
@@ -99,6 +118,9 @@ struct rtdd_ctx {
     rtdd::MgState *mg = nullptr;        // multigrid hierarchy buffers (multigrid.hip), kept between solves of one size
     hipStream_t stream = nullptr;
     std::vector<rtdd::Level> levels;
+    int alloc_images = 1;               // how many images' planes the NEXT rtdd_allocate makes every level hold (rtdd_pyramid_create_batch; one shot)
+    int levels_images = 1;              // ... and how many the levels hold now
+    rtdd::Batch batch;                  // the images the launches of the call in progress cover (cascade_api.cpp); n = 1, first = 0 otherwise
     int maxLevel = -1;
     bool weights_loaded = false;
     float lut_host[257];
@@ -214,10 +236,12 @@ int mg_download(rtdd_ctx *ctx, int level, int which, float *host, int *rows, int
 int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, int n, float omega, int *plane, int *launches, int keep = -1);
 
 // ---- image_kernels.hip --------------------------------------------------------------------------
+// (images, z*: a batched launch over `images` images whose arguments lie z* bytes apart)
 int launch_convert(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, float *dst, size_t dstPitch,
-                   const uint8_t *mask, size_t maskPitch, int rows, int cols);
+                   const uint8_t *mask, size_t maskPitch, int rows, int cols, int images = 1, size_t zSrc = 0, size_t zDst = 0, size_t zMask = 0);
 int launch_pyrdown_annotation(rtdd_ctx *ctx, const uint8_t *ps, size_t psp, const uint8_t *pe, size_t pep, int prows, int pcols,
-                              uint8_t *cs, size_t csp, uint8_t *ce, size_t cep, int crows, int ccols);
+                              uint8_t *cs, size_t csp, uint8_t *ce, size_t cep, int crows, int ccols,
+                              int images = 1, size_t zPs = 0, size_t zPe = 0, size_t zCs = 0, size_t zCe = 0);
 int launch_paint(rtdd_ctx *ctx, int x, int y, int color, int radius, uint8_t *edited, size_t editedPitch,
                  uint8_t *scribble, size_t scribblePitch, int rows, int cols);
 
@@ -230,8 +254,10 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
 // ---- cascade.hip -------------------------------------------------------------------------------
 int launch_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, uint8_t *gray, size_t gp, int rows, int cols);
 int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, int cols, uint8_t *dst, size_t dp);
+struct PyrupBatch { int n = 1; size_t src = 0, dst = 0, edited = 0, mask = 0, coarse = 0; };      // images and byte strides of a batched pyrUp
 int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
-                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out = nullptr, size_t cp = 0, bool guarded = false);
+                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out = nullptr, size_t cp = 0, bool guarded = false,
+                        const PyrupBatch *batch = nullptr);
 int launch_depth_to_u8(rtdd_ctx *ctx, const float *src, size_t sp, uint8_t *dst, size_t dp, int rows, int cols);
 int launch_decode_annotation(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, const uint8_t *ann, size_t ap, uint8_t *edited, size_t ep,
                              uint8_t *scribble, size_t sp, int rows, int cols);
@@ -247,7 +273,7 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve = false);
 void prune_confirmed(rtdd_ctx *ctx);    // drop the logged calls a copy-back kernel has confirmed (no synchronisation)
 int settle_pending(rtdd_ctx *ctx);      // before a call changes what the logged calls ran on: synchronise + check (+ heal) while that state still exists
 // cascade_api.cpp: levels from_level .. 0 of an estimate (src/main.cpp:261-291); level_seq (optional) receives each level's solve sequence number
-int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq);
+int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq, int first = 0, int n = 1);
 // an estimate of the pending log again, from the level whose solve has sequence number failed_seq (0: every level)
 int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq);
 

@@ -40,10 +40,12 @@ __global__ __launch_bounds__(256) void k_prepare(const float *__restrict__ depth
                                                  const uint8_t *__restrict__ scribble, size_t scribblePitch,
                                                  const uint8_t *__restrict__ gray, size_t grayPitch,
                                                  float *__restrict__ X0, float *__restrict__ X1,
-                                                 uint32_t *__restrict__ M, int ip, int rows, int cols, int gated, int thr) {
+                                                 uint32_t *__restrict__ M, int ip, int rows, int cols, int gated, int thr,
+                                                 size_t zDepth, size_t zScribble, size_t zGray, size_t zPlane) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + wave_id();
     if (x >= cols || y >= rows) return;
+    RTDD_Z(depth, zDepth); RTDD_Z(scribble, zScribble); RTDD_Z(gray, zGray); RTDD_Z(X0, zPlane); RTDD_Z(X1, zPlane); RTDD_Z(M, zPlane);
     const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
     const uint8_t *grow = gray + (size_t)y * grayPitch;
     const float d = drow[x];
@@ -74,10 +76,12 @@ __global__ __launch_bounds__(256) void k_prepare4(const float *__restrict__ dept
                                                   const uint8_t *__restrict__ scribble, size_t scribblePitch,
                                                   const uint8_t *__restrict__ gray, size_t grayPitch,
                                                   float *__restrict__ X0, float *__restrict__ X1,
-                                                  uint32_t *__restrict__ M, int ip, int rows, int cols, int gated, int thr) {
+                                                  uint32_t *__restrict__ M, int ip, int rows, int cols, int gated, int thr,
+                                                  size_t zDepth, size_t zScribble, size_t zGray, size_t zPlane) {
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
     const int y = blockIdx.y * 4 + wave_id();
     if (x0 >= cols || y >= rows) return;
+    RTDD_Z(depth, zDepth); RTDD_Z(scribble, zScribble); RTDD_Z(gray, zGray); RTDD_Z(X0, zPlane); RTDD_Z(X1, zPlane); RTDD_Z(M, zPlane);
     const float *drow = (const float *)((const char *)depth + (size_t)y * depthPitch);
     const uint8_t *grow = gray + (size_t)y * grayPitch, *srow = scribble + (size_t)y * scribblePitch;
     const bool down_ok = y + 1 < rows;
@@ -271,11 +275,13 @@ __device__ __forceinline__ uint8_t round_u8(float v) {
 }
 
 __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
-                                                int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq) {
+                                                int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq,
+                                                size_t zPlane, size_t zDepth, size_t zU8) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + wave_id();
-    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;
+    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0)) return;
     if (x >= cols || y >= rows) return;
+    RTDD_Z(X, zPlane); RTDD_Z(depth, zDepth); if (u8) RTDD_Z(u8, zU8);
     const float v = X[(size_t)y * ip + x];
     ((float *)((char *)depth + (size_t)y * depthPitch))[x] = v;
     if (u8) u8[(size_t)y * u8Pitch + x] = round_u8(v);
@@ -283,11 +289,13 @@ __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int
 
 // four pixels per thread when the caller's rows are 16-byte aligned (a group past the end of the row: pixel by pixel)
 __global__ __launch_bounds__(256) void k_finish4(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
-                                                 int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq) {
+                                                 int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq,
+                                                 size_t zPlane, size_t zDepth, size_t zU8) {
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
     const int y = blockIdx.y * 4 + wave_id();
-    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | threadIdx.x) == 0)) return;
+    if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0)) return;
     if (x0 >= cols || y >= rows) return;
+    RTDD_Z(X, zPlane); RTDD_Z(depth, zDepth); if (u8) RTDD_Z(u8, zU8);
     const float4 v = *(const float4 *)(X + (size_t)y * ip + x0);
     float *o = (float *)((char *)depth + (size_t)y * depthPitch) + x0;
     const float t[4] = {v.x, v.y, v.z, v.w};
@@ -384,21 +392,23 @@ __global__ __launch_bounds__(256) void k_rbgs_half(float *__restrict__ X, const 
 // ================================================================================================
 // host-side launchers
 // ================================================================================================
-static inline dim3 grid64x4(int rows, int cols) { return dim3((cols + 63) / 64, (rows + 3) / 4); }
+static inline dim3 grid64x4(int rows, int cols, int images = 1) { return dim3((cols + 63) / 64, (rows + 3) / 4, images); }
 
 int launch_prepare(rtdd_ctx *ctx, const Level &L, size_t ip, const float *depth, size_t depthPitch,
                    const uint8_t *scribble, size_t scribblePitch, const uint8_t *gray, size_t grayPitch,
                    int rows, int cols, int level) {
     const int gated = level != ctx->maxLevel;
     const int thr = level == 0 ? 0 : 4;
+    const Batch &B = ctx->batch;                // (n = 1: one image, strides unused; L is already image B.first's view)
+    const size_t zP = L.elems * sizeof(float);
     const bool aligned = ((uintptr_t)depth % 16 == 0) && depthPitch % 16 == 0 && ((uintptr_t)gray % 4 == 0) && grayPitch % 4 == 0 &&
-                         ((uintptr_t)scribble % 4 == 0) && scribblePitch % 4 == 0;
+                         ((uintptr_t)scribble % 4 == 0) && scribblePitch % 4 == 0 && B.depth % 16 == 0 && B.gray % 4 == 0 && B.scribble % 4 == 0;
     if (aligned)
-        hipLaunchKernelGGL(k_prepare4, grid64x4(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, depth, depthPitch, scribble, scribblePitch,
-                           gray, grayPitch, L.P(0, ip), L.P(1, ip), L.M(ip), (int)ip, rows, cols, gated, thr);
+        hipLaunchKernelGGL(k_prepare4, grid64x4(rows, (cols + 3) / 4, B.n), dim3(256), 0, ctx->stream, depth, depthPitch, scribble, scribblePitch,
+                           gray, grayPitch, L.P(0, ip), L.P(1, ip), L.M(ip), (int)ip, rows, cols, gated, thr, B.depth, B.scribble, B.gray, zP);
     else
-        hipLaunchKernelGGL(k_prepare, grid64x4(rows, cols), dim3(256), 0, ctx->stream, depth, depthPitch, scribble, scribblePitch,
-                           gray, grayPitch, L.P(0, ip), L.P(1, ip), L.M(ip), (int)ip, rows, cols, gated, thr);
+        hipLaunchKernelGGL(k_prepare, grid64x4(rows, cols, B.n), dim3(256), 0, ctx->stream, depth, depthPitch, scribble, scribblePitch,
+                           gray, grayPitch, L.P(0, ip), L.P(1, ip), L.M(ip), (int)ip, rows, cols, gated, thr, B.depth, B.scribble, B.gray, zP);
     RTDD_LAUNCH_CHECK(ctx, "k_prepare");
     return RTDD_OK;
 }
@@ -448,10 +458,12 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
 }
 
 int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols, uint8_t *u8, size_t u8Pitch) {
-    if ((uintptr_t)depth % 16 == 0 && depthPitch % 16 == 0)
-        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq);
+    const Batch &B = ctx->batch;
+    const size_t zP = L.elems * sizeof(float);
+    if ((uintptr_t)depth % 16 == 0 && depthPitch % 16 == 0 && B.depth % 16 == 0 && B.u8 % 4 == 0)
+        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq, zP, B.depth, B.u8);
     else
-        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq);
+        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq, zP, B.depth, B.u8);
     ctx->persistent_used = true;                  // (the guard may have recorded a failed solve: the next synchronising call looks)
     RTDD_LAUNCH_CHECK(ctx, "k_finish");
     return RTDD_OK;

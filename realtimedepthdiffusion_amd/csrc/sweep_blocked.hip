@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
                                                       const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
                                                       const float *__restrict__ omegas, int ip, int rows, int cols,
                                                       int hx, int hy, int nsweeps, float gamma,
-                                                      int block_sweeps, int *sync_words, int gx, int gy, int xcd_tiles, int flag_base) {
+                                                      int block_sweeps, int *sync_words, int gx, int gy, int xcd_tiles, int flag_base, size_t zPlane) {
     // block_sweeps == nsweeps: the plain time-blocked launch (results -> Yk/Ym).
     // block_sweeps <  nsweeps: PERSISTENT mode -- the workgroup keeps its tile in registers for the whole solve and,
     // every block_sweeps (= halo width, even) sweeps, trades halo strips with its 8 neighbours through memory instead
@@ -92,6 +92,9 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
         if (t >= gx * gy) return;
         bx = t % gx; by = t / gx;           // (numbering the tiles in compact 8x4 patches instead of row bands measured the same)
     }
+    // batched launch (rtdd_estimate_depth_batch): blockIdx.z = image, its planes zPlane bytes behind the previous image's, its tiles' flags
+    // behind the previous image's tiles'
+    RTDD_Z(Xk, zPlane); RTDD_Z(Xm, zPlane); RTDD_Z(Yk, zPlane); RTDD_Z(Ym, zPlane); RTDD_Z(M, zPlane);
     RTDD_STAMP(0);
     // Tile load and setup at a raised wave priority: where two workgroups share a CU (4K, 8K) the one that has just arrived gets through
     // its loads, table gathers and reciprocals ahead of the other one's sweeps and joins them sooner (4K +2.7 %, 8K +2.3 %; levels 1-3:
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     // waves top-down, odd waves bottom-up, every edge row published as soon as it is computed and fetched a step ahead).
 #include "sweep_tile_sweeps.inc"      // publish / await / sweep lambdas
     // (the divide variant is chosen per wave; the neighbour handshake above does not care which one a wave runs)
-    const int tile_id = by * gx + bx, ntiles = gx * gy;
+    const int ntiles = gx * gy, tile_base = (int)blockIdx.z * ntiles, tile_id = by * gx + bx;
     int s = 0, blk = 0;
     bool odd = false;
     RTDD_XT_BEGIN;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 #ifndef RTDD_EXCHANGE_ACQUIRE
 #define RTDD_EXCHANGE_ACQUIRE 0
 #endif
-            if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1)) return;      // flag, bounded poll, (acquire,) barrier
+            if (exchange_wait<RTDD_EXCHANGE_ACQUIRE != 0>(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, flag_base + blk + 1, tile_base)) return;      // flag, bounded poll, (acquire,) barrier
             RTDD_XT(2);
             RTDD_XT(3);
 #if RTDD_EXCHANGE_ACQUIRE
@@ -309,8 +312,9 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
 template <bool CONTRACT>
 __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk, const float *__restrict__ Xm, float *__restrict__ Yk, float *__restrict__ Ym,
                                                     const uint32_t *__restrict__ M, const float *__restrict__ lut_g, const float *__restrict__ omegas,
-                                                    int ip, int rows, int cols, int hx, int hy, int nsweeps, float gamma, int gx, int gy, int xcd_tiles, int *sync_words) {
+                                                    int ip, int rows, int cols, int hx, int hy, int nsweeps, float gamma, int gx, int gy, int xcd_tiles, int *sync_words, size_t zPlane) {
     constexpr int R = 4;
+    RTDD_Z(Xk, zPlane); RTDD_Z(Xm, zPlane); RTDD_Z(Yk, zPlane); RTDD_Z(Ym, zPlane); RTDD_Z(M, zPlane);
     __shared__ float lut[257];
     // [buffer][wave][lane] = (top row value, tag, bottom row value, tag): the tag is the number of the sweep the values are for, + 1,
     // written by a second instruction BEHIND the values (the LDS serves a wave's accesses in order), so a reader that finds the tag
@@ -548,10 +552,10 @@ static bool persistent_possible(rtdd_ctx *ctx, int tile, int nthreads) {
 
 template <int LX, int NT, int G>
 static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, float *Xk, float *Xm, float *Yk, float *Ym, const uint32_t *M,
-                       const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma, int block_sweeps, int flag_base) {
+                       const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma, int block_sweeps, int flag_base, size_t zPlane) {
     const bool persist = block_sweeps < n;
-    const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
-#define RTDD_LAUNCH(C, P) hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, C, P>), launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma, block_sweeps, ctx->sync_words, (int)grid.x, (int)grid.y, xcd_tiles, flag_base)
+    const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles, 1, ctx->batch.n) : dim3(grid.x, grid.y, ctx->batch.n);
+#define RTDD_LAUNCH(C, P) hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, C, P>), launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma, block_sweeps, ctx->sync_words, (int)grid.x, (int)grid.y, xcd_tiles, flag_base, zPlane)
     if (ctx->opt.fp_contract) { if (persist) RTDD_LAUNCH(true, true); else RTDD_LAUNCH(true, false); }
     else { if (persist) RTDD_LAUNCH(false, true); else RTDD_LAUNCH(false, false); }
 #undef RTDD_LAUNCH
@@ -572,16 +576,19 @@ static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, fl
 // It only has to rank candidates; it reproduces the measured launch times within ~15 %.
 static const int kWgPerCu[kNumTiles + 1] = {0, 3, 1, 1, 1, 2, 2, 4, 1, 2, 2, 2, 1, 1, 2, 4, 2};
 
-static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int tile, int T, bool persist) {
+// (images: a batched launch runs the level of that many independent images at once -- rtdd_estimate_depth_batch -- so the chip sees
+// images x tiles workgroups: small levels then want SHALLOW halos, few tiles per image and one round, where a single image wants deep
+// halos to save launches: 120 x 67 x 64 images: tile 9 at depth 8, 6 tiles per image, instead of the column tile at depth 28, 135 per image)
+static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int tile, int T, bool persist, int images = 1) {
     const int G = kTiles[tile].g;
     const int EW = 4 * kTiles[tile].lx, EH = tile_rows(tile, kTiles[tile].nt);
     const int hx = (T + 3) / 4 * 4, TW = EW - 2 * hx, TH = EH - 2 * T;
     if (TW < 8 || TH < 8) return 1e30;
-    const double nwg = (double)((cols + TW - 1) / TW) * ((rows + TH - 1) / TH);
+    const double nwg = (double)((cols + TW - 1) / TW) * ((rows + TH - 1) / TH) * images;
     const double cus = ctx->num_cus, ext = (double)EW * EH;
     const double lat = 0.25 + 0.28 * G;
     const double thr1 = 1.5 * ext / 12288.0;                    // one workgroup alone on a CU
-    const double img_bytes = (double)rows * cols * 20.0;
+    const double img_bytes = (double)rows * cols * 20.0 * images;
     const double small = img_bytes < 2e6 ? 0.5 : 1.0;           // tiny levels (< 100 Kpx) sit in L2: cheaper loads and boundaries
     const double bw = img_bytes > 2e8 ? 17600.0 : 22600.0;      // bytes/us per CU: 4.5 TB/s from HBM (8K), 5.8 TB/s from the Infinity Cache
     const double load1 = small * ext * 12.0 / bw, store1 = small * (double)TW * TH * 8.0 / bw;
@@ -612,7 +619,7 @@ static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int ti
     return t / T;
 }
 
-static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fixed_tile, int fixed_T, int *tile, int *T, bool *persist) {
+static double choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fixed_tile, int fixed_T, int *tile, int *T, bool *persist) {
     static const int tiles[] = {4, 8, 9, 14, 6, 5, 7, 12};
     static const int depths[] = {4, 8, 12, 16, 24, 28};
     double best = 1e30;
@@ -623,7 +630,7 @@ static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fi
             if (fixed_T && d != fixed_T) continue;
             for (int p = 0; p < 2; p++) {
                 if (p && !ctx->opt.persistent) continue;
-                const double c = config_cost(ctx, rows, cols, n, ti, d, p != 0);
+                const double c = config_cost(ctx, rows, cols, n, ti, d, p != 0, ctx->batch.n);
                 if (c < best) { best = c; *tile = ti; *T = d; *persist = p != 0; }
             }
         }
@@ -631,7 +638,8 @@ static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fi
     if (fixed_tile && best >= 1e30) *tile = fixed_tile;
     if (fixed_T && best >= 1e30) *T = fixed_T;
     if (getenv("RTDD_DEBUG_CONFIG"))
-        fprintf(stderr, "[rtdd] %dx%d n=%d -> tile %d depth %d persistent %d (model %.3f us/sweep)\n", cols, rows, n, *tile, *T, (int)*persist, best);
+        fprintf(stderr, "[rtdd] %dx%d x %d image(s) n=%d -> tile %d depth %d persistent %d (model %.3f us/sweep)\n", cols, rows, ctx->batch.n, n, *tile, *T, (int)*persist, best);
+    return best;
 }
 
 #define RTDD_ALL_TILES \
@@ -639,10 +647,42 @@ static void choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fi
     RTDD_TILE_CASE(6, 16, 512, 3) RTDD_TILE_CASE(7, 16, 256, 3) RTDD_TILE_CASE(8, 32, 1024, 2) RTDD_TILE_CASE(9, 16, 1024, 1) RTDD_TILE_CASE(10, 16, 512, 2) \
     RTDD_TILE_CASE(11, 32, 1024, 1) RTDD_TILE_CASE(12, 32, 768, 4) RTDD_TILE_CASE(13, 32, 512, 6)
 
+static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n, int *pk, int *pm, int *launches);
+
 // Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
 // holding x_{k+n} / x_{k+n-1}.  omegas_dev[0..n) must already be on the device.
+// A batch (ctx->batch.n images, rtdd_estimate_depth_batch) runs as ONE sequence of launches over all images (blockIdx.z) -- unless one
+// image alone already fills the chip and would run persistently (1080p: 252 tiles): then image after image, each with the launch a
+// single solve gets, which the model prices lower than a launch per block over the whole batch.
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
                           int *pk, int *pm, int *launches) {
+    const int images = ctx->batch.n;
+    if (images > 1 && ctx->opt.tile == 0 && ctx->opt.temporal_depth == 0 && !(cols <= 128 && rows <= 64)) {
+        int t1, T1, tb, Tb; bool p1, pb;
+        const Batch saved = ctx->batch;
+        ctx->batch.n = 1;
+        const double c1 = choose_config(ctx, rows, cols, n, 0, 0, &t1, &T1, &p1);
+        ctx->batch = saved;
+        const double cb = choose_config(ctx, rows, cols, n, 0, 0, &tb, &Tb, &pb);
+        if (p1 && c1 * images < cb) {
+            int rc = RTDD_OK, a = *pk, b = *pm, total = 0;
+            for (int i = 0; i < images && rc == RTDD_OK; i++) {
+                a = *pk; b = *pm;
+                int ln = 0;
+                ctx->batch.n = 1;
+                rc = launch_sweeps_blocked_impl(ctx, L.view(i), ip, rows, cols, omegas_dev, n, &a, &b, &ln);
+                total += ln;
+            }
+            ctx->batch = saved;
+            *pk = a; *pm = b; *launches = total;
+            return rc;
+        }
+    }
+    return launch_sweeps_blocked_impl(ctx, L, ip, rows, cols, omegas_dev, n, pk, pm, launches);
+}
+
+static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
+                                      int *pk, int *pm, int *launches) {
     const float gamma = 0.99;
     // Tile / depth / persistence choice: a small cost model calibrated on MI355X measurements
     // (scripts/tile_sweep*.sh, scripts/size_sweep.sh, scripts/ubench/*; tables in profiles/).
@@ -681,7 +721,8 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         // PERSISTENT mode: all remaining sweeps in ONE launch, neighbouring workgroups trade halo strips every T sweeps.
         // Only when every workgroup is certainly co-resident (grid <= #CUs), T is even, and there is more than one block.
         int block_sweeps = m;
-        bool persistent = !single && want_persistent && (int)(grid.x * grid.y) <= ctx->num_cus && grid.x * grid.y <= (unsigned)kSyncMaxTiles &&
+        const int images = ctx->batch.n;
+        bool persistent = !single && want_persistent && (int)(grid.x * grid.y) * images <= ctx->num_cus && grid.x * grid.y * images <= (unsigned)kSyncMaxTiles &&
                                 (T % 2 == 0) && n - done > T && hy == T &&
                                 hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
         if (is_col_tile(tile)) persistent = false;          // (the column-layout kernel has no persistent mode)
@@ -706,12 +747,13 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         for (int i = 0; i < 4; i++) if (i != *pk && i != *pm) { if (free0 < 0) free0 = i; else free1 = i; }
         float *Xk = L.P(*pk, ip), *Xm = L.P(*pm, ip);
         float *Yk = L.P(free0, ip), *Ym = L.P(free1, ip);
+        const size_t zPlane = L.elems * sizeof(float);
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) \
-    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps, flag_base); break;
+    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps, flag_base, zPlane); break;
         if (is_col_tile(tile)) {
-            const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles) : grid;
-            if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
-            else hipLaunchKernelGGL(k_sweep_col<false>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words);
+            const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles, 1, images) : dim3(grid.x, grid.y, images);
+            if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words, zPlane);
+            else hipLaunchKernelGGL(k_sweep_col<false>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words, zPlane);
         } else
         switch (tile) { RTDD_ALL_TILES }
 #undef RTDD_TILE_CASE

@@ -138,3 +138,54 @@ def test_acquire_fallback_of_the_hand_off_builds(tmp_path):
     persistent = [f for f in re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", asm) if "k_rbgs_blocked" in f.split("\n", 1)[0] and "buffer_inv sc1" in f]
     assert len(persistent) >= 4, "the acquire variant must invalidate at agent scope (buffer_inv sc1) in every persistent instantiation"
     assert not any(re.search(r"global_load_dwordx4 .* sc1", f) for f in persistent)
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="ROCm LLVM tools not present")
+def test_the_valu_operation_count_bench_py_prices_the_roofline_with_is_the_built_kernels(tmp_path):
+    """bench.py's roofline multiplies useful pixel-sweeps by "VALU operations per pixel-sweep".  That figure is a COUNT of the
+    instructions on the fall-through path of the sweep-pair loop of k_sweep_blocked<32, 1024, 3, true, true> (scripts/isa_count.py); the
+    constant bench.py falls back to where it cannot disassemble must equal a fresh count from the object that was just built (VERDICT r4
+    item 5c: the committed 15.1 was a typed-in number)."""
+    import importlib.util
+    import sys
+    rt.build()
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import isa_count
+    c = isa_count.sweep_pair()
+    spec = importlib.util.spec_from_file_location("bench_for_count", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    assert abs(c["per_pixel_sweep"] - bench.VALU_OPS["jacobi"]) < 0.05, (c["valu"], c["per_pixel_sweep"], bench.VALU_OPS["jacobi"])
+    # what the count is made of (per pair of sweeps x 12 pixels): the sums, the 3-operation divide, the tiny-numerator test, clamp and update
+    by = c["by_mnemonic"]
+    assert by.get("v_med3_f32") == 24 and by.get("v_lshl_add_u32") == 24 and by.get("v_cndmask_b32_e64", 0) == 0, by
+    assert by.get("ds_bpermute_b32") == 12 and by.get("ds_write_b128") == 4 and by.get("ds_read_b128") == 4, by      # lane shifts and edge rows: LDS path, not VALU
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="ROCm LLVM tools not present")
+def test_every_exec_mask_the_sweep_sets_is_undone_before_anything_else_runs(tmp_path):
+    """The update's last fma runs under an EXEC mask written by hand (sweep_common.hpp masked_fmac4: s_mov_b64 exec, <free-pixel mask>;
+    v_fmac_f32; ...; s_mov_b64 exec, -1).  In every k_sweep_blocked instantiation: between a hand-written `s_mov_b64 exec, s[..]` and the
+    restoring `s_mov_b64 exec, -1` there is nothing but the masked v_fmac_f32 / v_add_f32 and further mask writes -- the compiler can
+    schedule nothing in between (one asm statement), and this is the check that it did not."""
+    asm = _disassembly(tmp_path)
+    funcs = re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", asm)
+    checked = 0
+    for f in funcs:
+        head = f.split("\n", 1)[0]
+        if "k_sweep_blocked" not in head:
+            continue
+        instrs = [l.split("//")[0].strip() for l in f.split("\n")[1:] if re.match(r"\s+[a-z]", l)]
+        # (the compiler writes EXEC too -- s_mov_b64 exec, s[..] behind its own divergent regions, followed by a branch or by whatever comes
+        # next; a hand-written mask is the one whose next instruction is the masked operation)
+        masked = ("v_fmac_f32_e32", "v_add_f32_e32")
+        open_mask = False
+        for i, ins in enumerate(instrs):
+            if re.match(r"s_mov_b64 exec, s\[\d+:\d+\]", ins) and (open_mask or (i + 1 < len(instrs) and instrs[i + 1].startswith(masked))):
+                open_mask = True; checked += 1
+                assert instrs[i + 1].startswith(masked), f"{head}: '{instrs[i + 1]}' follows a hand-written EXEC mask"
+            elif ins == "s_mov_b64 exec, -1":
+                open_mask = False
+            elif open_mask:
+                assert ins.startswith(masked) and re.match(r"s_mov_b64 exec, ", instrs[i + 1]), f"{head}: '{ins}' / '{instrs[i + 1]}' under a hand-written EXEC mask"
+        assert not open_mask, head
+    assert checked >= 12 * 26, f"only {checked} masked updates found"
