@@ -628,6 +628,7 @@ def main():
         if v is not None:
             out["roofline"] = {"bound": "valu", "achieved": v["achieved"], "peak": v["peak"], "unit": "Tlane-op/s", "frac": v["frac"], "traffic": None,
                                "kernel": kname, "launch_us": launch_us, "ops_per_pixel_sweep": v["ops_per_pixel_sweep"],
+                               "ops_source": v.get("ops_source"), "frac_at_round4_count": v.get("frac_at_round4_count"),
                                "mix_issue_cycles_measured": v["mix_issue_cycles_measured"], "frac_of_mix_issue_rate": v["frac_of_mix_issue_rate"],
                                "definition": "useful pixel-sweeps/s of the kernel x VALU operations per pixel-sweep (static ISA count) / (256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz); halo redundancy not credited",
                                "hbm_equivalent": hbm_equivalent}
