@@ -257,7 +257,7 @@ __global__ __launch_bounds__(1024) void k_sat_colbase(u64 *__restrict__ colsum, 
 // wave totals by a 16-lane scan, two aligned 16-byte stores per row.
 template <bool VEC>
 __global__ __launch_bounds__(1024) void k_sat_build(const uint8_t *__restrict__ orig, size_t op, const u64 *__restrict__ colbase, u64 *__restrict__ T,
-                                                    int tp, int rows, int cols, int RB) {
+                                                    int tp, int rows, int cols, int RB, int tpitch) {
     __shared__ u64 wtot[2][4][16];                                  // [buffer][row of the group of four][wave]
     __shared__ u64 rowcarry[2][32];                                 // [parity of the column range][row of the band]: everything left of the range
     const int tid = threadIdx.x, lane = tid & 63, nt = (int)blockDim.x, nw = nt >> 6;
@@ -310,19 +310,13 @@ __global__ __launch_bounds__(1024) void k_sat_build(const uint8_t *__restrict__ 
                 const u64 left = rowcarry[par][sub + i];
                 const u64 add = left + before + excl[i];
                 if (r < rows && x < tp) {
-                    u64x2 *q = (u64x2 *)(T + (size_t)r * tp + x);
+                    u64x2 *q = (u64x2 *)(T + (size_t)r * tpitch + x);
                     q[0] = u64x2{s[i][0] + add, s[i][1] + add}; q[1] = u64x2{s[i][2] + add, s[i][3] + add};
                 }
                 if (tid == 0) rowcarry[par ^ 1][sub + i] = left + all;   // read again only after the next barrier
             }
         }
     }
-}
-
-// T(r, c) with T(-1, .) = T(., -1) = 0
-__device__ __forceinline__ u64 sat_at(const u64 *__restrict__ T, int tp, int r, int c) {
-    const u64 v = T[__umul24(max(r, 0), tp) + (uint32_t)max(c, 0)];       // (rows, tp < 2^24 and rows * tp < 2^32: check_effect; v_mul_lo_u32 is a quarter-rate instruction)
-    return (r < 0 || c < 0) ? 0ull : v;
 }
 
 // k / 2 of  int k = kernelSize * depth / 255.0  (src/GPUDepthEffect.cu:43: int * float -> float, / double, truncation), without the
@@ -351,90 +345,103 @@ __device__ __forceinline__ uint32_t quot_u8(uint32_t s, uint32_t count, float rc
     return (uint32_t)min(n, 255);
 }
 
-// simulateDefocus (K9) -- src/GPUDepthEffect.cu:29-72.  Lane = pixel, wave = 64 pixels of one row, workgroup = 64 x 8 pixels (each
-// wave two rows: their depth loads, then their 8 corner loads are all in flight before any is used; measured 4K smooth depth
-// 50.8 / 48.2 / 55.7 / 75.0 us for 1 / 2 / 4 / 8 rows per wave -- the kernel is bound by the lines its gathers pull from L2, and a
-// wave that spreads over more rows keeps fewer of them in L1 between its left- and right-corner loads).  Workgroups are numbered so
-// that each XCD (dispatch: workgroup p -> XCD p % 8) takes a contiguous band of tile rows: its L2 then holds one eighth of the table
-// plus the rows a window reaches beyond it.  `orig` and `art` move as dwords: the three dwords of a quad of pixels are loaded / stored
-// by its first three lanes and re-cut into pixels with one quad-permute each (VEC: rows 4-byte aligned; otherwise, and in a ragged
-// last tile, bytes).
-#ifndef RTDD_DEFOCUS_ROWS
-#define RTDD_DEFOCUS_ROWS 2
-#endif
-constexpr int kDefocusRows = RTDD_DEFOCUS_ROWS;                     // rows per wave
+// simulateDefocus (K9) -- src/GPUDepthEffect.cu:29-72: the lookup.  Lane = pixel, wave = 64 pixels x 2 rows, workgroup = 64 x 8 pixels
+// (1 / 2 / 4 / 8 rows per wave measured 50.8 / 48.2 / 55.7 / 75.0 us at 4K in round 3: a wave that spreads over more rows keeps fewer of
+// the table lines it gathers in L1 between its left- and right-corner loads; TWO pixels per lane in x measured 101 against 79 us in
+// round 5 -- a wave instruction then touches twice the lines).  Workgroups are numbered so that each XCD (dispatch: workgroup p -> XCD
+// p % 8) takes a contiguous band of tile rows.  Round 5 rebuilt the kernel around its instruction count and its loads:
+//   * the table is PADDED: one zero row above row 0 and four zero entries left of column 0 (T'[r + 1][c + 4] = T(r, c); the padding is
+//     zeroed when the table's geometry changes and nobody ever writes it), so T(-1, .) = T(., -1) = 0 needs no select;
+//   * the four corners are raw BUFFER loads: a 32-bit byte offset each -- row * pitch_bytes is one 24-bit multiply shared by two
+//     corners, the column term one shift-add shared by two -- instead of four 64-bit address computations with a select each;
+//   * the original pixel is only needed where the window is empty (depth < 510 / kernelSize: the reference's loops do not run and the
+//     pixel is copied): loaded under one wave-uniform branch, not for every pixel (25 MB less at 4K);
+//   * `art` moves as dwords: the three dwords of a quad of pixels are stored by its first three lanes after one quad permute.
+// 4K smooth depth 86.5 -> 78.5 us for the whole effect, 1440p 46.0 -> 43.2, 8K 746 -> 732 (profiles/r05_defocus_lookup_ab.txt); the
+// same integer sums and quotient code as before: bit-identical (every pixel at 4K / 8K against an independent table, tests/).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u64 tab_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, 0, 0);
+    return ((u64)v.y << 32) | v.x;
+}
+
+constexpr int kLk2Rows = 2;                                         // rows per wave
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ orig, size_t op, const float *__restrict__ depth, size_t dp,
-                                                 const u64 *__restrict__ T, int tp, uint8_t *__restrict__ art, size_t ap,
-                                                 int rows, int cols, int kernelSize, int gx, int ntiles, int xcd_tiles) {
+                                                  const u64 *__restrict__ Tpad, int tpitch, uint8_t *__restrict__ art, size_t ap,
+                                                  int rows, int cols, int kernelSize, int gx, int ntiles, int xcd_tiles) {
     const int p = blockIdx.x;
     const int tile = xcd_tiles > 0 ? (p & 7) * xcd_tiles + (p >> 3) : p;
     if (tile >= ntiles) return;
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int x0 = (tile % gx) * 64, x = x0 + lane, xc = min(x, cols - 1);
-    const int yw = (tile / gx) * (4 * kDefocusRows) + wv * kDefocusRows;
-    const bool whole = VEC && x0 + 64 <= cols;                      // wave-uniform: the dword path
-    const int j = lane & 3;
-    float d[kDefocusRows];
-    uint32_t opx[kDefocusRows];                                     // this pixel's B | G << 8 | R << 16
+    const int x0 = (tile % gx) * 64, yw = (tile / gx) * (4 * kLk2Rows) + wv * kLk2Rows;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Tpad, 0, (int)((uint32_t)(rows + 1) * (uint32_t)tpitch * 8u), 0x00020000);
+    const uint32_t pitch8 = (uint32_t)tpitch * 8u;
+    const bool whole = VEC && x0 + 64 <= cols;                      // wave-uniform: the output as dwords
+    const int x = x0 + lane, xc = min(x, cols - 1), j = lane & 3;
+    float d[kLk2Rows];
 #pragma unroll
-    for (int i = 0; i < kDefocusRows; i++) {
-        const int y = min(yw + i, rows - 1);
-        d[i] = ((const float *)((const char *)depth + (size_t)y * dp))[xc];
-        const uint8_t *orow = orig + (size_t)y * op;
-        if (whole) {
-            const uint32_t L = j < 3 ? ((const uint32_t *)(orow + 3 * (size_t)x0))[3 * (lane >> 2) + j] : 0u;
-            const uint32_t prv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x90, 0xF, 0xF, true);   // quad_perm:[0,0,1,2]
-            opx[i] = __builtin_amdgcn_alignbit(L, prv, (32 - 8 * j) & 31) & 0xFFFFFFu;
-        } else {
-            const uint8_t *o = orow + 3 * (size_t)xc;
-            opx[i] = o[0] | (o[1] << 8) | (o[2] << 16);
-        }
-    }
-    int ya[kDefocusRows], yb[kDefocusRows], xa[kDefocusRows], xb[kDefocusRows];
-    u64 c00[kDefocusRows], c01[kDefocusRows], c10[kDefocusRows], c11[kDefocusRows];
+    for (int i = 0; i < kLk2Rows; i++) d[i] = ((const float *)((const char *)depth + (size_t)min(yw + i, rows - 1) * dp))[xc];
+    uint32_t cnt[kLk2Rows];
+    u64 X[kLk2Rows];
+    int ya[kLk2Rows], yb[kLk2Rows], xa[kLk2Rows], xb[kLk2Rows];
 #pragma unroll
-    for (int i = 0; i < kDefocusRows; i++) {
+    for (int i = 0; i < kLk2Rows; i++) {
         const int y = min(yw + i, rows - 1);
         const int h = half_window(kernelSize, d[i]);
         ya[i] = max(y - h, 0); yb[i] = (int)min((long long)y + h, (long long)rows);
         xa[i] = max(xc - h, 0); xb[i] = (int)min((long long)xc + h, (long long)cols);
-        // a window too large for one lookup fetches its first strip's corners here (the rest below); h == 0 fetches T(y-1, x-1) four times
-        c00[i] = sat_at(T, tp, ya[i] - 1, xa[i] - 1); c01[i] = sat_at(T, tp, ya[i] - 1, xb[i] - 1);
-        c10[i] = sat_at(T, tp, yb[i] - 1, xa[i] - 1); c11[i] = sat_at(T, tp, yb[i] - 1, xb[i] - 1);
+        // T(ya - 1, xa - 1) = T'[ya][xa + 3], ...: byte offsets row * pitch8 + 8 * col + 24
+        const uint32_t ra = (uint32_t)__umul24(ya[i], pitch8), rb = (uint32_t)__umul24(yb[i], pitch8);       // rows <= 2^14, pitch8 < 2^24: exact in 32 bits (check_effect)
+        const uint32_t ca = 8u * (uint32_t)xa[i] + 24u, cb = 8u * (uint32_t)xb[i] + 24u;
+        const u64 c00 = tab_load(rsrc, ra + ca), c01 = tab_load(rsrc, ra + cb), c10 = tab_load(rsrc, rb + ca), c11 = tab_load(rsrc, rb + cb);
+        X[i] = c11 - c10 - c01 + c00;
+        const int wd = xb[i] - xa[i], ht = yb[i] - ya[i];
+        cnt[i] = (wd > 0 && ht > 0) ? (uint32_t)ht * (uint32_t)wd : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < kDefocusRows; i++) {
-        const int y = yw + i;
-        uint32_t res = opx[i];                                      // count == 0 (:62-66): the pixel itself
-        const int wd = xb[i] - xa[i], ht = yb[i] - ya[i];
-        if (wd > 0 && ht > 0) {
-            const uint32_t cnt = (uint32_t)ht * (uint32_t)wd;
-            uint32_t sb, sg, sr;
-            if (cnt <= (uint32_t)kSatMaxArea) {                     // every nominal window up to 2560x1440, most beyond
-                const u64 X = c11[i] - c10[i] - c01[i] + c00[i];
-                sb = (uint32_t)(X & kSatFieldMask); sg = (uint32_t)((X >> 21) & kSatFieldMask); sr = (uint32_t)(X >> 42);
-            } else {                                                // strips of <= kSatMaxArea pixels (columns too, should a row be wider)
-                sb = sg = sr = 0;
+    for (int i = 0; i < kLk2Rows; i++) {
+        const int y = yw + i, yc = min(y, rows - 1);
+        uint32_t res;
+        {
+            const uint32_t sb = (uint32_t)(X[i] & kSatFieldMask), sg = (uint32_t)((X[i] >> 21) & kSatFieldMask), sr = (uint32_t)(X[i] >> 42);
+            const uint32_t c = cnt[i] ? cnt[i] : 1u;
+            const float rc = __builtin_amdgcn_rcpf((float)c);
+            res = quot_u8(sb, c, rc) | (quot_u8(sg, c, rc) << 8) | (quot_u8(sr, c, rc) << 16);
+        }
+        // windows of more than kSatMaxArea pixels (the packed fields would run into each other) and empty ones: under wave-uniform branches
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt[i] > (uint32_t)kSatMaxArea) != 0, 0)) {
+            if (cnt[i] > (uint32_t)kSatMaxArea) {                   // strips of <= kSatMaxArea pixels that share corner rows (columns too, should a row be wider)
+                uint32_t sb = 0, sg = 0, sr = 0;
+                const int wd = xb[i] - xa[i];
                 const int cw = min(wd, kSatMaxArea), rh = max(kSatMaxArea / cw, 1);
                 for (int xs = xa[i]; xs < xb[i]; xs += cw) {
                     const int xe = min(xs + cw, xb[i]);
-                    u64 D0 = sat_at(T, tp, ya[i] - 1, xe - 1) - sat_at(T, tp, ya[i] - 1, xs - 1);
+                    const uint32_t cs = 8u * (uint32_t)xs + 24u, ce = 8u * (uint32_t)xe + 24u;
+                    const uint32_t r0 = (uint32_t)ya[i] * pitch8;
+                    u64 D0 = tab_load(rsrc, r0 + ce) - tab_load(rsrc, r0 + cs);
                     for (int ys = ya[i]; ys < yb[i]; ys += rh) {
                         const int ye = min(ys + rh, yb[i]);
-                        const u64 D1 = sat_at(T, tp, ye - 1, xe - 1) - sat_at(T, tp, ye - 1, xs - 1);
-                        const u64 X = D1 - D0;
-                        sb += (uint32_t)(X & kSatFieldMask); sg += (uint32_t)((X >> 21) & kSatFieldMask); sr += (uint32_t)(X >> 42);
+                        const uint32_t r1 = (uint32_t)ye * pitch8;
+                        const u64 D1 = tab_load(rsrc, r1 + ce) - tab_load(rsrc, r1 + cs);
+                        const u64 Xs = D1 - D0;
+                        sb += (uint32_t)(Xs & kSatFieldMask); sg += (uint32_t)((Xs >> 21) & kSatFieldMask); sr += (uint32_t)(Xs >> 42);
                         D0 = D1;
                     }
                 }
+                if (cnt[i] < 65536u && (sb | sg | sr) < (1u << 24)) {           // nominal: exact sums, exact integer quotients
+                    const float rc = __builtin_amdgcn_rcpf((float)cnt[i]);
+                    res = quot_u8(sb, cnt[i], rc) | (quot_u8(sg, cnt[i], rc) << 8) | (quot_u8(sr, cnt[i], rc) << 16);
+                } else {                                            // (an out-of-range depth: the reference's own f32 sums round here)
+                    const float count = (float)cnt[i];
+                    res = store_u8((float)sb / count) | (store_u8((float)sg / count) << 8) | (store_u8((float)sr / count) << 16);
+                }
             }
-            if (cnt < 65536u && (sb | sg | sr) < (1u << 24)) {      // nominal: exact sums, exact integer quotients (quot_u8)
-                const float rc = __builtin_amdgcn_rcpf((float)cnt);
-                res = quot_u8(sb, cnt, rc) | (quot_u8(sg, cnt, rc) << 8) | (quot_u8(sr, cnt, rc) << 16);
-            } else {                                                // (an out-of-range depth: the reference's own f32 sums round here)
-                const float count = (float)cnt;
-                res = store_u8((float)sb / count) | (store_u8((float)sg / count) << 8) | (store_u8((float)sr / count) << 16);
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt[i] == 0u) != 0, 0)) {   // count == 0 (src/GPUDepthEffect.cu:62-66): the pixel itself
+            if (cnt[i] == 0u) {
+                const uint8_t *o = orig + (size_t)yc * op + 3 * (size_t)xc;
+                res = o[0] | (o[1] << 8) | (o[2] << 16);
             }
         }
         if (y < rows) {                                             // wave-uniform
@@ -728,19 +735,26 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
         ctx->persistent_used = true;                 // (the next synchronising call reads the control words: check_persistent_status)
         return RTDD_OK;
     }
-    const int tp = (cols + 3) / 4 * 4;                                  // table row pitch in entries: 32-byte aligned groups of four
+    const int tp = (cols + 3) / 4 * 4;                                  // entries the build writes per row: 32-byte aligned groups of four
+    // the table is padded -- one zero row above, four zero entries left of every row (k_defocus): T'[r + 1][c + 4] = T(r, c)
+    const int tpitch = tp + 4;
     // band height: one workgroup per band builds the table, so enough bands to occupy the chip (270 / 135 / 135 workgroups of 8 / 16 / 16
     // waves at 1080p / 4K / 8K); a band costs 8 B per column three times over (colsum, its scan, the build's read)
     static const int rb_env = getenv("RTDD_DEFOCUS_BAND") ? atoi(getenv("RTDD_DEFOCUS_BAND")) : 0;
     const int RB = rb_env >= 4 && rb_env <= 32 && rb_env % 4 == 0 ? rb_env : rows <= 1536 ? 4 : rows <= 3072 ? 16 : 32;
     const int nbands = (rows + RB - 1) / RB;
-    const size_t need = (((size_t)rows + nbands) * tp * sizeof(u64) + 256) / sizeof(uint32_t);   // table + band bases, in u32 words
+    const size_t table_entries = ((size_t)rows + 1) * tpitch;
+    const size_t need = ((table_entries + (size_t)nbands * tp) * sizeof(u64) + 256) / sizeof(uint32_t);   // padded table + band bases, in u32 words
     if (ctx->sat_elems < need) {
         if (ctx->sat) { RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream)); RTDD_HIP(ctx, hipFree(ctx->sat)); ctx->sat = nullptr; ctx->sat_elems = 0; }
         RTDD_HIP(ctx, hipMalloc((void **)&ctx->sat, need * sizeof(uint32_t)));
-        ctx->sat_elems = need;
+        ctx->sat_elems = need; ctx->sat_rows = ctx->sat_cols = 0;
     }
-    u64 *T = (u64 *)ctx->sat, *base = T + (size_t)rows * tp;
+    u64 *Tpad = (u64 *)ctx->sat, *T = Tpad + tpitch + 4, *base = Tpad + table_entries;
+    if (ctx->sat_rows != rows || ctx->sat_cols != cols) {              // another geometry: the padding lies elsewhere -- zero the table once (the build never writes the padding)
+        RTDD_HIP(ctx, hipMemsetAsync(Tpad, 0, table_entries * sizeof(u64), ctx->stream));
+        ctx->sat_rows = rows; ctx->sat_cols = cols;
+    }
     const bool vin = (uintptr_t)orig % 4 == 0 && op % 4 == 0, vout = vin && (uintptr_t)art % 4 == 0 && ap % 4 == 0;
     const dim3 g1((tp / 4 + 255) / 256, nbands);
     if (vin) hipLaunchKernelGGL(k_sat_colsum<true>, g1, dim3(256), 0, ctx->stream, orig, op, base, tp, rows, cols, RB);
@@ -750,14 +764,16 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
     hipLaunchKernelGGL(k_sat_colbase, dim3((tp + 63) / 64), dim3(64 * scan_waves), 0, ctx->stream, base, tp, nbands);
     RTDD_LAUNCH_CHECK(ctx, "k_sat_colbase");
     int build_waves = (tp / 4 + 63) / 64; if (build_waves > 16) build_waves = 16;
-    if (vin) hipLaunchKernelGGL(k_sat_build<true>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, orig, op, base, T, tp, rows, cols, RB);
-    else hipLaunchKernelGGL(k_sat_build<false>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, orig, op, base, T, tp, rows, cols, RB);
+    if (vin) hipLaunchKernelGGL(k_sat_build<true>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, orig, op, base, T, tp, rows, cols, RB, tpitch);
+    else hipLaunchKernelGGL(k_sat_build<false>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, orig, op, base, T, tp, rows, cols, RB, tpitch);
     RTDD_LAUNCH_CHECK(ctx, "k_sat_build");
-    const int gx = (cols + 63) / 64, gy = (rows + 4 * kDefocusRows - 1) / (4 * kDefocusRows), ntiles = gx * gy;
-    const int xcd_tiles = ntiles >= 64 ? (ntiles + 7) / 8 : 0;
-    const dim3 g4(xcd_tiles > 0 ? 8 * xcd_tiles : ntiles);
-    if (vout) hipLaunchKernelGGL(k_defocus<true>, g4, dim3(256), 0, ctx->stream, orig, op, depth, dp, T, tp, art, ap, rows, cols, kernelSize, gx, ntiles, xcd_tiles);
-    else hipLaunchKernelGGL(k_defocus<false>, g4, dim3(256), 0, ctx->stream, orig, op, depth, dp, T, tp, art, ap, rows, cols, kernelSize, gx, ntiles, xcd_tiles);
+    {
+        const int gx2 = (cols + 63) / 64, gy2 = (rows + 4 * kLk2Rows - 1) / (4 * kLk2Rows), nt2 = gx2 * gy2;
+        const int xt2 = nt2 >= 64 ? (nt2 + 7) / 8 : 0;
+        const dim3 g5(xt2 > 0 ? 8 * xt2 : nt2);
+        if (vout) hipLaunchKernelGGL(k_defocus<true>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2);
+        else hipLaunchKernelGGL(k_defocus<false>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2);
+    }
     RTDD_LAUNCH_CHECK(ctx, "k_defocus");
     ctx->defocus_last_path = 1;
     return RTDD_OK;

@@ -160,6 +160,7 @@ struct rtdd_ctx {
     signed char persist_fit[17][2];  // per (tile id, contraction): does one workgroup of the persistent kernel fit a CU of THIS device (-1 = not asked yet)
     uint32_t *sat = nullptr;        // defocus summed-area table scratch
     size_t sat_elems = 0;
+    int sat_rows = 0, sat_cols = 0;     // the geometry the table's zero padding was laid out for (effect_kernels.hip)
     int num_cus = 256;
     rtdd::Options opt;
     bool profile_on = false;
