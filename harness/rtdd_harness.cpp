@@ -262,7 +262,12 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
                 if (p.frame == n) {
                     // main.cpp:46-62: the mouse callback paints the DEVICE images and downloads them into the host's Mats, which the next
                     // estimate uploads again (:236-237).  The frames in flight are let land first: they read the images being painted.
-                    if (!painted) while (rtdd_live_pending(ctx) > 0) { const int f = n - rtdd_live_pending(ctx); CK(rtdd_live_wait(ctx)); landed(f); }
+                    if (!painted) {
+                        while (rtdd_live_pending(ctx) > 0) { const int f = n - rtdd_live_pending(ctx); CK(rtdd_live_wait(ctx)); landed(f); }
+                        // (an uploaded annotation pair becomes the pyramid's level-0 images: ask where they are now, include/rtdd.h)
+                        CK(rtdd_pyramid_image(ctx, RTDD_IMG_SCRIBBLE, 0, &p_scr, &pi_scr, nullptr, nullptr));
+                        CK(rtdd_pyramid_image(ctx, RTDD_IMG_EDITED, 0, &p_ed, &pi_ed, nullptr, nullptr));
+                    }
                     CK(rtdd_paint_image(ctx, p.x, p.y, p.label, p.radius, (uint8_t *)p_ed, pi_ed, (uint8_t *)p_scr, pi_scr, rows, cols));
                     painted = true;
                 }
@@ -275,6 +280,7 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
         }
         while (rtdd_live_pending(ctx) > 0) { const int f = count - rtdd_live_pending(ctx); CK(rtdd_live_wait(ctx)); landed(f); }
         *ms_per_estimate = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (count > 0 ? count : 1);
+        CK(rtdd_pyramid_image(ctx, RTDD_IMG_EDITED, 0, &p_ed, &pi_ed, nullptr, nullptr));
         if (annotated) { annotated->resize((size_t)rows * cols * 3); CK(rtdd_download(ctx, annotated->data(), (size_t)cols * 3, p_ed, pi_ed, (size_t)cols * 3, rows)); }
         CK(rtdd_ctx_synchronize(ctx));
         return RTDD_OK;

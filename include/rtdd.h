@@ -301,8 +301,11 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations);
  * waited for, and should be page-locked (rtdd_host_alloc) -- pageable memory makes the copies synchronous.  hostScribble / hostEdited
  * NULL: no upload, the annotation is the one already on the device.  A third submit waits for the oldest frame itself.
  * rtdd_live_wait blocks until the OLDEST frame in flight has landed in its host buffer (a timed-out persistent launch is healed
- * there like in rtdd_ctx_synchronize; with two frames in flight the healed older frame may already see the newer frame's
- * annotation).  Results: hostDepthU8, and RTDD_IMG_DEPTH / RTDD_IMG_DEPTH_U8 on the device as after rtdd_estimate_depth. */
+ * there like in rtdd_ctx_synchronize: every frame in flight is run again on its own uploaded annotation; the COARSE annotation levels,
+ * which only ever accumulate, may by then hold the newer frame's strokes too).  Results: hostDepthU8, and RTDD_IMG_DEPTH /
+ * RTDD_IMG_DEPTH_U8 on the device as after rtdd_estimate_depth.  No staging copies: an uploaded annotation pair BECOMES the pyramid's
+ * level-0 RTDD_IMG_SCRIBBLE / RTDD_IMG_EDITED -- pointers obtained from rtdd_pyramid_image for those two images are good until the
+ * next rtdd_live_submit that uploads: ask again after it (every other image keeps its address). */
 int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribblePitch, const uint8_t *hostEdited, size_t editedPitch,
                      int maxIterations, uint8_t *hostDepthU8, size_t depthPitch);
 int rtdd_live_wait(rtdd_ctx *ctx);

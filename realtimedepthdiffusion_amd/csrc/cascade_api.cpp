@@ -40,6 +40,11 @@ struct Live {
     int *status_host = nullptr;           // page-locked, 2 x 8 ints: the kernels' control words as they were behind each frame's estimate
     struct Frame { uint8_t *host = nullptr; size_t pitch = 0; bool in_flight = false; unsigned long long op_id = 0; } frame[2];
     unsigned long long submitted = 0, waited = 0;
+    // Round 5: no device-to-device staging copies.  A frame's annotation is uploaded into the staging pair that is NOT the pyramid's
+    // current level-0 annotation, and the pyramid's level-0 scribble / edited images then simply BECOME that pair (pointer swap); the
+    // frame's u8 map is written by the estimate's copy-back into RTDD_IMG_DEPTH_U8 AND into the frame's slot (k_finish: two targets).
+    // The pyramid's own annotation buffers are kept here and put back before the pyramid is freed.
+    void *own_scribble = nullptr, *own_edited = nullptr;
 };
 
 static bool inside(const Image &im, const void *p) {
@@ -74,6 +79,7 @@ static void free_image(Image &im) {
 static void live_free(Pyramid *p) {
     Live *v = p->live;
     if (!v) return;
+    if (v->own_scribble) { p->scribble[0].ptr = v->own_scribble; p->edited[0].ptr = v->own_edited; }
     if (v->up) { (void)hipStreamSynchronize(v->up); (void)hipStreamDestroy(v->up); }
     if (v->copy) { (void)hipStreamSynchronize(v->copy); (void)hipStreamDestroy(v->copy); }
     for (int k = 0; k < 2; k++) {
@@ -251,24 +257,21 @@ static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, s
         // every image of the batch in one launch per step, whatever the estimate covers: the flag is one for the whole batch, and the
         // down-sampling only ever adds (an up-to-date image stays as it is)
         DeviceGuard g(ctx->device);
-        const int all = p->images;
-        for (int l = 1; l < P && rc == RTDD_OK; l++)                           // src/main.cpp:249-253
-            if (p->edited[l].rows > 0 && p->edited[l].cols > 0)
-                rc = launch_pyrdown_annotation(ctx, (const uint8_t *)p->scribble[l - 1].ptr, p->scribble[l - 1].pitch,
-                                               (const uint8_t *)p->edited[l - 1].ptr, p->edited[l - 1].pitch, p->edited[l - 1].rows, p->edited[l - 1].cols,
-                                               (uint8_t *)p->scribble[l].ptr, p->scribble[l].pitch, (uint8_t *)p->edited[l].ptr, p->edited[l].pitch,
-                                               p->edited[l].rows, p->edited[l].cols, all, p->scribble[l - 1].stride, p->edited[l - 1].stride, p->scribble[l].stride, p->edited[l].stride);
-        if (rc != RTDD_OK) return rc;
-        if (p->edited[P - 1].rows > 0 && p->edited[P - 1].cols > 0)
-            rc = launch_convert(ctx, (const uint8_t *)p->edited[P - 1].ptr, p->edited[P - 1].pitch, (float *)p->depth[P - 1].ptr, p->depth[P - 1].pitch,
-                                (const uint8_t *)p->scribble[P - 1].ptr, p->scribble[P - 1].pitch, p->edited[P - 1].rows, p->edited[P - 1].cols,
-                                all, p->edited[P - 1].stride, p->depth[P - 1].stride, p->scribble[P - 1].stride);   // :257-259
+        uint8_t *sc[32], *ed[32]; size_t sp[32], ep[32], zs[32], ze[32]; int lr[32], lc[32];
+        if (P > 12) return fail(ctx, RTDD_ERR_INVALID, "more than 12 pyramid levels");
+        for (int l = 0; l < P; l++) {
+            sc[l] = (uint8_t *)p->scribble[l].ptr; ed[l] = (uint8_t *)p->edited[l].ptr; sp[l] = p->scribble[l].pitch; ep[l] = p->edited[l].pitch;
+            zs[l] = p->scribble[l].stride; ze[l] = p->edited[l].stride; lr[l] = p->edited[l].rows; lc[l] = p->edited[l].cols;
+        }
+        // src/main.cpp:249-259: the P - 1 annotation levels and the coarsest level's injection, one launch (image_kernels.hip)
+        rc = launch_annotation_pyramid(ctx, P, sc, sp, zs, ed, ep, ze, lr, lc, (float *)p->depth[P - 1].ptr, p->depth[P - 1].pitch, p->depth[P - 1].stride, p->images);
         if (rc != RTDD_OK) return rc;
         p->annotation_dirty = false;
     }
     PendingOp op;
     op.kind = PendingOp::kEstimate; op.opt = ctx->opt; op.maxIterations = maxIterations;
     op.u8_copy = u8_copy; op.u8_copy_pitch = u8_copy_pitch; op.batch_first = first; op.batch_n = n;
+    for (int i = 0; i < 3; i++) op.live_images[i] = ctx->live_images[i];       // a live frame: the level-0 annotation pair and the u8 slot it ran on
     rc = estimate_levels(ctx, maxIterations, P - 1, op.level_seq, first, n);
     if (rc == RTDD_OK && u8_copy) {
         DeviceGuard g(ctx->device);
@@ -320,6 +323,9 @@ static int live_create(rtdd_ctx *ctx) {
         RTDD_HIP(ctx, hipEventCreateWithFlags(&v->est_done[k], hipEventDisableTiming));
         RTDD_HIP(ctx, hipEventCreateWithFlags(&v->d2h_done[k], hipEventDisableTiming));
     }
+    if (v->scribble_stage[0].pitch != p->scribble[0].pitch || v->edited_stage[0].pitch != p->edited[0].pitch || v->u8_stage[0].pitch != p->depth_u8.pitch)
+        return fail(ctx, RTDD_ERR_STATE, "live staging images and pyramid images differ in pitch");
+    v->own_scribble = p->scribble[0].ptr; v->own_edited = p->edited[0].ptr;
     RTDD_HIP(ctx, hipHostMalloc((void **)&v->status_host, 2 * 8 * sizeof(int), hipHostMallocDefault));
     for (int i = 0; i < 16; i++) v->status_host[i] = 0;
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));                                // the staging images' fills
@@ -379,18 +385,24 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
     if (v->submitted - v->waited >= 2 && (rc = rtdd_live_wait(ctx)) != RTDD_OK) return rc;   // two frames in flight at most: the slot is free again
     const int k = (int)(v->submitted % 2);
     if (hostScribble) {
-        RTDD_HIP(ctx, hipMemcpy2DAsync(v->scribble_stage[k].ptr, v->scribble_stage[k].pitch, hostScribble, scribblePitch, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, v->up));
-        RTDD_HIP(ctx, hipMemcpy2DAsync(v->edited_stage[k].ptr, v->edited_stage[k].pitch, hostEdited, editedPitch, (size_t)p->cols * 3, p->rows, hipMemcpyHostToDevice, v->up));
+        // upload into the staging pair the pyramid is NOT looking at: the only frame that can still be in flight reads the other one
+        // (at most two frames in flight, and the older one has been waited for above)
+        const int u = p->scribble[0].ptr == v->scribble_stage[0].ptr ? 1 : 0;
+        RTDD_HIP(ctx, hipMemcpy2DAsync(v->scribble_stage[u].ptr, v->scribble_stage[u].pitch, hostScribble, scribblePitch, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, v->up));
+        RTDD_HIP(ctx, hipMemcpy2DAsync(v->edited_stage[u].ptr, v->edited_stage[u].pitch, hostEdited, editedPitch, (size_t)p->cols * 3, p->rows, hipMemcpyHostToDevice, v->up));
         RTDD_HIP(ctx, hipEventRecord(v->h2d_done[k], v->up));
         // (in the steady state the upload overlapped the previous frame and is long done: a cross-stream wait the compute stream does not
         // need costs it ~10 us of idle time)
         if (hipEventQuery(v->h2d_done[k]) != hipSuccess) RTDD_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->h2d_done[k], 0));
-        RTDD_HIP(ctx, hipMemcpy2DAsync(p->scribble[0].ptr, p->scribble[0].pitch, v->scribble_stage[k].ptr, v->scribble_stage[k].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
-        RTDD_HIP(ctx, hipMemcpy2DAsync(p->edited[0].ptr, p->edited[0].pitch, v->edited_stage[k].ptr, v->edited_stage[k].pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+        p->scribble[0].ptr = v->scribble_stage[u].ptr; p->edited[0].ptr = v->edited_stage[u].ptr;      // the pyramid's level-0 annotation IS the uploaded pair: no copy
         p->annotation_dirty = true;
     }
     unsigned long long op_id = ctx->op_counter;
-    if ((rc = estimate_submit(ctx, maxIterations, (uint8_t *)v->u8_stage[k].ptr, v->u8_stage[k].pitch, &op_id)) != RTDD_OK) return rc;
+    // (the estimate's copy-back writes this frame's map into RTDD_IMG_DEPTH_U8 and into the frame's staging slot: estimate_levels)
+    ctx->live_images[0] = p->scribble[0].ptr; ctx->live_images[1] = p->edited[0].ptr; ctx->live_images[2] = v->u8_stage[k].ptr;
+    rc = estimate_submit(ctx, maxIterations, nullptr, 0, &op_id);
+    ctx->live_images[0] = ctx->live_images[1] = ctx->live_images[2] = nullptr;
+    if (rc != RTDD_OK) return rc;
     RTDD_HIP(ctx, hipEventRecord(v->est_done[k], ctx->stream));
     RTDD_HIP(ctx, hipStreamWaitEvent(v->copy, v->est_done[k], 0));
     RTDD_HIP(ctx, hipMemcpy2DAsync(hostDepthU8, depthPitch, v->u8_stage[k].ptr, v->u8_stage[k].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, v->copy));
@@ -424,6 +436,7 @@ int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level
         // writes the u8 map (:290).  Same values in the same buffers (tests/test_gpu_cascade.py compares every level's image).
         ctx->defer_finish = solved && l > 0;
         ctx->finish_u8 = l == 0 ? (uint8_t *)p->depth_u8.at(first) : nullptr; ctx->finish_u8_pitch = p->depth_u8.pitch;
+        ctx->finish_u8b = l == 0 ? (uint8_t *)ctx->live_images[2] : nullptr; ctx->finish_u8b_pitch = p->depth_u8.pitch;     // (a live frame: its staging slot too)
         if (solved) {
             // the level of images first .. first + n - 1 in the same launches (blockIdx.z = image: Batch, rtdd_internal.hpp)
             ctx->batch.n = n; ctx->batch.first = first;
@@ -434,7 +447,7 @@ int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level
             if (level_seq && l < 32) level_seq[l] = ctx->solve_seq;
         }
         const bool deferred = ctx->defer_finish;
-        ctx->defer_finish = false; ctx->finish_u8 = nullptr;
+        ctx->defer_finish = false; ctx->finish_u8 = nullptr; ctx->finish_u8b = nullptr;
         if (rc == RTDD_OK && l > 0) {
             DeviceGuard g(ctx->device);
             const float *src = (const float *)p->depth[l].at(first); size_t sp = p->depth[l].pitch;
@@ -469,7 +482,12 @@ int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
     int from = -1;                                  // the level whose solve gave up; an estimate queued behind the failed call: every level
     for (int l = 0; l < 32; l++) if (failed_seq != 0 && op.level_seq[l] == failed_seq) from = l;
     if (from < 0) for (int l = 31; l >= 0 && from < 0; l--) if (op.level_seq[l] != 0) from = l;
+    if (op.live_images[0]) {                        // a live frame is run again on ITS annotation pair into ITS u8 slot (the newest frame's replay comes last: the pyramid ends up naming its images)
+        p->scribble[0].ptr = op.live_images[0]; p->edited[0].ptr = op.live_images[1];
+        ctx->live_images[2] = op.live_images[2];
+    }
     int rc = from >= 0 ? estimate_levels(ctx, op.maxIterations, from, nullptr, op.batch_first, op.batch_n) : RTDD_OK;
+    ctx->live_images[2] = nullptr;
     if (rc == RTDD_OK && op.u8_copy)
         RTDD_HIP(ctx, hipMemcpy2DAsync(op.u8_copy, op.u8_copy_pitch, p->depth_u8.at(op.batch_first), p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
     return rc;

@@ -40,6 +40,66 @@ __global__ __launch_bounds__(256) void k_pyrdown_annotation(const uint8_t *__res
     }
 }
 
+// The whole annotation pyramid of an estimate in ONE launch (src/main.cpp:249-259: P - 1 GPUPyrDownAnnotation calls, then
+// GPUConvertToFloat on the coarsest level).  A coarse pixel x looks at the fine pixels 2x - 1 and 2x (above), so the level-l pixels
+// [a 2^l - (2^l - 1), a 2^l] and nothing else feed level-(l + k) pixel a ... : the footprints of the coarsest level's pixels tile
+// EVERY level disjointly.  A workgroup therefore owns kApB x kApB pixels of the coarsest level and, level by level, all the pixels of the
+// finer levels under them: it writes a level, __syncthreads(), and reads it back for the next one -- no other workgroup touches those
+// pixels, nothing is cleared (the coarse images accumulate over the frames exactly as with one launch per level), the scan order and
+// "last hit wins" are pyrDown's above.  Pixels of a fine level beyond the last coarsest pixel's footprint (the level sizes are floors)
+// belong to the workgroups of the next tile row / column: the grid is one tile larger than the coarsest level needs.
+// Five launches of ~7 us each (dependent, tiny) -> one: a live 1080p frame 1.18 -> 1.15 ms of GPU time (profiles/r05_live_timeline_*).
+constexpr int kApMaxLevels = 12, kApB = 2;
+struct AnnotationPyramid {
+    int levels;                                   // P
+    uint8_t *scribble[kApMaxLevels], *edited[kApMaxLevels];
+    size_t sp[kApMaxLevels], ep[kApMaxLevels];    // pitches
+    size_t zs[kApMaxLevels], ze[kApMaxLevels];    // byte strides between the images of a batch (blockIdx.z)
+    int rows[kApMaxLevels], cols[kApMaxLevels];
+    float *depth; size_t dp, zd;                  // the coarsest level's depth image (src/main.cpp:257-259)
+};
+
+__global__ __launch_bounds__(256) void k_annotation_pyramid(AnnotationPyramid A) {
+    const int P = A.levels, top = P - 1;
+    const size_t z = blockIdx.z;
+    for (int l = 1; l <= top; l++) {
+        const int f = 1 << (top - l);                                // level-l pixels per coarsest pixel, per direction
+        // this workgroup's pixels of level l: [X0 f - (f - 1), (X0 + kApB - 1) f] x the same in y, clipped to the level
+        const int xa = max((int)blockIdx.x * kApB * f - (f - 1), 0), xb = min(((int)blockIdx.x * kApB + kApB - 1) * f, A.cols[l] - 1);
+        const int ya = max((int)blockIdx.y * kApB * f - (f - 1), 0), yb = min(((int)blockIdx.y * kApB + kApB - 1) * f, A.rows[l] - 1);
+        const int w = xb - xa + 1, h = yb - ya + 1;
+        if (w > 0 && h > 0) {
+            const uint8_t *ps = A.scribble[l - 1] + z * A.zs[l - 1], *pe = A.edited[l - 1] + z * A.ze[l - 1];
+            uint8_t *cs = A.scribble[l] + z * A.zs[l], *ce = A.edited[l] + z * A.ze[l];
+            const int prows = A.rows[l - 1], pcols = A.cols[l - 1];
+            for (int i = threadIdx.x; i < w * h; i += 256) {
+                const int x = xa + i % w, y = ya + i / w;
+                int hit = -1;
+#pragma unroll
+                for (int jj = -1; jj <= 0; jj++)
+#pragma unroll
+                    for (int ii = -1; ii <= 0; ii++) {
+                        const int px = 2 * x + ii, py = 2 * y + jj;
+                        if (px >= 0 && py >= 0 && px < pcols && py < prows && ps[(size_t)py * A.sp[l - 1] + px] == 255)
+                            hit = pe[(size_t)py * A.ep[l - 1] + 3 * px];
+                    }
+                if (hit >= 0) {
+                    cs[(size_t)y * A.sp[l] + x] = 255;
+                    ce[(size_t)y * A.ep[l] + 3 * x] = (uint8_t)hit;
+                }
+            }
+        }
+        __syncthreads();                                             // the level is read back by this workgroup only
+    }
+    // convert (K5) on the coarsest level: the workgroup's kApB x kApB pixels
+    const int x = (int)blockIdx.x * kApB + (int)(threadIdx.x % kApB), y = (int)blockIdx.y * kApB + (int)(threadIdx.x / kApB);
+    if (threadIdx.x < kApB * kApB && A.depth && x < A.cols[top] && y < A.rows[top]) {
+        const uint8_t *m = A.scribble[top] + z * A.zs[top], *e = A.edited[top] + z * A.ze[top];
+        if (m[(size_t)y * A.sp[top] + x] == 255)
+            ((float *)((char *)A.depth + z * A.zd + (size_t)y * A.dp))[x] = (float)e[(size_t)y * A.ep[top] + 3 * x];
+    }
+}
+
 // paintImage (K7) -- src/GPUImageProcessing.cu:51-70.  Launched over the brush's bounding box only
 // (the reference launches the whole image and discards all but the brush).
 __global__ __launch_bounds__(256) void k_paint(int x0, int y0, int x1, int y1, int color, uint8_t *__restrict__ edited, size_t editedPitch,
@@ -65,6 +125,30 @@ int launch_pyrdown_annotation(rtdd_ctx *ctx, const uint8_t *ps, size_t psp, cons
                               uint8_t *cs, size_t csp, uint8_t *ce, size_t cep, int crows, int ccols, int images, size_t zPs, size_t zPe, size_t zCs, size_t zCe) {
     hipLaunchKernelGGL(k_pyrdown_annotation, grid64x4(crows, ccols, images), dim3(256), 0, ctx->stream, ps, psp, pe, pep, prows, pcols, cs, csp, ce, cep, crows, ccols, zPs, zPe, zCs, zCe);
     RTDD_LAUNCH_CHECK(ctx, "k_pyrdown_annotation");
+    return RTDD_OK;
+}
+
+int launch_annotation_pyramid(rtdd_ctx *ctx, int levels, uint8_t *const *scribble, const size_t *sp, const size_t *zs, uint8_t *const *edited, const size_t *ep, const size_t *ze,
+                              const int *rows, const int *cols, float *depth, size_t dp, size_t zd, int images) {
+    if (levels < 1 || levels > kApMaxLevels) return fail(ctx, RTDD_ERR_INVALID, "annotation pyramid: too many levels");
+    AnnotationPyramid A{};
+    A.levels = levels;
+    for (int l = 0; l < levels; l++) { A.scribble[l] = scribble[l]; A.edited[l] = edited[l]; A.sp[l] = sp[l]; A.ep[l] = ep[l]; A.zs[l] = zs[l]; A.ze[l] = ze[l]; A.rows[l] = rows[l]; A.cols[l] = cols[l]; }
+    A.depth = depth; A.dp = dp; A.zd = zd;
+    // tiles of kApB x kApB coarsest pixels, one tile more than the coarsest level needs in either direction: the finer levels' last
+    // pixels (their sizes are floors) lie under coarsest pixels that do not exist
+    const int top = levels - 1;
+    int gx = 1, gy = 1;
+    for (int l = 1; l <= top; l++) {                                 // the largest tile index any level's last pixel falls into
+        const int f = 1 << (top - l);
+        const int tx = (cols[l] - 1 + f - 1) / f / kApB + 1, ty = (rows[l] - 1 + f - 1) / f / kApB + 1;
+        if (cols[l] > 0 && tx > gx) gx = tx;
+        if (rows[l] > 0 && ty > gy) gy = ty;
+    }
+    if (top == 0) { gx = (cols[0] + kApB - 1) / kApB; gy = (rows[0] + kApB - 1) / kApB; }
+    if (gx < 1 || gy < 1) return RTDD_OK;
+    hipLaunchKernelGGL(k_annotation_pyramid, dim3(gx, gy, images), dim3(256), 0, ctx->stream, A);
+    RTDD_LAUNCH_CHECK(ctx, "k_annotation_pyramid");
     return RTDD_OK;
 }
 

@@ -97,6 +97,7 @@ struct PendingOp {
     int maxIterations = 0;
     int level_seq[32] = {};               // sequence number of level l's solve (0: the level is empty)
     int batch_first = 0, batch_n = 1;     // the images of the context's batched pyramid the estimate covers
+    void *live_images[3] = {nullptr, nullptr, nullptr};   // a live frame: the level-0 scribble / edited pair it ran on and the u8 staging slot its map is also written to (cascade_api.cpp)
     uint8_t *u8_copy = nullptr; size_t u8_copy_pitch = 0;   // live mode: the u8 map is copied here (device) behind the estimate
     unsigned long long id = 0;            // position in the context's call order (live mode drops the confirmed prefix of the log)
     // kDefocus / kDesaturate / kHaze: a depth effect queued BEHIND an unconfirmed solve (it may have read that solve's input instead of
@@ -120,6 +121,7 @@ struct rtdd_ctx {
     std::vector<rtdd::Level> levels;
     int alloc_images = 1;               // how many images' planes the NEXT rtdd_allocate makes every level hold (rtdd_pyramid_create_batch; one shot)
     int levels_images = 1;              // ... and how many the levels hold now
+    void *live_images[3] = {nullptr, nullptr, nullptr};   // set by rtdd_live_submit around its estimate (logged with it)
     rtdd::Batch batch;                  // the images the launches of the call in progress cover (cascade_api.cpp); n = 1, first = 0 otherwise
     int maxLevel = -1;
     bool weights_loaded = false;
@@ -136,6 +138,8 @@ struct rtdd_ctx {
     int deferred_plane = -1;
     uint8_t *finish_u8 = nullptr;
     size_t finish_u8_pitch = 0;
+    uint8_t *finish_u8b = nullptr;       // ... and a second copy of that map (a live frame's staging slot)
+    size_t finish_u8b_pitch = 0;
     int defocus_last_path = 0;           // RTDD_OPT_DEFOCUS_LAST_PATH: what the most recent rtdd_simulate_defocus launched (1 table, 2 tile kernel)
     bool defocus_table_sticky = false;   // a tile-kernel defocus met out-of-range depths (seen at a synchronisation): automatic choice = the table from then on
     int flag_epoch = 0;             // the per-tile flags of the persistent kernels only ever grow: base value of the next persistent launch (api.cpp)
@@ -243,6 +247,9 @@ int launch_convert(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, float *ds
 int launch_pyrdown_annotation(rtdd_ctx *ctx, const uint8_t *ps, size_t psp, const uint8_t *pe, size_t pep, int prows, int pcols,
                               uint8_t *cs, size_t csp, uint8_t *ce, size_t cep, int crows, int ccols,
                               int images = 1, size_t zPs = 0, size_t zPe = 0, size_t zCs = 0, size_t zCe = 0);
+// the annotation pyramid of an estimate (levels 1 .. levels-1 from level 0) and the coarsest level's injection, one launch (image_kernels.hip)
+int launch_annotation_pyramid(rtdd_ctx *ctx, int levels, uint8_t *const *scribble, const size_t *sp, const size_t *zs, uint8_t *const *edited, const size_t *ep, const size_t *ze,
+                              const int *rows, const int *cols, float *depth, size_t dp, size_t zd, int images);
 int launch_paint(rtdd_ctx *ctx, int x, int y, int color, int radius, uint8_t *edited, size_t editedPitch,
                  uint8_t *scribble, size_t scribblePitch, int rows, int cols);
 

@@ -276,7 +276,7 @@ __device__ __forceinline__ uint8_t round_u8(float v) {
 
 __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
                                                 int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq,
-                                                size_t zPlane, size_t zDepth, size_t zU8) {
+                                                size_t zPlane, size_t zDepth, size_t zU8, uint8_t *__restrict__ u8b, size_t u8bPitch) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + wave_id();
     if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0)) return;
@@ -285,12 +285,13 @@ __global__ __launch_bounds__(256) void k_finish(const float *__restrict__ X, int
     const float v = X[(size_t)y * ip + x];
     ((float *)((char *)depth + (size_t)y * depthPitch))[x] = v;
     if (u8) u8[(size_t)y * u8Pitch + x] = round_u8(v);
+    if (u8b) u8b[(size_t)y * u8bPitch + x] = round_u8(v);          // (a live frame's staging slot: the same map once more, no copy kernel)
 }
 
 // four pixels per thread when the caller's rows are 16-byte aligned (a group past the end of the row: pixel by pixel)
 __global__ __launch_bounds__(256) void k_finish4(const float *__restrict__ X, int ip, float *__restrict__ depth, size_t depthPitch,
                                                  int rows, int cols, uint8_t *__restrict__ u8, size_t u8Pitch, int *sync_words, int seq,
-                                                 size_t zPlane, size_t zDepth, size_t zU8) {
+                                                 size_t zPlane, size_t zDepth, size_t zU8, uint8_t *__restrict__ u8b, size_t u8bPitch) {
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
     const int y = blockIdx.y * 4 + wave_id();
     if (solve_is_dead(sync_words, seq, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0)) return;
@@ -301,9 +302,13 @@ __global__ __launch_bounds__(256) void k_finish4(const float *__restrict__ X, in
     const float t[4] = {v.x, v.y, v.z, v.w};
     if (x0 + 3 < cols) *(float4 *)o = v;
     else { for (int i = 0; i < 4; i++) if (x0 + i < cols) o[i] = t[i]; }
-    if (u8) {
-        uint8_t *q = u8 + (size_t)y * u8Pitch + x0;
-        if (x0 + 3 < cols && u8Pitch % 4 == 0 && (uintptr_t)u8 % 4 == 0)
+    uint8_t *targets[2] = {u8, u8b};              // (u8b: a live frame's staging slot -- the same map once more, no copy kernel)
+    const size_t pitches[2] = {u8Pitch, u8bPitch};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (!targets[k]) continue;
+        uint8_t *q = targets[k] + (size_t)y * pitches[k] + x0;
+        if (x0 + 3 < cols && pitches[k] % 4 == 0 && (uintptr_t)targets[k] % 4 == 0)
             *(uint32_t *)q = (uint32_t)round_u8(t[0]) | ((uint32_t)round_u8(t[1]) << 8) | ((uint32_t)round_u8(t[2]) << 16) | ((uint32_t)round_u8(t[3]) << 24);
         else { for (int i = 0; i < 4; i++) if (x0 + i < cols) q[i] = round_u8(t[i]); }
     }
@@ -461,9 +466,9 @@ int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float
     const Batch &B = ctx->batch;
     const size_t zP = L.elems * sizeof(float);
     if ((uintptr_t)depth % 16 == 0 && depthPitch % 16 == 0 && B.depth % 16 == 0 && B.u8 % 4 == 0)
-        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq, zP, B.depth, B.u8);
+        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq, zP, B.depth, B.u8, ctx->finish_u8b, ctx->finish_u8b_pitch);
     else
-        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq, zP, B.depth, B.u8);
+        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq, zP, B.depth, B.u8, ctx->finish_u8b, ctx->finish_u8b_pitch);
     ctx->persistent_used = true;                  // (the guard may have recorded a failed solve: the next synchronising call looks)
     RTDD_LAUNCH_CHECK(ctx, "k_finish");
     return RTDD_OK;
