@@ -80,7 +80,7 @@ def jacobi_valu_ops():
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import isa_count
             c = isa_count.sweep_pair()
-            _valu_ops_source.update(v=c["per_pixel_sweep"], src=f"counted now in the built sweep_blocked.o: {c['valu']} VALU instructions per sweep pair x 12 pixels (scripts/isa_count.py)")
+            _valu_ops_source.update(v=c["per_pixel_sweep"], src=f"counted now in the disassembly of the built kernel: {c['valu']} VALU instructions per sweep pair x 12 pixels (scripts/isa_count.py)")
         except Exception as e:                      # no llvm-objdump / no object on this box
             _valu_ops_source.update(v=VALU_OPS["jacobi"], src=f"recorded constant (the built object could not be disassembled here: {type(e).__name__})")
     return _valu_ops_source["v"], _valu_ops_source["src"]

@@ -82,11 +82,36 @@ class Profile(C.Structure):
 
 
 def build(force=False):
-    """Compile librtdd.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile librtdd.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    The persistent kernels' hand-off reads its halo with sc1 loads and NO agent-scope acquire; that is only right if the compiler put
+    nothing between those loads and the wait behind them (csrc/sweep_common.hpp).  scripts/isa_check.py checks exactly that on the
+    objects just built -- every path, spills included.  If the check fails, or cannot run (no llvm-objdump), the two kernels are
+    rebuilt with -DRTDD_EXCHANGE_ACQUIRE=1 (one acquire per exchange, plain loads: ~0.8 us per exchange slower, no such dependence) and
+    a warning says so: a compiler bump can cost speed, never silently a wrong depth map."""
+    import sys
     args = ["make", "-C", _CSRC, "-j4"]
     if force:
         args.append("-B")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    stamp = os.path.join(_CSRC, ".exchange_variant")
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "scripts"))
+        import isa_check
+        isa_check.check_build(_CSRC)
+        variant = "sc1"
+    except Exception as e:      # AssertionError (the check failed), FileNotFoundError (no objdump), ...
+        already = os.path.exists(stamp) and open(stamp).read().strip() == "acquire" and os.path.getmtime(stamp) >= os.path.getmtime(os.path.join(_CSRC, "sweep_blocked.o"))
+        if not already:
+            print(f"[rtdd build] the structural check of the no-acquire hand-off did not pass ({type(e).__name__}: {e}): rebuilding the persistent "
+                  "kernels with -DRTDD_EXCHANGE_ACQUIRE=1", file=sys.stderr)
+            for f in ("sweep_blocked.o", "rbgs_blocked.o"):
+                if os.path.exists(os.path.join(_CSRC, f)):
+                    os.remove(os.path.join(_CSRC, f))
+            subprocess.check_call(["make", "-C", _CSRC, "-j4", "CXXFLAGS_EXTRA=-DRTDD_EXCHANGE_ACQUIRE=1"], stdout=subprocess.DEVNULL)
+        variant = "acquire"
+    with open(stamp, "w") as f:
+        f.write(variant + "\n")
     return _SO
 
 

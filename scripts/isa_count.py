@@ -31,10 +31,10 @@ def disassemble(obj):
         local = os.path.join(tmp, "x.o")
         shutil.copy(obj, local)
         subprocess.check_call([OBJDUMP, "--offloading", local], stdout=subprocess.DEVNULL, cwd=tmp)
-        dev = glob.glob(local + ".*gfx950*")
+        dev = sorted(glob.glob(local + ".*gfx950*"))
         if not dev:
             raise RuntimeError("no gfx950 code object in " + obj)
-        text = subprocess.check_output([OBJDUMP, "-d", dev[0]], text=True)
+        text = "\n".join(subprocess.check_output([OBJDUMP, "-d", d], text=True) for d in dev)      # (a shared library holds one code object per translation unit)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     funcs, cur, base = {}, None, 0
@@ -76,7 +76,10 @@ def fallthrough_loops(instrs):
 
 def sweep_pair(obj=None, kernel=HOT_KERNEL):
     """Instruction census of the fast sweep pair: {'valu', 'salu', 'lds', 'per_pixel_sweep', 'by_mnemonic'}."""
-    obj = obj or os.path.join(ROOT, "realtimedepthdiffusion_amd", "csrc", "sweep_blocked.o")
+    if obj is None:                                # the object where it exists (a build tree), else the library itself (what travels to a GPU box)
+        obj = os.path.join(ROOT, "realtimedepthdiffusion_amd", "csrc", "sweep_blocked.o")
+        if not os.path.exists(obj):
+            obj = os.path.join(ROOT, "realtimedepthdiffusion_amd", "librtdd.so")
     funcs = disassemble(obj)
     names = [n for n in funcs if kernel in n]
     if len(names) != 1:

@@ -81,48 +81,41 @@ def _vgprs(text):
     return out
 
 
-def _check_sc1_loads(asm, kernel, min_loads):
-    """The persistent hand-off reads its halo with `global_load_dwordx4 ... sc1` straight into the tile's registers and has NO
-    agent-scope acquire (csrc/persist_sync.hpp, exchange_wait<false>): the loaded registers are only valid behind the one
-    `s_waitcnt vmcnt(0)` that follows the loads, and the loads sit inside a divergent `if`.  A register copy the compiler placed between
-    a load and that wait (a phi at the join of the `if`) would silently read stale bits -- a wrong depth map, not an error.  So: in every
-    persistent instantiation, between each sc1 load and the next s_waitcnt vmcnt(0), no instruction may name the load's destination."""
-    funcs = re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", asm)
-    loads = 0
-    kernels = 0
-    for f in funcs:
-        head = f.split("\n", 1)[0]
-        if kernel not in head:
-            continue
-        lines = [l.split("//")[0].rstrip() for l in f.split("\n")[1:] if l.strip() and not l.lstrip().startswith(("//", ";"))]
-        instrs = [l.strip() for l in lines if re.match(r"\s+[a-z]", l)]
-        here = 0
-        for i, ins in enumerate(instrs):
-            if not (ins.startswith("global_load_dwordx4") and ins.rstrip().endswith("sc1")):
-                continue
-            dst = _vgprs(ins.split(None, 1)[1].split(",")[0])
-            assert len(dst) == 4, ins
-            for later in instrs[i + 1:]:
-                if later.startswith("s_waitcnt") and "vmcnt(0)" in later:
-                    break
-                if later.startswith(("s_endpgm", "s_branch")):
-                    raise AssertionError(f"{head}: no s_waitcnt vmcnt(0) behind '{ins}'")
-                ops = later.split(None, 1)[1] if " " in later else ""
-                assert not (_vgprs(ops) & dst), f"{head}: '{later}' touches the registers of '{ins}' before the wait"
-            here += 1
-        if here:
-            kernels += 1
-        loads += here
-    assert loads >= min_loads and kernels >= 1, f"only {loads} sc1 loads in {kernels} instantiations of {kernel}: was the hand-off rewritten?"
-    return kernels, loads
-
-
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="ROCm LLVM tools not present")
-def test_sc1_halo_loads_are_not_touched_before_their_wait(tmp_path):
-    kernels, loads = _check_sc1_loads(_disassembly(tmp_path), "k_sweep_blocked", 2 * 2 * 13)     # 13 tiles x 2 contractions, >= 2 loads each
-    assert kernels == 26, kernels                                                                   # every PERSIST instantiation (the others have no sc1 load)
-    kernels, loads = _check_sc1_loads(_disassembly(tmp_path, "rbgs_blocked.o"), "k_rbgs_blocked", 4 * 4)
-    assert kernels >= 4, kernels
+def test_sc1_halo_loads_are_not_touched_before_their_wait():
+    """scripts/isa_check.py (what realtimedepthdiffusion_amd.build() itself runs after every build, falling back to the acquire hand-off
+    when it fails): on every path from an sc1 halo load -- branch targets followed -- nothing names the load's registers (a copy, a
+    scratch spill, an AGPR move) before an s_waitcnt vmcnt(0).  26 persistent instantiations of k_sweep_blocked, 8 of k_rbgs_blocked."""
+    import sys
+    rt.build()
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import isa_check
+    got = isa_check.check_build()
+    assert got["k_sweep_blocked"][0] == 26 and got["k_rbgs_blocked"][0] >= 4, got
+    assert open(os.path.join(CSRC, ".exchange_variant")).read().strip() == "sc1"      # the build kept the fast form because this check passed
+
+
+def test_the_structural_check_catches_a_use_before_the_wait(tmp_path):
+    """... and it is a check: a listing in which a halo register is copied before the wait, on a branch target only, fails it."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import isa_check
+    import isa_count
+    listing = {"k_sweep_blocked_fake": [
+        (0, "s_and_saveexec_b64 s[0:1], vcc", None), (4, "s_cbranch_execz 2", 16),
+        (8, "global_load_dwordx4 v[4:7], v[0:1], off sc1", None), (12, "s_nop 0", None),
+        (16, "s_or_b64 exec, exec, s[0:1]", None), (20, "s_cbranch_vccnz 3", 36),
+        (24, "s_waitcnt vmcnt(0)", None), (28, "v_mov_b32_e32 v9, v5", None), (32, "s_endpgm", None),
+        (36, "v_mov_b32_e32 v9, v5", None), (40, "s_waitcnt vmcnt(0)", None), (44, "s_endpgm", None)]}
+    orig = isa_count.disassemble
+    isa_count.disassemble = lambda obj: listing
+    try:
+        with pytest.raises(AssertionError, match="touches the registers"):
+            isa_check.check_object("unused", "k_sweep_blocked")
+        listing["k_sweep_blocked_fake"][9] = (36, "v_mov_b32_e32 v9, v3", None)          # the branch target no longer names a loaded register
+        assert isa_check.check_object("unused", "k_sweep_blocked") == (1, 1)
+    finally:
+        isa_count.disassemble = orig
 
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="ROCm LLVM tools not present")
