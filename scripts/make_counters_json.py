@@ -18,7 +18,18 @@ rnd, wl = sys.argv[1], sys.argv[2]
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 d = f"gpurun_out/prof_{rnd}_{wl}"
 SIMDS, CLOCK = 256 * 4, 2.4e9
-VALU_OPS = 15.1                     # bench.py VALU_OPS["jacobi"]: static ISA count per useful pixel-sweep
+# VALU operations per useful pixel-sweep: COUNTED in the built kernel (scripts/isa_count.py) and required to equal the constant bench.py
+# falls back to -- a record made from a build whose loop no longer is what the roofline prices is refused
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import isa_count
+_count = isa_count.sweep_pair()
+VALU_OPS = _count["per_pixel_sweep"]
+import importlib.util
+_spec = importlib.util.spec_from_file_location("bench_consts", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+_bench = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_bench)
+if abs(VALU_OPS - _bench.VALU_OPS["jacobi"]) > 0.05:
+    sys.exit(f"make_counters_json: the built kernel issues {VALU_OPS:.2f} VALU operations per pixel-sweep ({_count['valu']} per sweep pair), bench.py prices {_bench.VALU_OPS['jacobi']}: update bench.py VALU_OPS first")
 VALU_PEAK = 256 * 4 * 32 * 2.4e9
 
 
@@ -110,6 +121,7 @@ summary = {"workload": wl, "round": rnd,
                         "counters": "rocprofv3 --kernel-trace --pmc <one group per pass: FETCH_SIZE | WRITE_SIZE | SQ group 1 | SQ group 2> -- python3 bench.py --steps 3 --warmup 1 ... (scripts/profile_round.sh)"},
            "window": f"kernel statistics are over the last {STEPS} solves of the clean trace (= the timed steps; a solve starts at its k_prepare launch); the process ran {n_solves_all} solves in all "
                      "(clock ramp + warm-up + timed)",
+           "valu_ops_per_pixel_sweep": VALU_OPS, "valu_ops_source": f"{_count['valu']} VALU instructions on the fall-through path of the sweep-pair loop / 24 (scripts/isa_count.py, counted in the build that was profiled)",
            "corrections": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE x1, KB -> bytes x1024; VALU issue fraction = SQ_INSTS_VALU x 2 cycles / (duration x 1024 SIMD-32 x 2.4 GHz)",
            "bench_line_unprofiled": {k: bench.get("bench_unprofiled.json", {}).get(k) for k in ("value", "ms_per_step", "roofline")},
            "ms_per_step_under_kernel_trace": bench.get("trace.json", {}).get("ms_per_step"),
@@ -143,7 +155,7 @@ summary["solves_counted"] = {"clean trace": n_solves_all, "fetch pass": n_fetch,
 summary["hbm_bytes_per_solve_all_kernels_corrected"] = all_bytes
 summary["kernel_ms_per_solve_clean_trace"] = sum(k["total_ms"] for k in kernels.values()) / STEPS
 cfg = bench.get("trace.json", {}).get("config", {})      # what the profiled command launched: bench.py attaches these counters only to a run of the same kernel
-# the roofline fraction recomputed from THIS profile (Jacobi workloads): useful pixel-sweeps per launch x 15.1 / mean launch duration / peak
+# the roofline fraction recomputed from THIS profile (Jacobi workloads): useful pixel-sweeps per launch x the counted VALU operations per pixel-sweep / mean launch duration / peak
 line = bench.get("bench_unprofiled.json", {})
 try:
     rows_, cols_ = {"1080p": (1080, 1920), "4k": (2160, 3840), "8k": (4320, 7680)}[wl.split("_")[0]]

@@ -2,7 +2,7 @@
 # their own (as MI355X_MICROARCH.md prescribes: --pmc only ever beside --kernel-trace): FETCH_SIZE, WRITE_SIZE, two SQ passes.
 # usage: ROUND=r02 WL=1080p_jacobi1000 bash scripts/profile_round.sh     -> gpurun_out/prof_${ROUND}_$WL/ ; then scripts/make_counters_json.py
 export TMPDIR=/tmp
-R=${ROUND:-r04}; WL=${WL:-1080p_jacobi1000}
+R=${ROUND:-r05}; WL=${WL:-1080p_jacobi1000}
 OUT=gpurun_out/prof_${R}_$WL; mkdir -p $OUT
 FULL="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-estimate --workload $WL $EXTRA"
 SHORT="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-estimate --workload $WL $EXTRA"
