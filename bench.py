@@ -495,6 +495,9 @@ def main():
         if spec.startswith("batch"):
             b_, spec = spec[5:].split("_", 1)
             extra["batch"] = int(b_)
+        if spec.endswith("_estimate"):          # batchB_ROWSxCOLSxITERS_estimate: the batch as whole estimates (ITERS sweeps at the coarsest level)
+            spec = spec[:-len("_estimate")]
+            extra["estimate"] = True
         r_, c_, i_ = (int(v) for v in spec.split("x"))
         WORKLOADS[args.workload] = dict(rows=r_, cols=c_, iters=i_, **extra)
     w = WORKLOADS[args.workload]
@@ -506,6 +509,9 @@ def main():
     my_images = shard.images_for_rank(batch, world, rank) if batch else [rank]
     dev = f"cuda:{local}"
     executed = []                           # iterations actually run per step (residual-stopped methods), and the residual reached
+    import math
+    levels_ = int(math.log2(max(min(cols, rows) // 45, 1)) + 1)          # src/main.cpp:95
+    est_px_iter = sum((rows >> l) * (cols >> l) * int(iters / 2 ** (levels_ - 1 - l)) for l in range(levels_))     # pixel-sweeps of one whole estimate
 
     if dry:
         def step(i):
@@ -529,13 +535,12 @@ def main():
         elif share_gpu and world > 1: ctx.set_option(rt.OPT_PERSISTENT, 0)      # ranks sharing one GPU are not co-resident: no persistent launches
         if w.get("estimate"):
             # this rank's images as ONE batched pyramid; a step = the whole estimate of every one of them (warm-started: the sweep counts are fixed)
-            levels_ = ctx.pyramid_create_batch(rows, cols, len(problems))
+            assert ctx.pyramid_create_batch(rows, cols, len(problems)) == levels_
             for b, p in enumerate(problems):
                 ctx.pyramid_select(b)
                 ctx.pyramid_set_image(rt.device_image(np.repeat(p["gray"][..., None], 3, 2), dev))
                 ctx.pyramid_set_annotation(rt.device_image(np.where(p["mask"] == 255, p["edited"][..., 0], 32).astype(np.uint8), dev))
             masks = grays = []; depths = [[] for _ in range(args.steps + args.warmup)]
-            est_px_iter = sum((rows >> l) * (cols >> l) * int(iters / 2 ** (levels_ - 1 - l)) for l in range(levels_))
         else:
             masks = [rt.device_image(p["mask"], dev) for p in problems]; grays = [rt.device_image(p["gray"], dev) for p in problems]
             # one pristine initial-depth image per image and step, uploaded before the clock starts
@@ -594,7 +599,7 @@ def main():
     else:
         px_iter_per_image = rows * cols * iters
     if w.get("estimate"):
-        px_iter_per_image = 0 if dry else est_px_iter
+        px_iter_per_image = est_px_iter
     algo_bytes = ALGO_BYTES[method]
     agg_dev = dev if tbackend == "nccl" else "cpu"
     units, elapsed, thr = shard.aggregate(args.steps * len(my_images) * px_iter_per_image, elapsed, dist, agg_dev, tgroup)   # SUM of units, MAX of time

@@ -6,7 +6,8 @@ time out: since round 4 a time-out is healed silently, so RTDD_OPT_TIMEOUT_HEALS
 phase (round 4): K pairs of pipelined live frames (rtdd_live_submit, two in flight, uploads / downloads on their own streams) from a
 cold start, each map against the oracle cascade's first / second estimate.  Fourth phase: H fresh contexts, each made to time out (a
 hand-off flag withheld) in front of three queued solves and an effect, each healed to the oracle's bits.
-usage: soak.py [N solves] [M estimates] [K live pairs] [H healed contexts]"""
+Fifth phase (round 5): batches of six cold estimates in the same launches (rtdd_estimate_depth_batch), each against the oracle cascade.
+usage: soak.py [N solves] [M estimates] [K live pairs] [H healed contexts] [batches]"""
 import sys, os, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -118,3 +119,25 @@ for i in range(k_heal):
     c.close()
     if i % 50 == 49: print(i + 1, "healed contexts ok, %.1f s" % (time.time() - t), flush=True)
 print("soak ok:", k_heal, "contexts, each healed one timed-out persistent launch: three queued solves + haze == the oracle's bits")
+
+# ---- fifth phase (round 5): batched estimates under the same load -- B cold 1080p estimates in the same launches (blockIdx.z = image,
+# one flag set per image and tile in the persistent levels), every image's finest level == the oracle cascade's first estimate
+k_batch = int(sys.argv[5]) if len(sys.argv) > 5 else 200
+B = 6
+c = rt.Context(0); c.set_stream(main.cuda_stream); c.GPULoadWeights(0.4); c.pyramid_create_batch(rows, cols, B)
+t = time.time()
+for i in range(k_batch):
+    for b in range(B):
+        c.pyramid_select(b); c.pyramid_set_image(img); c.pyramid_set_annotation(an)      # cold
+    if i % 3 == 0:
+        with torch.cuda.stream(side):
+            noise.mul_(1.0001)
+    c.estimate_depth_batch(1000)
+    c.synchronize()
+    for b in (i % B, (i + 3) % B):                        # two of the six per round (hashing 8 MB on the host is what this loop costs)
+        c.pyramid_select(b)
+        assert hashlib.sha1(c.pyramid_download(rt.IMG_DEPTH, 0).tobytes()).hexdigest() == ref_e, (i, b, "a batched estimate differs from the oracle cascade")
+    if i % 100 == 99: print(i + 1, "batches ok, %.1f s" % (time.time() - t), flush=True)
+assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 0, "a persistent launch timed out (and was healed)"
+print("soak ok:", k_batch, "batches of", B, "cold estimates, every checked image == the oracle cascade's bits")
+c.close()

@@ -48,6 +48,17 @@ def test_eight_ranks_dry_run_both_scalings():
     assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["images_per_step"] == 64 and d["config"]["images_this_rank"] == 8
 
 
+def test_batched_estimates_shard_like_the_batch_of_solves():
+    """`batch64_1080p_estimate`: the same 64 images as whole estimates, image i on rank i % N, a rank's images as one
+    batched pyramid; units = the pixel-sweeps of the five levels of every image."""
+    per_estimate = sum((1080 >> l) * (1920 >> l) * int(1000 / 2 ** (4 - l)) for l in range(5))
+    for n, mine in ((2, 32), (8, 8)):
+        d = _run(["--gpus", str(n), "--dry-run", "--steps", "2", "--warmup", "1", "--workload", "batch64_1080p_estimate"], timeout=600)
+        assert d["n_gpus"] == n and d["scaling"] == "strong" and d["config"]["images_per_step"] == 64 and d["config"]["images_this_rank"] == mine
+        assert "estimates" in d["config"]["workload"]
+        assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * 2 - 2 * 64 * per_estimate) < 1e-3 * 2 * 64 * per_estimate
+
+
 def test_gpus_flag_must_match_world_size():
     e = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run"], env=e, capture_output=True, text=True, timeout=120)
@@ -94,3 +105,11 @@ def test_config4_batch64_on_one_gpu_verified():
     assert "configs[3]" in d["config"]["workload"]
     assert d["verified"]["images_differing_all_ranks"] == 0 and len(d["verified"]["rank0_images"]) == 64
     assert d["config"]["persistent"] == 1 and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_run_their_share_of_a_batch_as_batched_estimates():
+    """Two ranks through the launcher, each its three images of a batch of six as ONE batched pyramid (rtdd_estimate_depth_batch)."""
+    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", "batch6_540x960x400_estimate"], env={"RTDD_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["images_per_step"] == 6 and d["config"]["images_this_rank"] == 3
+    assert d["value"] > 0 and d["estimates_per_s"] > 0

@@ -352,3 +352,41 @@ def test_an_upload_into_the_coarsest_depth_image_makes_the_next_estimate_inject_
         ref.estimate(200); c.estimate_depth(200); c.synchronize()
         for l in range(levels):
             assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, l), ref.depth[l], f"level {l} after an upload into the coarsest depth image")
+
+
+def test_a_healed_older_live_frame_runs_on_its_own_annotation(oracle, lut):
+    """Two live frames in flight with DIFFERENT annotations (the second adds a stroke), the first frame's persistent launch times out:
+    both are run again behind the caller's back.  Round 4's limit was that the healed older frame could see the newer frame's annotation;
+    since round 5 every frame is replayed on the annotation pair it uploaded (include/rtdd.h): the older frame's map does not know the
+    new stroke, the newer frame's map carries it, both honour their own labels, and the device ends up naming the newer frame's images.
+    (The COARSE annotation levels only ever accumulate -- they may hold the new stroke during the older frame's replay: the documented
+    remaining limit, which is why this test states properties and not the oracle's bits; with equal annotations the bits are the
+    oracle's: test_live_frames_pipelined_match_the_oracle[True].)"""
+    rows, cols = 540, 960
+    bgr, ann = _bgr(rows, cols, 131)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=4)
+    s1, e1 = ref.scribble[0].copy(), ref.edited[0].copy()
+    s2, e2 = s1.copy(), e1.copy()
+    free = np.argwhere(s1[100:400, 100:800] != 255)
+    y0, x0 = (free[len(free) // 2] + 100).tolist()
+    oracle.paint_image(x0, y0, 64, 21, e2, s2)                          # frame 2's new stroke (label 64)
+    new = (s2 == 255) & (s1 != 255)
+    assert new.sum() > 50
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        c.pyramid_create(rows, cols)
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann)); c.synchronize()
+        h = [rt.host_image((rows, cols)), rt.host_image((rows, cols, 3)), rt.host_image((rows, cols)), rt.host_image((rows, cols, 3))]
+        out = [rt.host_image((rows, cols)) for _ in range(2)]
+        h[0].a[...] = s1; h[1].a[...] = e1; h[2].a[...] = s2; h[3].a[...] = e2
+        c.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 1)
+        c.live_submit(h[0].a, h[1].a, out[0].a, 1000)
+        c.live_submit(h[2].a, h[3].a, out[1].a, 1000)
+        c.live_wait(); c.live_wait(); c.synchronize()
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1
+        m1, m2 = out[0].a.copy(), out[1].a.copy()
+        assert np.array_equal(m1[s1 == 255], e1[..., 0][s1 == 255]) and np.array_equal(m2[s2 == 255], e2[..., 0][s2 == 255]), "each frame honours its own labels"
+        assert (m2[new] == 64).all() and (m1[new] != 64).mean() > 0.9, "the older frame was replayed on ITS annotation: it does not know the new stroke"
+        assert np.array_equal(c.pyramid_download(rt.IMG_SCRIBBLE, 0), s2) and np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), m2)
+        for x in h + out:
+            x.free()
