@@ -3,7 +3,7 @@
 // main.cpp is an OpenCV HighGUI event loop over cv::cuda::GpuMat and cannot be built on a ROCm box
 // (SURVEY.md section 0); this program makes the SAME sequence of calls through librtdd.so's C ABI
 // with plain files instead of windows:
-//     -i image.ppm  -a annotation.pgm      (main.cpp:81-90; binary PPM/PGM instead of JPEG/PNG)
+//     -i image.jpg  -a annotation.png      (main.cpp:81-90; JPEG (jpeg_reader.hpp: libjpeg's default decode, restated), 8-bit PNG, binary PPM / PGM)
 //     key 'd'  -> one depth estimate        (main.cpp:232-295)  -> <out>DepthMap.pgm     (main.cpp:306-310)
 //     key 's'  -> also the annotated image   (main.cpp:298-303)  -> <out>AnnotatedImage.ppm: the image with the scribbles painted in
 //     key 'b'/'g'/'h' -> --effect defocus|desaturation|haze     -> <out>ArtisticEffect.ppm (main.cpp:190-230, 312-316)
@@ -26,6 +26,7 @@
 #include <zlib.h>
 
 #include "rtdd.h"
+#include "jpeg_reader.hpp"
 
 struct Pnm { int w = 0, h = 0, ch = 0; std::vector<unsigned char> px; };
 
@@ -147,7 +148,17 @@ static bool write_png(const std::string &path, int w, int h, int ch, const unsig
 }
 
 static bool ends_with(const std::string &s, const char *suffix) { const size_t n = std::strlen(suffix); return s.size() >= n && !s.compare(s.size() - n, n, suffix); }
-static bool read_image(const std::string &path, Pnm &im) { return ends_with(path, ".png") ? read_png(path, im) : read_pnm(path, im); }
+static bool read_jpeg(const std::string &path, Pnm &im) {           // (cv::imread's decode, restated: harness/jpeg_reader.hpp)
+    std::string why;
+    if (rtdd_jpeg::read_file(path, im.w, im.h, im.ch, im.px, &why)) return true;
+    std::fprintf(stderr, "%s: %s\n", path.c_str(), why.c_str());
+    return false;
+}
+static bool read_image(const std::string &path, Pnm &im) {
+    if (ends_with(path, ".png")) return read_png(path, im);
+    if (ends_with(path, ".jpg") || ends_with(path, ".jpeg") || ends_with(path, ".JPG") || ends_with(path, ".JPEG")) return read_jpeg(path, im);
+    return read_pnm(path, im);
+}
 static bool write_image(const std::string &path, int w, int h, int ch, const unsigned char *px) { return ends_with(path, ".png") ? write_png(path, w, h, ch, px) : write_pnm(path, w, h, ch, px); }
 
 #define CK(call) do { int rc_ = (call); if (rc_ != RTDD_OK) { std::printf("%s: %s (%s)\n", #call, rtdd_status_string(rc_), rtdd_last_error(ctx)); return rc_; } } while (0)
@@ -324,10 +335,10 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
 }
 
 int main(int argc, const char *argv[]) {
-    if (argc == 1) { std::printf("Usage: rtdd_harness -i image.ppm [-a annotation.pgm] [-o prefix] [--effect defocus|desaturation|haze] [--iters N] [--refine sor|mg|auto [--tolerance T]]\n"
+    if (argc == 1) { std::printf("Usage: rtdd_harness -i image.(jpg|png|ppm) [-a annotation.(png|pgm)] [-o prefix] [--effect defocus|desaturation|haze] [--iters N] [--refine sor|mg|auto [--tolerance T]]\n"
                                  "                    [--paint x,y,label,radius]... [--live N [--paint-at frame:x,y,label,radius]...] [--devices D --batch B [--sequential] [--write-all]] [--png]\n"
-                                 "       rtdd_harness --convert in.(png|ppm|pgm) out.(png|ppm|pgm)       (8-bit PNG <-> PNM, no GPU)\n"); return 0; }
-    if (argc == 4 && !std::strcmp(argv[1], "--convert")) {               // file format conversion only (no GPU): PNG <-> PNM
+                                 "       rtdd_harness --convert in.(jpg|png|ppm|pgm) out.(png|ppm|pgm)   (JPEG / 8-bit PNG / PNM -> PNG / PNM, no GPU)\n"); return 0; }
+    if (argc == 4 && !std::strcmp(argv[1], "--convert")) {               // file format conversion only (no GPU): JPEG / PNG / PNM -> PNG / PNM
         Pnm im;
         if (!read_image(argv[2], im)) { std::printf("cannot read %s\n", argv[2]); return 2; }
         return write_image(argv[3], im.w, im.h, im.ch, im.px.data()) ? 0 : 5;
@@ -353,10 +364,15 @@ int main(int argc, const char *argv[]) {
         else if (!std::strcmp(argv[i], "--png")) png = true;                       // DepthMap.png / ArtisticEffect.png like the reference
         else if (!std::strcmp(argv[i], "--paint")) { Paint p{0, 0, 0, 0, -1}; if (std::sscanf(next(), "%d,%d,%d,%d", &p.x, &p.y, &p.label, &p.radius) == 4) job.paints.push_back(p); }
         else if (!std::strcmp(argv[i], "--paint-at")) { Paint p{0, 0, 0, 0, 0}; if (std::sscanf(next(), "%d:%d,%d,%d,%d", &p.frame, &p.x, &p.y, &p.label, &p.radius) == 5) job.live_paints.push_back(p); }
-        else if (!std::strcmp(argv[i], "-h")) std::printf("Usage:\n -i input image (binary PPM)\n -a annotated image (binary PGM)\n");
+        else if (!std::strcmp(argv[i], "-h")) std::printf("Usage:\n -i input image (JPEG, 8-bit PNG, binary PPM)\n -a annotated image (8-bit PNG, binary PGM)\n");
     }
     Pnm rgb;
-    if (!read_image(in, rgb) || rgb.ch != 3) { std::printf("cannot read %s as a binary PPM or an 8-bit RGB PNG\n", in.c_str()); return 2; }
+    if (!read_image(in, rgb)) { std::printf("cannot read %s as a binary PPM / PGM, an 8-bit PNG or a JPEG\n", in.c_str()); return 2; }
+    if (rgb.ch == 1) {                                                       // cv::imread's default flag gives three channels whatever the file holds
+        Pnm c; c.w = rgb.w; c.h = rgb.h; c.ch = 3; c.px.resize(rgb.px.size() * 3);
+        for (size_t i = 0; i < rgb.px.size(); i++) c.px[3 * i] = c.px[3 * i + 1] = c.px[3 * i + 2] = rgb.px[i];
+        rgb = c;
+    }
     job.bgr = rgb;
     for (size_t i = 0; i < rgb.px.size(); i += 3) { job.bgr.px[i] = rgb.px[i + 2]; job.bgr.px[i + 2] = rgb.px[i]; }   // cv::imread gives BGR
     if (!an.empty()) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Convert any image Pillow can read (the dataset's JPEGs) to the binary PPM / PGM the harness reads.
 usage: to_pnm.py in.jpg out.ppm        (colour -> P6; add --gray for a one-channel P5)
-The harness itself reads PNM and 8-bit PNG; it has no JPEG decoder."""
+The harness reads JPEG (baseline and progressive Huffman, 8 bit: harness/jpeg_reader.hpp), 8-bit PNG and PNM itself; this is for the rest."""
 import sys
 from PIL import Image
 gray = "--gray" in sys.argv

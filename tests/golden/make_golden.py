@@ -195,7 +195,24 @@ def make_dataset():
         json.dump(manifest, fh, indent=1, sort_keys=True)
 
 
+def copy_dataset_jpegs():
+    """The twelve photographs AS FILES (dataset/images/<name>.jpg, byte for byte) beside their decoded copies: what the harness's own
+    JPEG reader (harness/jpeg_reader.hpp) is checked on -- its pixels must equal <name>.png, i.e. libjpeg-turbo's (tests/test_harness_jpeg.py)."""
+    import shutil
+    out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dataset")
+    for f in sorted(os.listdir(f"{REF}/images")):
+        if f.endswith(".jpg"):
+            rgb = np.array(Image.open(f"{REF}/images/{f}").convert("RGB"))
+            assert np.array_equal(rgb, np.array(Image.open(os.path.join(out_dir, f[:-4] + ".png")).convert("RGB"))), f
+            shutil.copyfile(f"{REF}/images/{f}", os.path.join(out_dir, f))
+            os.chmod(os.path.join(out_dir, f), 0o644)
+            print("copied", f)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--dataset-jpeg":
+        copy_dataset_jpegs()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--dataset":
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
         make_dataset()

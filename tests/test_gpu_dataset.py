@@ -76,14 +76,14 @@ def test_dataset_pair_whole_estimate_and_effects(oracle, lut, name):
         assert sha(c.pyramid_download(rt.IMG_DEPTH_U8)) == e["depth_u8_sha_c0"]
 
 
-@pytest.mark.parametrize("name", ["Flower", "Arara", "Straw"])
-def test_harness_on_the_dataset_files(oracle, lut, tmp_path, name):
-    """The C++ harness (host code over the C ABI) fed the dataset's files as they are: PNG image, PNG annotation, PNG out."""
+@pytest.mark.parametrize("name,ext", [("Flower", "png"), ("Arara", "png"), ("Straw", "png"), ("Dog", "jpg"), ("Heidelberg", "jpg"), ("WomanParasol", "jpg")])
+def test_harness_on_the_dataset_files(oracle, lut, tmp_path, name, ext):
+    """The C++ harness (host code over the C ABI) fed the dataset's files as they are: the JPEG the reference ships (sequential and
+    progressive ones, through the harness's own decoder) or its lossless PNG copy, PNG annotation, PNG out."""
     from PIL import Image
-    if not os.path.exists(BIN):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "harness")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "harness")])
     bgr, ann, e = load_pair(name)
-    out = subprocess.check_output([BIN, "-i", image_path(name), "-a", annotation_path(name), "-o", str(tmp_path) + "/", "--effect", "defocus", "--png"], text=True)
+    out = subprocess.check_output([BIN, "-i", image_path(name)[:-3] + ext, "-a", annotation_path(name), "-o", str(tmp_path) + "/", "--effect", "defocus", "--png"], text=True)
     assert "Saving images" in out
     depth_u8 = np.array(Image.open(tmp_path / "DepthMap.png"))
     assert sha(depth_u8) == e["depth_u8_sha_c1"]
