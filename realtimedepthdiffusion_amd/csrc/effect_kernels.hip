@@ -326,13 +326,12 @@ __global__ __launch_bounds__(1024) void k_sat_build(const uint8_t *__restrict__ 
 // negative and NaN products give a half-width <= 0: the reference's loops do not run and the pixel is copied (0 returned here).
 // Products beyond 255 * 2^22 are clamped: any k/2 >= max(rows, cols) selects the whole (clipped) image anyway.
 __device__ __forceinline__ int half_window(int kernelSize, float d) {
-    float v = (float)kernelSize * d;
-    if (!(v >= 510.0f)) return 0;
-    v = fminf(v, 1069547520.0f);                                    // 255 * 2^22
+    const float v0 = (float)kernelSize * d;
+    const float v = __builtin_amdgcn_fmed3f(v0, 0.0f, 1069547520.0f);   // 255 * 2^22 (a NaN gives 0); straight-line code: the table loads that depend on it issue sooner
     int k = (int)(v * (1.0f / 255.0f));
     const float r = __builtin_fmaf(-255.0f, (float)k, v);           // exact
     k += r < 0.0f ? -1 : (r >= 255.0f ? 1 : 0);
-    return k >> 1;
+    return v0 >= 510.0f ? k >> 1 : 0;                               // <= 2^21
 }
 
 // (uchar)(sum / count) of src/GPUDepthEffect.cu:68-70 (f32 divide, truncation) for an exact integer sum s < 2^24 and count < 2^16: a
@@ -343,6 +342,21 @@ __device__ __forceinline__ uint32_t quot_u8(uint32_t s, uint32_t count, float rc
     const int rem = (int)s - n * (int)count;
     n += rem < 0 ? -1 : (rem >= (int)count ? 1 : 0);
     return (uint32_t)min(n, 255);
+}
+
+// The same three quotients, packed b | g << 8 | r << 16, in 8 instead of 14 instructions each: q = trunc(s * rlo) with rlo = RN(1 / c) less
+// 2^-21 relative never exceeds floor(s / c) (v_rcp_f32 is within 1 ulp, the two products round by 2^-24 each) and is at most one below
+// it (s / c < 256, 256 * 2^-20.5 < 1); the remainder s - q c -- one fma, exact: an integer in [0, 2 c) -- says which; v_cvt_pk_u8_f32
+// places the byte (and saturates what a depth that is no depth produces).
+__device__ __forceinline__ uint32_t quot3_u8(uint32_t sb, uint32_t sg, uint32_t sr, uint32_t count, float rc) {
+    const float cf = (float)count, rlo = rc * (1.0f - 0x1p-21f);
+    auto q1 = [&](uint32_t s) {
+        const float sf = (float)s, q = __builtin_truncf(sf * rlo), r = __builtin_fmaf(-q, cf, sf);
+        return r >= cf ? q + 1.0f : q;
+    };
+    uint32_t out = __builtin_amdgcn_cvt_pk_u8_f32(q1(sb), 0, 0u);
+    out = __builtin_amdgcn_cvt_pk_u8_f32(q1(sg), 1, out);
+    return __builtin_amdgcn_cvt_pk_u8_f32(q1(sr), 2, out);
 }
 
 // simulateDefocus (K9) -- src/GPUDepthEffect.cu:29-72: the lookup.  Lane = pixel, wave = 64 pixels x 2 rows, workgroup = 64 x 8 pixels
@@ -383,31 +397,31 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
 #pragma unroll
     for (int i = 0; i < kLk2Rows; i++) d[i] = ((const float *)((const char *)depth + (size_t)min(yw + i, rows - 1) * dp))[xc];
     uint32_t cnt[kLk2Rows];
-    u64 X[kLk2Rows];
+    u64 C[kLk2Rows][4];
     int ya[kLk2Rows], yb[kLk2Rows], xa[kLk2Rows], xb[kLk2Rows];
 #pragma unroll
-    for (int i = 0; i < kLk2Rows; i++) {
+    for (int i = 0; i < kLk2Rows; i++) {                            // every corner load of the wave's rows before the first is used
         const int y = min(yw + i, rows - 1);
-        const int h = half_window(kernelSize, d[i]);
-        ya[i] = max(y - h, 0); yb[i] = (int)min((long long)y + h, (long long)rows);
-        xa[i] = max(xc - h, 0); xb[i] = (int)min((long long)xc + h, (long long)cols);
+        const int h = half_window(kernelSize, d[i]);                // <= 2^21: y + h stays an int
+        ya[i] = max(y - h, 0); yb[i] = min(y + h, rows);
+        xa[i] = max(xc - h, 0); xb[i] = min(xc + h, cols);
         // T(ya - 1, xa - 1) = T'[ya][xa + 3], ...: byte offsets row * pitch8 + 8 * col + 24
         const uint32_t ra = (uint32_t)__umul24(ya[i], pitch8), rb = (uint32_t)__umul24(yb[i], pitch8);       // rows <= 2^14, pitch8 < 2^24: exact in 32 bits (check_effect)
         const uint32_t ca = 8u * (uint32_t)xa[i] + 24u, cb = 8u * (uint32_t)xb[i] + 24u;
-        const u64 c00 = tab_load(rsrc, ra + ca), c01 = tab_load(rsrc, ra + cb), c10 = tab_load(rsrc, rb + ca), c11 = tab_load(rsrc, rb + cb);
-        X[i] = c11 - c10 - c01 + c00;
+        C[i][0] = tab_load(rsrc, ra + ca); C[i][1] = tab_load(rsrc, ra + cb); C[i][2] = tab_load(rsrc, rb + ca); C[i][3] = tab_load(rsrc, rb + cb);
         const int wd = xb[i] - xa[i], ht = yb[i] - ya[i];
-        cnt[i] = (wd > 0 && ht > 0) ? (uint32_t)ht * (uint32_t)wd : 0u;
+        cnt[i] = (wd > 0 && ht > 0) ? (uint32_t)__umul24(ht, wd) : 0u;   // (both <= 2^14)
     }
 #pragma unroll
     for (int i = 0; i < kLk2Rows; i++) {
         const int y = yw + i, yc = min(y, rows - 1);
         uint32_t res;
         {
-            const uint32_t sb = (uint32_t)(X[i] & kSatFieldMask), sg = (uint32_t)((X[i] >> 21) & kSatFieldMask), sr = (uint32_t)(X[i] >> 42);
+            const u64 X = C[i][3] - C[i][2] - C[i][1] + C[i][0];
+            const uint32_t lo = (uint32_t)X, hi = (uint32_t)(X >> 32);
+            const uint32_t sb = lo & (uint32_t)kSatFieldMask, sg = ((lo >> 21) | (hi << 11)) & (uint32_t)kSatFieldMask, sr = hi >> 10;
             const uint32_t c = cnt[i] ? cnt[i] : 1u;
-            const float rc = __builtin_amdgcn_rcpf((float)c);
-            res = quot_u8(sb, c, rc) | (quot_u8(sg, c, rc) << 8) | (quot_u8(sr, c, rc) << 16);
+            res = quot3_u8(sb, sg, sr, c, __builtin_amdgcn_rcpf((float)c));
         }
         // windows of more than kSatMaxArea pixels (the packed fields would run into each other) and empty ones: under wave-uniform branches
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt[i] > (uint32_t)kSatMaxArea) != 0, 0)) {
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restri
 #endif
     // ---- lookups (k_defocus with the corners in LDS) ----
     // The common case -- the window lies inside the region -- is straight-line code for the whole wave: clamped LDS addresses, selects
-    // instead of branches, 24-bit multiplies (quotient <= 256, count <= 56 x 56); what it computes for a lane whose window does not
+    // instead of branches, the quotients by quot3_u8 (count <= 56 x 56); what it computes for a lane whose window does not
     // fit is discarded.  Such lanes (a depth above 255 * (2 hm + 1) / kernelSize, never a depth map's) are summed from the image by
     // their wave under ONE wave-uniform branch per row of output.
     const int rh1 = rh - 1;
@@ -627,14 +641,7 @@ __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restri
         const u64 X = t11 - (c0 < 0 ? 0ull : t10) - (r0 < 0 ? 0ull : t01) + ((r0 < 0 || c0 < 0) ? 0ull : t00);
         const uint32_t fb = (uint32_t)(X & kSatFieldMask), fg = (uint32_t)((X >> 21) & kSatFieldMask), fr = (uint32_t)(X >> 42);
         const uint32_t cnt = (uint32_t)__mul24(ht, wd);             // (exact for a window inside the region; recomputed below otherwise)
-        const float rc = __builtin_amdgcn_rcpf((float)cnt);
-        auto quot_small = [&](uint32_t s) {                         // quot_u8 with 24-bit multiplies: s < 2^24, quotient <= 256, count < 2^12
-            int n = (int)((float)s * rc);
-            const int rem = (int)s - __mul24(n, (int)cnt);
-            n += rem < 0 ? -1 : (rem >= (int)cnt ? 1 : 0);
-            return (uint32_t)min(n, 255);
-        };
-        const uint32_t fast = quot_small(fb) | (quot_small(fg) << 8) | (quot_small(fr) << 16);
+        const uint32_t fast = quot3_u8(fb, fg, fr, cnt, __builtin_amdgcn_rcpf((float)cnt));   // (an empty window: discarded below)
         uint32_t res = (has && local) ? fast : opx[i];              // count == 0 (:62-66): the pixel itself
         unsigned long long todo = __builtin_amdgcn_ballot_w64(has && !local);
         if (__builtin_expect(todo != 0, 0)) {                       // windows beyond the region: the wave sums them from the image, one pixel at a time
