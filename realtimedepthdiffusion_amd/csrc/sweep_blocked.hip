@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "rtdd_internal.hpp"
+#include <cstring>
 #include "persist_sync.hpp"
 #include "sweep_common.hpp"
 #include "sweep_diag.hpp"      // RTDD_STAMP / RTDD_TL / RTDD_XT: empty unless a diagnostic micro-benchmark asks for them
@@ -607,7 +608,10 @@ static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int ti
     } else if (k >= 2) {
         const double rounds = ceil(nwg / (cus * k));
         const double m_eff = rounds <= 3 ? rounds * k : m;     // few rounds: the last, partly filled one costs a whole round
-        const double comp = 1.45 * T * thr1, mem = load1 + store1;
+        // (1.45: what the single-image choices of rounds 1-3 were calibrated with; the kernels have become faster since, and the batch
+        // measurements of round 5 -- scripts/batch_level_ab.py: 64 x 480x270 tile 6 depth 8 7.8 us per sweep, 64 x 960x540 29, 64 x 1080p 110; tiles
+        // 5 and 7 alike -- fit 0.95 for the tiles of three rows per thread; tile 9 (one row per thread: 13 us where 0.95 says 8) keeps 1.45)
+        const double comp = (images > 1 && G >= 3 ? 0.95 : 1.45) * T * thr1, mem = load1 + store1;
         t = boundary + load1 + m_eff * (comp > mem ? comp : mem);
     } else {
         t = boundary + ceil(m) * (load1 + T * (lat > thr1 ? lat : thr1) + 0.5 * store1);
@@ -657,14 +661,39 @@ static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, 
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
                           int *pk, int *pm, int *launches) {
     const int images = ctx->batch.n;
-    if (images > 1 && ctx->opt.tile == 0 && ctx->opt.temporal_depth == 0 && !(cols <= 128 && rows <= 64)) {
+#ifdef RTDD_FORCE_CFG_HOOK
+    {   // developer's hook (A/B builds only): RTDD_FORCE_CFG="cols,rows,tile,depth,persistent,per_image;..." pins the choice for a level size
+        static const char *env = getenv("RTDD_FORCE_CFG");
+        for (const char *q = env; q && *q;) {
+            int c = 0, r = 0, ti = 0, d = 0, pe = 0, pi = 0;
+            if (sscanf(q, "%d,%d,%d,%d,%d,%d", &c, &r, &ti, &d, &pe, &pi) == 6 && c == cols && r == rows && images > 1) {
+                const Options saved_opt = ctx->opt; const Batch saved = ctx->batch;
+                ctx->opt.tile = ti; ctx->opt.temporal_depth = d; ctx->opt.persistent = pe;
+                int rc = RTDD_OK, a = *pk, b = *pm, total = 0;
+                if (pi) {
+                    for (int i = 0; i < images && rc == RTDD_OK; i++) {
+                        a = *pk; b = *pm; int ln = 0; ctx->batch.n = 1;
+                        rc = launch_sweeps_blocked_impl(ctx, L.view(i), ip, rows, cols, omegas_dev, n, &a, &b, &ln); total += ln;
+                    }
+                } else rc = launch_sweeps_blocked_impl(ctx, L, ip, rows, cols, omegas_dev, n, &a, &b, &total);
+                ctx->opt = saved_opt; ctx->batch = saved;
+                *pk = a; *pm = b; *launches = total;
+                return rc;
+            }
+            q = strchr(q, ';'); if (q) q++;
+        }
+    }
+#endif
+    if (images > 1 && ctx->opt.tile == 0 && ctx->opt.temporal_depth == 0 && !(cols <= 128 && rows <= 96)) {
         int t1, T1, tb, Tb; bool p1, pb;
         const Batch saved = ctx->batch;
         ctx->batch.n = 1;
         const double c1 = choose_config(ctx, rows, cols, n, 0, 0, &t1, &T1, &p1);
         ctx->batch = saved;
         const double cb = choose_config(ctx, rows, cols, n, 0, 0, &tb, &Tb, &pb);
-        if (p1 && c1 * images < cb) {
+        // (the model prices a persistent 1080p launch at 2.5 us per sweep; it runs at 1.5 -- profiles/r05_1080p_jacobi1000_* -- and 64 images
+        // one after the other take 5.96 ms where one launch per block over the batch takes 6.83: scripts/batch_level_ab.py)
+        if (p1 && 0.6 * c1 * images < cb) {
             int rc = RTDD_OK, a = *pk, b = *pm, total = 0;
             for (int i = 0; i < images && rc == RTDD_OK; i++) {
                 a = *pk; b = *pm;
@@ -692,6 +721,10 @@ static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, 
         int bt = 0, bT = 0; bool bp = false;
         if (cols <= 64 && rows <= 64) { bt = 9; bT = 8; }                  // ONE tile, 4 px/thread: all sweeps in one launch
         else if (cols <= 128 && rows <= 32) { bt = 11; bT = 8; }           // ditto
+        // a batch whose images each fit ONE 128 x 96 tile: a workgroup per image, every sweep in one launch, no halo and no exchange
+        // (64 x 120x67 x 1000 sweeps: 0.76 ms against 1.92 for four persistent tiles per image; a single image is better off spread
+        // over the chip in the column layout, 0.46 ms)
+        else if (ctx->batch.n > 1 && cols <= 128 && rows <= 96) { bt = 4; bT = 8; }
         else choose_config(ctx, rows, cols, n, tile, T, &bt, &bT, &bp);
         if (tile == 0) tile = bt;
         if (T == 0) T = bT;
