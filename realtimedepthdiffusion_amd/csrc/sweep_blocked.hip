@@ -666,7 +666,7 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
         static const char *env = getenv("RTDD_FORCE_CFG");
         for (const char *q = env; q && *q;) {
             int c = 0, r = 0, ti = 0, d = 0, pe = 0, pi = 0;
-            if (sscanf(q, "%d,%d,%d,%d,%d,%d", &c, &r, &ti, &d, &pe, &pi) == 6 && c == cols && r == rows && images > 1) {
+            if (sscanf(q, "%d,%d,%d,%d,%d,%d", &c, &r, &ti, &d, &pe, &pi) == 6 && c == cols && r == rows) {
                 const Options saved_opt = ctx->opt; const Batch saved = ctx->batch;
                 ctx->opt.tile = ti; ctx->opt.temporal_depth = d; ctx->opt.persistent = pe;
                 int rc = RTDD_OK, a = *pk, b = *pm, total = 0;
