@@ -54,6 +54,26 @@ def test_harness_png_in_png_out(tmp_path):
     assert np.array_equal(np.array(Image.open(tmp_path / "ArtisticEffect.png")), g["defocus"][..., ::-1])
 
 
+@pytest.mark.parametrize("ext", ["jpg", "pgm"])
+def test_harness_one_channel_image_becomes_three(tmp_path, ext):
+    """A gray JPEG (decoded by the harness's own reader) or a PGM as the IMAGE: cv::imread's default flag hands main.cpp three equal channels
+    (src/main.cpp:93), so the estimate is the oracle cascade's on B = G = R = the file's pixels."""
+    from PIL import Image
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "harness")])
+    g = load(NAMES[0])
+    gray = np.ascontiguousarray(g["bgr"][..., 1])
+    if ext == "jpg":
+        Image.fromarray(gray, "L").save(tmp_path / "img.jpg", quality=90, progressive=True)
+        gray = np.array(Image.open(tmp_path / "img.jpg"))              # (what libjpeg makes of it: tests/test_harness_jpeg.py checks the reader against that)
+        assert gray.ndim == 2
+    else:
+        _write_pnm(tmp_path / "img.pgm", gray)
+    _write_pnm(tmp_path / "ann.pgm", g["annotation"])
+    subprocess.check_output([BIN, "-i", str(tmp_path / ("img." + ext)), "-a", str(tmp_path / "ann.pgm"), "-o", str(tmp_path) + "/"], text=True)
+    ref = _oracle_cascade({"bgr": np.repeat(gray[..., None], 3, 2), "annotation": g["annotation"]})
+    assert np.array_equal(_read_pnm(tmp_path / "DepthMap.pgm"), ref.depth_u8)
+
+
 def _oracle_cascade(g, paints=(), annotation=True, estimates=1, iters=1000):
     """The harness's call sequence restated over the oracle (tests/cascade_ref.py): decode, brush samples, `estimates` estimates."""
     import oracle
