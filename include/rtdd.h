@@ -119,6 +119,10 @@ enum rtdd_option {
     RTDD_OPT_PERSISTENT_SUSPENDED = 18, /* read only: 0 persistent launches are armed (or RTDD_OPT_PERSISTENT is 0 by the caller's choice); n > 0: suspended
                                        for n more solves after a time-out; -1: off for the rest of the context's life */
     RTDD_OPT_PENDING_CALLS = 19,    /* read only: calls currently remembered for a replay (see RTDD_ERR_TIMEOUT): those still in flight */
+    RTDD_OPT_LIVE_ZERO_COPY = 20,   /* rtdd_live_submit lets the estimate's copy-back kernel store the u8 map straight into hostDepthU8 when that buffer is
+                                       page-locked (rtdd_host_alloc, hipHostMalloc, hipHostRegister) -- no staging slot, no download.  1 (default): where it
+                                       pays (maps of up to 3 MB; larger ones when no other frame is in flight); 2: always; 0: never (stage and download:
+                                       what any other host pointer gets) */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),
@@ -140,7 +144,7 @@ int rtdd_version(void);                                  /* major * 100 + minor.
                                                           * rtdd_solve_ex / rtdd_refine_depth / rtdd_last_solve_info write the whole struct, so a
                                                           * caller compiled against a 1xx header must be rebuilt (#define RTDD_VERSION below).  210 adds
                                                           * rtdd_pyramid_annotation_changed, RTDD_OPT_TIMEOUT_HEALS and the self-healing time-out; 220: RTDD_OPT_TIMEOUT_HEAL,
-                                                          * persistence re-armed after a time-out, rtdd_estimate_depth_batch */
+                                                          * persistence re-armed after a time-out, rtdd_estimate_depth_batch, RTDD_OPT_LIVE_ZERO_COPY */
 #define RTDD_VERSION 220
 
 /* ---- solver (include/GPUSolver.h:6-10) ------------------------------------------------------ */
@@ -298,7 +302,8 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations);
  * (:236-237), the estimate, download of the u8 map (:290-291) -- pipelined two frames deep: the copies run on a second stream of the
  * context's, so frame N+1's upload and frame N's download overlap the other frame's arithmetic and a frame costs about
  * max(compute, copies).  rtdd_live_submit returns at once; the host buffers must stay valid (and unchanged) until the frame has been
- * waited for, and should be page-locked (rtdd_host_alloc) -- pageable memory makes the copies synchronous.  hostScribble / hostEdited
+ * waited for, and should be page-locked (rtdd_host_alloc) -- pageable memory makes the copies synchronous, and a page-locked hostDepthU8
+ * is written by the estimate's last kernel itself instead of being downloaded (RTDD_OPT_LIVE_ZERO_COPY).  hostScribble / hostEdited
  * NULL: no upload, the annotation is the one already on the device.  A third submit waits for the oldest frame itself.
  * rtdd_live_wait blocks until the OLDEST frame in flight has landed in its host buffer (a timed-out persistent launch is healed
  * there like in rtdd_ctx_synchronize: every frame in flight is run again on its own uploaded annotation; the COARSE annotation levels,

@@ -38,7 +38,7 @@ struct Live {
     Image scribble_stage[2], edited_stage[2], u8_stage[2];
     hipEvent_t h2d_done[2] = {nullptr, nullptr}, est_done[2] = {nullptr, nullptr}, d2h_done[2] = {nullptr, nullptr};
     int *status_host = nullptr;           // page-locked, 2 x 8 ints: the kernels' control words as they were behind each frame's estimate
-    struct Frame { uint8_t *host = nullptr; size_t pitch = 0; bool in_flight = false; unsigned long long op_id = 0; } frame[2];
+    struct Frame { uint8_t *host = nullptr; size_t pitch = 0; bool in_flight = false, direct = false; unsigned long long op_id = 0; } frame[2];
     unsigned long long submitted = 0, waited = 0;
     // Round 5: no device-to-device staging copies.  A frame's annotation is uploaded into the staging pair that is NOT the pyramid's
     // current level-0 annotation, and the pyramid's level-0 scribble / edited images then simply BECOME that pair (pointer swap); the
@@ -46,6 +46,19 @@ struct Live {
     // The pyramid's own annotation buffers are kept here and put back before the pyramid is freed.
     void *own_scribble = nullptr, *own_edited = nullptr;
 };
+
+// The device's name for a page-locked host image (every byte of rows x cols at `pitch` inside one registered range), or nullptr.  Asked
+// for every frame (two driver queries, ~2 us of host time): a buffer freed and allocated again at the same address may not be page-locked any more.
+static uint8_t *live_device_view(const uint8_t *host, size_t pitch, int rows, int cols) {
+    uint8_t *dev = nullptr;
+    hipPointerAttribute_t a0, a1;
+    const uint8_t *last = host + (size_t)(rows - 1) * pitch + (size_t)cols - 1;
+    if (hipPointerGetAttributes(&a0, host) == hipSuccess && hipPointerGetAttributes(&a1, last) == hipSuccess && a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost &&
+        a0.devicePointer && a1.devicePointer && (const uint8_t *)a1.devicePointer - (const uint8_t *)a0.devicePointer == last - host)
+        dev = (uint8_t *)a0.devicePointer;
+    else (void)hipGetLastError();                                   // (an ordinary host pointer: the query fails, nothing else has)
+    return dev;
+}
 
 static bool inside(const Image &im, const void *p) {
     return im.ptr && (const char *)p >= (const char *)im.ptr && (const char *)p < (const char *)im.ptr + im.stride * (size_t)im.images;
@@ -272,6 +285,7 @@ static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, s
     op.kind = PendingOp::kEstimate; op.opt = ctx->opt; op.maxIterations = maxIterations;
     op.u8_copy = u8_copy; op.u8_copy_pitch = u8_copy_pitch; op.batch_first = first; op.batch_n = n;
     for (int i = 0; i < 3; i++) op.live_images[i] = ctx->live_images[i];       // a live frame: the level-0 annotation pair and the u8 slot it ran on
+    op.live_u8_pitch = ctx->live_u8_pitch;
     rc = estimate_levels(ctx, maxIterations, P - 1, op.level_seq, first, n);
     if (rc == RTDD_OK && u8_copy) {
         DeviceGuard g(ctx->device);
@@ -362,7 +376,8 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
     if (rc != RTDD_OK) return rc;
     for (unsigned long long f = v->waited; f < v->submitted; f++) {
         const int j = (int)(f % 2);
-        RTDD_HIP(ctx, hipMemcpy2D(v->frame[j].host, v->frame[j].pitch, v->u8_stage[j].ptr, v->u8_stage[j].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost));
+        // (a frame whose map the copy-back kernel stores in the host's buffer itself has just been run again into that buffer)
+        if (!v->frame[j].direct) RTDD_HIP(ctx, hipMemcpy2D(v->frame[j].host, v->frame[j].pitch, v->u8_stage[j].ptr, v->u8_stage[j].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost));
         v->status_host[8 * j + kSyncStatus] = 0;
     }
     v->frame[k].in_flight = false; v->waited++;
@@ -398,17 +413,31 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
         p->annotation_dirty = true;
     }
     unsigned long long op_id = ctx->op_counter;
-    // (the estimate's copy-back writes this frame's map into RTDD_IMG_DEPTH_U8 and into the frame's staging slot: estimate_levels)
-    ctx->live_images[0] = p->scribble[0].ptr; ctx->live_images[1] = p->edited[0].ptr; ctx->live_images[2] = v->u8_stage[k].ptr;
+    // Where the map goes.  A page-locked host buffer (rtdd_host_alloc, hipHostMalloc, hipHostRegister) is device-visible: the estimate's
+    // copy-back kernel stores the u8 map straight into it (2 MB of posted writes at 1080p) and the frame ends with an event on the compute
+    // stream -- no download, no second stream: a copy stream waiting for the compute stream costs the compute stream ~80 us per frame
+    // here, the stores ~20 us per MB while they hold the stream (EXPERIMENTS.md round 5: 1080p 1.21 -> 1.17 ms per pipelined frame, 4K 1.55 ->
+    // 1.65).  So: maps of up to 3 MB always, larger ones when no other frame is in flight (then nothing overlaps a download anyway: 4K
+    // one frame at a time 2.31 -> 2.20 ms).  Any other host pointer: the staging slot and a download on the copy stream, as before.
+    const bool want_direct = ctx->opt.live_zero_copy == 2 || (ctx->opt.live_zero_copy == 1 && ((size_t)p->rows * p->cols <= (3u << 20) || v->submitted == v->waited));
+    uint8_t *direct = want_direct ? live_device_view(hostDepthU8, depthPitch, p->rows, p->cols) : nullptr;
+    // (the estimate's copy-back writes this frame's map into RTDD_IMG_DEPTH_U8 and into the frame's second target: estimate_levels)
+    ctx->live_images[0] = p->scribble[0].ptr; ctx->live_images[1] = p->edited[0].ptr;
+    ctx->live_images[2] = direct ? (void *)direct : v->u8_stage[k].ptr; ctx->live_u8_pitch = direct ? depthPitch : 0;
     rc = estimate_submit(ctx, maxIterations, nullptr, 0, &op_id);
-    ctx->live_images[0] = ctx->live_images[1] = ctx->live_images[2] = nullptr;
+    ctx->live_images[0] = ctx->live_images[1] = ctx->live_images[2] = nullptr; ctx->live_u8_pitch = 0;
     if (rc != RTDD_OK) return rc;
-    RTDD_HIP(ctx, hipEventRecord(v->est_done[k], ctx->stream));
-    RTDD_HIP(ctx, hipStreamWaitEvent(v->copy, v->est_done[k], 0));
-    RTDD_HIP(ctx, hipMemcpy2DAsync(hostDepthU8, depthPitch, v->u8_stage[k].ptr, v->u8_stage[k].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, v->copy));
-    RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
-    RTDD_HIP(ctx, hipEventRecord(v->d2h_done[k], v->copy));
-    v->frame[k].host = hostDepthU8; v->frame[k].pitch = depthPitch; v->frame[k].in_flight = true; v->frame[k].op_id = op_id;
+    if (direct) {
+        RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        RTDD_HIP(ctx, hipEventRecord(v->d2h_done[k], ctx->stream));
+    } else {
+        RTDD_HIP(ctx, hipEventRecord(v->est_done[k], ctx->stream));
+        RTDD_HIP(ctx, hipStreamWaitEvent(v->copy, v->est_done[k], 0));
+        RTDD_HIP(ctx, hipMemcpy2DAsync(hostDepthU8, depthPitch, v->u8_stage[k].ptr, v->u8_stage[k].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, v->copy));
+        RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
+        RTDD_HIP(ctx, hipEventRecord(v->d2h_done[k], v->copy));
+    }
+    v->frame[k].host = hostDepthU8; v->frame[k].pitch = depthPitch; v->frame[k].in_flight = true; v->frame[k].op_id = op_id; v->frame[k].direct = direct != nullptr;
     v->submitted++;
     return RTDD_OK;
 }
@@ -436,7 +465,7 @@ int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level
         // writes the u8 map (:290).  Same values in the same buffers (tests/test_gpu_cascade.py compares every level's image).
         ctx->defer_finish = solved && l > 0;
         ctx->finish_u8 = l == 0 ? (uint8_t *)p->depth_u8.at(first) : nullptr; ctx->finish_u8_pitch = p->depth_u8.pitch;
-        ctx->finish_u8b = l == 0 ? (uint8_t *)ctx->live_images[2] : nullptr; ctx->finish_u8b_pitch = p->depth_u8.pitch;     // (a live frame: its staging slot too)
+        ctx->finish_u8b = l == 0 ? (uint8_t *)ctx->live_images[2] : nullptr; ctx->finish_u8b_pitch = ctx->live_u8_pitch ? ctx->live_u8_pitch : p->depth_u8.pitch;     // (a live frame: its staging slot, or the host's buffer, too)
         if (solved) {
             // the level of images first .. first + n - 1 in the same launches (blockIdx.z = image: Batch, rtdd_internal.hpp)
             ctx->batch.n = n; ctx->batch.first = first;
@@ -484,10 +513,10 @@ int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
     if (from < 0) for (int l = 31; l >= 0 && from < 0; l--) if (op.level_seq[l] != 0) from = l;
     if (op.live_images[0]) {                        // a live frame is run again on ITS annotation pair into ITS u8 slot (the newest frame's replay comes last: the pyramid ends up naming its images)
         p->scribble[0].ptr = op.live_images[0]; p->edited[0].ptr = op.live_images[1];
-        ctx->live_images[2] = op.live_images[2];
+        ctx->live_images[2] = op.live_images[2]; ctx->live_u8_pitch = op.live_u8_pitch;
     }
     int rc = from >= 0 ? estimate_levels(ctx, op.maxIterations, from, nullptr, op.batch_first, op.batch_n) : RTDD_OK;
-    ctx->live_images[2] = nullptr;
+    ctx->live_images[2] = nullptr; ctx->live_u8_pitch = 0;
     if (rc == RTDD_OK && op.u8_copy)
         RTDD_HIP(ctx, hipMemcpy2DAsync(op.u8_copy, op.u8_copy_pitch, p->depth_u8.at(op.batch_first), p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
     return rc;

@@ -77,6 +77,7 @@ struct Options {
     int debug_poll_limit_us = 0;     // RTDD_OPT_DEBUG_POLL_LIMIT_US: exchange poll limit (0 = default, 200 ms)
     int debug_force_status = 0;      // RTDD_OPT_DEBUG_FORCE_STATUS: one-shot value for the status word behind the next blocked launch
     int timeout_heal = 1;            // RTDD_OPT_TIMEOUT_HEAL: 1 a timed-out persistent launch is healed (calls logged, run again); 0 it is reported
+    int live_zero_copy = 1;          // RTDD_OPT_LIVE_ZERO_COPY: a live frame's u8 map is stored by the copy-back kernel straight into the host's page-locked buffer (0 never, 1 where it pays, 2 always)
     int rearm_after = 64;            // RTDD_OPT_PERSISTENT_REARM_AFTER: solves without persistence after the first heal, doubling with every further one
 };
 
@@ -98,6 +99,7 @@ struct PendingOp {
     int level_seq[32] = {};               // sequence number of level l's solve (0: the level is empty)
     int batch_first = 0, batch_n = 1;     // the images of the context's batched pyramid the estimate covers
     void *live_images[3] = {nullptr, nullptr, nullptr};   // a live frame: the level-0 scribble / edited pair it ran on and the u8 staging slot its map is also written to (cascade_api.cpp)
+    size_t live_u8_pitch = 0;                             // ... that target's pitch when it is the host's own buffer (0: the staging slot)
     uint8_t *u8_copy = nullptr; size_t u8_copy_pitch = 0;   // live mode: the u8 map is copied here (device) behind the estimate
     unsigned long long id = 0;            // position in the context's call order (live mode drops the confirmed prefix of the log)
     // kDefocus / kDesaturate / kHaze: a depth effect queued BEHIND an unconfirmed solve (it may have read that solve's input instead of
@@ -140,6 +142,7 @@ struct rtdd_ctx {
     size_t finish_u8_pitch = 0;
     uint8_t *finish_u8b = nullptr;       // ... and a second copy of that map (a live frame's staging slot)
     size_t finish_u8b_pitch = 0;
+    size_t live_u8_pitch = 0;            // a live frame whose second target is the HOST's own page-locked buffer: its pitch (0: the staging slot's)
     int defocus_last_path = 0;           // RTDD_OPT_DEFOCUS_LAST_PATH: what the most recent rtdd_simulate_defocus launched (1 table, 2 tile kernel)
     bool defocus_table_sticky = false;   // a tile-kernel defocus met out-of-range depths (seen at a synchronisation): automatic choice = the table from then on
     int flag_epoch = 0;             // the per-tile flags of the persistent kernels only ever grow: base value of the next persistent launch (api.cpp)

@@ -167,11 +167,20 @@ def test_estimate_heals_a_timed_out_persistent_level(oracle, lut, capfd):
         assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, 0), ref.depth[0], "estimate after a healed one (warm start)")
 
 
+class _Pageable:
+    """an ordinary numpy array where the tests otherwise pass a page-locked host image"""
+    def __init__(self, shape):
+        self.a = np.zeros(shape, np.uint8)
+
+
+@pytest.mark.parametrize("out_kind", ["page_locked", "page_locked_staged", "pageable"])
 @pytest.mark.parametrize("withhold", [False, True])
-def test_live_frames_pipelined_match_the_oracle(oracle, lut, withhold):
+def test_live_frames_pipelined_match_the_oracle(oracle, lut, withhold, out_kind):
     """rtdd_live_submit / rtdd_live_wait (src/main.cpp:232-295 per frame: upload scribble + edited, estimate, download the u8 map), two
     frames in flight on two streams, page-locked host images: every frame's map is the oracle's n-th warm-started estimate -- also when
-    the first frame's persistent launch times out and both frames in flight are healed behind the caller's back."""
+    the first frame's persistent launch times out and both frames in flight are healed behind the caller's back.  Three ways for the map
+    to reach the host: stored by the copy-back kernel straight into a page-locked buffer (the default), staged and downloaded because the
+    option says so, staged and downloaded because the buffer is an ordinary allocation."""
     rows, cols = 540, 960
     bgr, ann = _bgr(rows, cols, 31)
     ref = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads())
@@ -181,7 +190,11 @@ def test_live_frames_pipelined_match_the_oracle(oracle, lut, withhold):
         c.GPULoadWeights(0.4)
         c.pyramid_create(rows, cols)
         c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann)); c.synchronize()
-        scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3)); out = [rt.host_image((rows, cols)) for _ in range(2)]
+        scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3))
+        out = [(_Pageable if out_kind == "pageable" else rt.host_image)((rows, cols)) for _ in range(2)]
+        assert c.get_option(rt.OPT_LIVE_ZERO_COPY) == 1
+        if out_kind == "page_locked_staged":
+            c.set_option(rt.OPT_LIVE_ZERO_COPY, 0)
         scr.a[...] = ref.scribble[0]; ed.a[...] = ref.edited[0]
         if withhold:
             c.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 1)
@@ -207,6 +220,30 @@ def test_live_frames_pipelined_match_the_oracle(oracle, lut, withhold):
         assert np.array_equal(out[0].a, ref.depth_u8)
         with pytest.raises(rt.RtddError):
             c.live_wait()                                                           # nothing in flight
+
+
+@pytest.mark.parametrize("zero_copy", [1, 2])
+def test_live_frame_into_a_window_of_a_wider_page_locked_image(oracle, lut, zero_copy):
+    """The host's map may be a window of a larger page-locked image (a pitch of its own, an interior first pixel): the copy-back kernel
+    stores into exactly that window -- the pixels around it keep their values."""
+    rows, cols = 135, 241
+    bgr, ann = _bgr(rows, cols, 8)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=4)
+    ref.estimate(1000)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        c.pyramid_create(rows, cols)
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann)); c.synchronize()
+        c.set_option(rt.OPT_LIVE_ZERO_COPY, zero_copy)
+        with pytest.raises(rt.RtddError):
+            c.set_option(rt.OPT_LIVE_ZERO_COPY, 3)
+        scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3)); big = rt.host_image((rows + 6, cols + 37))
+        scr.a[...] = ref.scribble[0]; ed.a[...] = ref.edited[0]; big.a[...] = 77
+        win = big.a[3:3 + rows, 19:19 + cols]
+        c.live_submit(scr.a, ed.a, win, 1000); c.live_wait()
+        assert np.array_equal(win, ref.depth_u8)
+        frame = big.a.copy(); frame[3:3 + rows, 19:19 + cols] = 77
+        assert (frame == 77).all()
 
 
 def test_annotation_pyramid_follows_every_write(oracle, lut):
