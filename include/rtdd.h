@@ -120,9 +120,9 @@ enum rtdd_option {
                                        for n more solves after a time-out; -1: off for the rest of the context's life */
     RTDD_OPT_PENDING_CALLS = 19,    /* read only: calls currently remembered for a replay (see RTDD_ERR_TIMEOUT): those still in flight */
     RTDD_OPT_LIVE_ZERO_COPY = 20,   /* rtdd_live_submit lets the estimate's copy-back kernel store the u8 map straight into hostDepthU8 when that buffer is
-                                       page-locked (rtdd_host_alloc, hipHostMalloc, hipHostRegister) -- no staging slot, no download.  1 (default): where it
-                                       pays (maps of up to 3 MB; larger ones when no other frame is in flight); 2: always; 0: never (stage and download:
-                                       what any other host pointer gets) */
+                                       page-locked (rtdd_host_alloc, hipHostMalloc, hipHostRegister) -- no staging slot, no download.  1 (default): when
+                                       no other frame is in flight (one frame at a time; in a pipelined loop rtdd_live_wait downloads the staged map
+                                       while the next frame computes, which is cheaper still); 2: always; 0: never */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),
@@ -302,8 +302,9 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations);
  * (:236-237), the estimate, download of the u8 map (:290-291) -- pipelined two frames deep: the copies run on a second stream of the
  * context's, so frame N+1's upload and frame N's download overlap the other frame's arithmetic and a frame costs about
  * max(compute, copies).  rtdd_live_submit returns at once; the host buffers must stay valid (and unchanged) until the frame has been
- * waited for, and should be page-locked (rtdd_host_alloc) -- pageable memory makes the copies synchronous, and a page-locked hostDepthU8
- * is written by the estimate's last kernel itself instead of being downloaded (RTDD_OPT_LIVE_ZERO_COPY).  hostScribble / hostEdited
+ * waited for, and should be page-locked (rtdd_host_alloc) -- pageable memory makes the copies synchronous, and with no other frame in
+ * flight a page-locked hostDepthU8 is written by the estimate's last kernel itself instead of being downloaded (RTDD_OPT_LIVE_ZERO_COPY);
+ * otherwise rtdd_live_wait downloads the map.  hostScribble / hostEdited
  * NULL: no upload, the annotation is the one already on the device.  A third submit waits for the oldest frame itself.
  * rtdd_live_wait blocks until the OLDEST frame in flight has landed in its host buffer (a timed-out persistent launch is healed
  * there like in rtdd_ctx_synchronize: every frame in flight is run again on its own uploaded annotation; the COARSE annotation levels,

@@ -358,7 +358,13 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
     Live *v = p->live;
     DeviceGuard g(ctx->device);
     const int k = (int)(v->waited % 2);
-    RTDD_HIP(ctx, hipEventSynchronize(v->d2h_done[k]));
+    if (v->frame[k].direct) RTDD_HIP(ctx, hipEventSynchronize(v->d2h_done[k]));
+    else {
+        RTDD_HIP(ctx, hipEventSynchronize(v->est_done[k]));
+        RTDD_HIP(ctx, hipMemcpy2DAsync(v->frame[k].host, v->frame[k].pitch, v->u8_stage[k].ptr, v->u8_stage[k].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, v->copy));
+        RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
+        RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
+    }
     if (v->status_host[8 * k + kSyncStatus] == 0) {                                 // the usual case: the frame is good, and so is everything logged before it
         size_t n = 0;
         while (n < ctx->pending.size() && ctx->pending[n].id <= v->frame[k].op_id) n++;
@@ -413,13 +419,15 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
         p->annotation_dirty = true;
     }
     unsigned long long op_id = ctx->op_counter;
-    // Where the map goes.  A page-locked host buffer (rtdd_host_alloc, hipHostMalloc, hipHostRegister) is device-visible: the estimate's
-    // copy-back kernel stores the u8 map straight into it (2 MB of posted writes at 1080p) and the frame ends with an event on the compute
-    // stream -- no download, no second stream: a copy stream waiting for the compute stream costs the compute stream ~80 us per frame
-    // here, the stores ~20 us per MB while they hold the stream (EXPERIMENTS.md round 5: 1080p 1.21 -> 1.17 ms per pipelined frame, 4K 1.55 ->
-    // 1.65).  So: maps of up to 3 MB always, larger ones when no other frame is in flight (then nothing overlaps a download anyway: 4K
-    // one frame at a time 2.31 -> 2.20 ms).  Any other host pointer: the staging slot and a download on the copy stream, as before.
-    const bool want_direct = ctx->opt.live_zero_copy == 2 || (ctx->opt.live_zero_copy == 1 && ((size_t)p->rows * p->cols <= (3u << 20) || v->submitted == v->waited));
+    // Where the map goes.  What it must not do is make a copy stream wait for the compute stream ON THE DEVICE: that costs the compute
+    // stream ~80 us per frame on this runtime (with both copies removed and only the event pair left: still 80; EXPERIMENTS.md round 5).
+    //   * another frame in flight (a pipelined loop): the map goes to the frame's staging slot, and rtdd_live_wait -- the HOST, which is
+    //     idle for 0.9 of such a frame -- downloads it once the estimate's event has come; the copy overlaps the next frame's arithmetic
+    //     (1080p 1.21 -> 1.14 ms per frame, 4K 1.57 -> 1.52);
+    //   * no other frame in flight (one frame at a time: nothing could overlap a download) and a page-locked host buffer (rtdd_host_alloc,
+    //     hipHostMalloc, hipHostRegister: device-visible): the estimate's copy-back kernel stores the u8 map straight into it, ~20 us
+    //     per MB of posted writes, and the frame ends with an event on the compute stream (1080p 1.42 -> 1.33 ms, 4K 2.31 -> 2.20).
+    const bool want_direct = ctx->opt.live_zero_copy == 2 || (ctx->opt.live_zero_copy == 1 && v->submitted == v->waited);
     uint8_t *direct = want_direct ? live_device_view(hostDepthU8, depthPitch, p->rows, p->cols) : nullptr;
     // (the estimate's copy-back writes this frame's map into RTDD_IMG_DEPTH_U8 and into the frame's second target: estimate_levels)
     ctx->live_images[0] = p->scribble[0].ptr; ctx->live_images[1] = p->edited[0].ptr;
@@ -431,11 +439,10 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
         RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         RTDD_HIP(ctx, hipEventRecord(v->d2h_done[k], ctx->stream));
     } else {
+        // staged: the download is issued by rtdd_live_wait, from the HOST, once this event has come -- a copy stream made to wait for the
+        // compute stream on the device costs the compute stream ~80 us per frame (above); the host has the time (it is idle for 0.9 of a
+        // pipelined frame), and the copy still overlaps the next frame's arithmetic
         RTDD_HIP(ctx, hipEventRecord(v->est_done[k], ctx->stream));
-        RTDD_HIP(ctx, hipStreamWaitEvent(v->copy, v->est_done[k], 0));
-        RTDD_HIP(ctx, hipMemcpy2DAsync(hostDepthU8, depthPitch, v->u8_stage[k].ptr, v->u8_stage[k].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, v->copy));
-        RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
-        RTDD_HIP(ctx, hipEventRecord(v->d2h_done[k], v->copy));
     }
     v->frame[k].host = hostDepthU8; v->frame[k].pitch = depthPitch; v->frame[k].in_flight = true; v->frame[k].op_id = op_id; v->frame[k].direct = direct != nullptr;
     v->submitted++;

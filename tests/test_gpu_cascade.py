@@ -173,14 +173,15 @@ class _Pageable:
         self.a = np.zeros(shape, np.uint8)
 
 
-@pytest.mark.parametrize("out_kind", ["page_locked", "page_locked_staged", "pageable"])
+@pytest.mark.parametrize("out_kind", ["page_locked", "page_locked_direct", "page_locked_staged", "pageable"])
 @pytest.mark.parametrize("withhold", [False, True])
 def test_live_frames_pipelined_match_the_oracle(oracle, lut, withhold, out_kind):
     """rtdd_live_submit / rtdd_live_wait (src/main.cpp:232-295 per frame: upload scribble + edited, estimate, download the u8 map), two
     frames in flight on two streams, page-locked host images: every frame's map is the oracle's n-th warm-started estimate -- also when
-    the first frame's persistent launch times out and both frames in flight are healed behind the caller's back.  Three ways for the map
-    to reach the host: stored by the copy-back kernel straight into a page-locked buffer (the default), staged and downloaded because the
-    option says so, staged and downloaded because the buffer is an ordinary allocation."""
+    the first frame's persistent launch times out and both frames in flight are healed behind the caller's back.  Two ways for the map
+    to reach the host -- stored by the copy-back kernel straight into a page-locked buffer, or staged on the device and downloaded by
+    rtdd_live_wait -- chosen per frame by default (direct when no other frame is in flight), forced either way by the option, and staged
+    whatever the option says when the buffer is an ordinary allocation."""
     rows, cols = 540, 960
     bgr, ann = _bgr(rows, cols, 31)
     ref = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads())
@@ -193,8 +194,8 @@ def test_live_frames_pipelined_match_the_oracle(oracle, lut, withhold, out_kind)
         scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3))
         out = [(_Pageable if out_kind == "pageable" else rt.host_image)((rows, cols)) for _ in range(2)]
         assert c.get_option(rt.OPT_LIVE_ZERO_COPY) == 1
-        if out_kind == "page_locked_staged":
-            c.set_option(rt.OPT_LIVE_ZERO_COPY, 0)
+        if out_kind in ("page_locked_staged", "page_locked_direct"):
+            c.set_option(rt.OPT_LIVE_ZERO_COPY, 0 if out_kind == "page_locked_staged" else 2)
         scr.a[...] = ref.scribble[0]; ed.a[...] = ref.edited[0]
         if withhold:
             c.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 1)
