@@ -210,7 +210,7 @@ def estimate_ms(rt, ctx, p, rows, cols, dev, n=20):
     for _ in range(n):
         ctx.live_submit(scr.a, ed.a, outs[0].a, 1000); ctx.live_wait()
     ms_e2e = (time.perf_counter() - t) / n * 1e3
-    frames = 2 * n
+    frames = max(200, 2 * n)                     # (long enough that the first upload and the last download, which overlap nothing, do not show)
     t = time.perf_counter()
     for f in range(frames):
         if f >= 2:
