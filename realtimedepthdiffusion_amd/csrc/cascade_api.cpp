@@ -409,12 +409,16 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
         // upload into the staging pair the pyramid is NOT looking at: the only frame that can still be in flight reads the other one
         // (at most two frames in flight, and the older one has been waited for above)
         const int u = p->scribble[0].ptr == v->scribble_stage[0].ptr ? 1 : 0;
-        RTDD_HIP(ctx, hipMemcpy2DAsync(v->scribble_stage[u].ptr, v->scribble_stage[u].pitch, hostScribble, scribblePitch, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, v->up));
-        RTDD_HIP(ctx, hipMemcpy2DAsync(v->edited_stage[u].ptr, v->edited_stage[u].pitch, hostEdited, editedPitch, (size_t)p->cols * 3, p->rows, hipMemcpyHostToDevice, v->up));
-        RTDD_HIP(ctx, hipEventRecord(v->h2d_done[k], v->up));
-        // (in the steady state the upload overlapped the previous frame and is long done: a cross-stream wait the compute stream does not
-        // need costs it ~10 us of idle time)
-        if (hipEventQuery(v->h2d_done[k]) != hipSuccess) RTDD_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->h2d_done[k], 0));
+        // (no other frame in flight: nothing for the upload to overlap -- it goes on the compute stream itself, no event between the
+        // streams: 1080p 1.335 -> 1.324 ms one frame at a time, 4K 2.21 -> 2.18)
+        const bool lone = v->submitted == v->waited;
+        hipStream_t us = lone ? ctx->stream : v->up;
+        RTDD_HIP(ctx, hipMemcpy2DAsync(v->scribble_stage[u].ptr, v->scribble_stage[u].pitch, hostScribble, scribblePitch, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, us));
+        RTDD_HIP(ctx, hipMemcpy2DAsync(v->edited_stage[u].ptr, v->edited_stage[u].pitch, hostEdited, editedPitch, (size_t)p->cols * 3, p->rows, hipMemcpyHostToDevice, us));
+        if (!lone) {
+            RTDD_HIP(ctx, hipEventRecord(v->h2d_done[k], v->up));
+            RTDD_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->h2d_done[k], 0));
+        }
         p->scribble[0].ptr = v->scribble_stage[u].ptr; p->edited[0].ptr = v->edited_stage[u].ptr;      // the pyramid's level-0 annotation IS the uploaded pair: no copy
         p->annotation_dirty = true;
     }
