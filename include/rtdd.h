@@ -123,6 +123,8 @@ enum rtdd_option {
                                        page-locked (rtdd_host_alloc, hipHostMalloc, hipHostRegister) -- no staging slot, no download.  1 (default): when
                                        no other frame is in flight (one frame at a time; in a pipelined loop rtdd_live_wait downloads the staged map
                                        while the next frame computes, which is cheaper still); 2: always; 0: never */
+    RTDD_OPT_ANNOTATION_LDS = 21,   /* 1 (default): an estimate's annotation pyramid walks its levels in LDS (one launch, one memory round trip; pyramids of
+                                       up to six levels); 0: the same launch with the levels read back from global memory (a developer's A/B knob) */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
                                        4 = 128x96, 5 = 128x48, 6 = 64x96, 7 = 64x48, 8 = 128x64 (8 px/thread),
                                        9 = 64x64 (4 px/thread), 10 = 64x64 (8 px/thread), 11 = 128x32 (4 px/thread),

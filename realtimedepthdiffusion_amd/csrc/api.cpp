@@ -321,6 +321,7 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_DEFOCUS_PATH: REQUIRE(ctx, value >= 0 && value <= 2, "defocus path must be 0..2"); ctx->opt.defocus_path = value; if (value == 0) ctx->defocus_table_sticky = false; break;      // (setting the automatic choice again forgets what earlier depths made it choose)
         case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 16, "tile must be 0..16"); ctx->opt.tile = value; break;
         case RTDD_OPT_PERSISTENT: ctx->opt.persistent = ctx->persistent_wanted = value ? 1 : 0; ctx->persist_suspend = 0; break;    // (said explicitly: armed at once, whatever a heal suspended)
+        case RTDD_OPT_ANNOTATION_LDS: ctx->opt.annotation_lds = value ? 1 : 0; break;
         case RTDD_OPT_LIVE_ZERO_COPY: REQUIRE(ctx, value >= 0 && value <= 2, "RTDD_OPT_LIVE_ZERO_COPY is 0, 1 or 2"); ctx->opt.live_zero_copy = value; break;
         case RTDD_OPT_TIMEOUT_HEAL: ctx->opt.timeout_heal = value ? 1 : 0; if (!value && !ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } break;
         case RTDD_OPT_PERSISTENT_REARM_AFTER: REQUIRE(ctx, value >= 0 && value <= (1 << 20), "must be 0..2^20"); ctx->opt.rearm_after = value; break;
@@ -356,6 +357,7 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_TIMEOUT_HEALS: *value = ctx->heals; break;
         case RTDD_OPT_TIMEOUT_HEAL: *value = ctx->opt.timeout_heal; break;
         case RTDD_OPT_LIVE_ZERO_COPY: *value = ctx->opt.live_zero_copy; break;
+        case RTDD_OPT_ANNOTATION_LDS: *value = ctx->opt.annotation_lds; break;
         case RTDD_OPT_PERSISTENT_REARM_AFTER: *value = ctx->opt.rearm_after; break;
         case RTDD_OPT_PERSISTENT_SUSPENDED: *value = ctx->persist_suspend; break;
         case RTDD_OPT_PENDING_CALLS: prune_confirmed(ctx); *value = (int)ctx->pending.size(); break;

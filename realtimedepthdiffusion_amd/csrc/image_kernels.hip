@@ -100,6 +100,86 @@ __global__ __launch_bounds__(256) void k_annotation_pyramid(AnnotationPyramid A)
     }
 }
 
+// The same pyramid with the chain in LDS (pyramids of up to six levels: every size up to 4K).  In footprint-local coordinates (origin =
+// the unclipped first pixel of the workgroup's footprint on that level) level-l pixel (lx, ly) reads level-(l - 1) pixels
+// (2 lx + {0, 1}, 2 ly + {0, 1}), and all a level hands to the next is "the edited value where the scribble flag is 255, else nothing":
+// one short per pixel.  Every global load of the workgroup -- its level-0 footprint and, because the coarse images accumulate over the
+// frames, the OLD state of every coarser level -- is issued before the first is used (ONE memory round trip; a first version that
+// stored each level's map to LDS as it arrived paid one per level and measured no faster than the global chain: EXPERIMENTS.md), then
+// the levels are walked in LDS and the pixels that were hit stored.
+template <int TOP>
+__global__ __launch_bounds__(256) void k_annotation_pyramid_lds(AnnotationPyramid A) {
+    constexpr int kN0 = kApB << TOP, kE0 = (kN0 * kN0 + 255) / 256;  // level-0 footprint edge, its entries per thread
+    constexpr int kTotal = (4 * kN0 * kN0 - kApB * kApB) / 3;       // sum over the levels of (kApB << (TOP - l))^2
+    __shared__ short map[kTotal];
+    const int tid = threadIdx.x;
+    const size_t z = blockIdx.z;
+    int flag[TOP + 1][kE0], val[TOP + 1][kE0];
+#pragma unroll
+    for (int l = 0; l <= TOP; l++) {
+        const int f = 1 << (TOP - l), n = kApB * f;
+        const int x0 = (int)blockIdx.x * kApB * f - (f - 1), y0 = (int)blockIdx.y * kApB * f - (f - 1);
+        const uint8_t *ps = A.scribble[l] + z * A.zs[l], *pe = A.edited[l] + z * A.ze[l];
+#pragma unroll
+        for (int k = 0; k < kE0; k++) {
+            if (k * 256 >= n * n) continue;                          // (compile time after unrolling: the coarser levels have fewer entries)
+            const int i = tid + 256 * k, lx = i & (n - 1), ly = i / n, x = x0 + lx, y = y0 + ly;
+            const bool in = i < n * n && x >= 0 && y >= 0 && x < A.cols[l] && y < A.rows[l];
+            const int xc = in ? x : 0, yc = in ? y : 0;
+            flag[l][k] = ps[(size_t)yc * A.sp[l] + xc]; val[l][k] = pe[(size_t)yc * A.ep[l] + 3 * xc];
+        }
+    }
+    int off = 0;
+#pragma unroll
+    for (int l = 0; l <= TOP; l++) {
+        const int f = 1 << (TOP - l), n = kApB * f;
+        const int x0 = (int)blockIdx.x * kApB * f - (f - 1), y0 = (int)blockIdx.y * kApB * f - (f - 1);
+#pragma unroll
+        for (int k = 0; k < kE0; k++) {
+            if (k * 256 >= n * n) continue;
+            const int i = tid + 256 * k, lx = i & (n - 1), ly = i / n, x = x0 + lx, y = y0 + ly;
+            const bool in = x >= 0 && y >= 0 && x < A.cols[l] && y < A.rows[l];
+            if (i < n * n) map[off + i] = (short)((in && flag[l][k] == 255) ? val[l][k] : -1);
+        }
+        off += n * n;
+    }
+    __syncthreads();
+    int poff = 0;
+#pragma unroll
+    for (int l = 1; l <= TOP; l++) {
+        const int f = 1 << (TOP - l), n = kApB * f, pn = 2 * n, coff = poff + pn * pn;
+        const int x0 = (int)blockIdx.x * kApB * f - (f - 1), y0 = (int)blockIdx.y * kApB * f - (f - 1);
+        uint8_t *cs = A.scribble[l] + z * A.zs[l], *ce = A.edited[l] + z * A.ze[l];
+#pragma unroll
+        for (int k = 0; k < kE0; k++) {
+            if (k * 256 >= n * n) continue;
+            const int i = tid + 256 * k;
+            if (i < n * n) {
+                const int lx = i & (n - 1), ly = i / n, x = x0 + lx, y = y0 + ly;
+                const short *q = map + poff + (2 * ly) * pn + 2 * lx;
+                int hit = -1;                                        // scan order py outer, px inner, the last hit wins (k_pyrdown_annotation)
+                if (q[0] >= 0) hit = q[0];
+                if (q[1] >= 0) hit = q[1];
+                if (q[pn] >= 0) hit = q[pn];
+                if (q[pn + 1] >= 0) hit = q[pn + 1];
+                if (hit >= 0 && x >= 0 && y >= 0 && x < A.cols[l] && y < A.rows[l]) {
+                    map[coff + i] = (short)hit;
+                    cs[(size_t)y * A.sp[l] + x] = 255;
+                    ce[(size_t)y * A.ep[l] + 3 * x] = (uint8_t)hit;
+                }
+            }
+        }
+        __syncthreads();
+        poff = coff;
+    }
+    // convert (K5) on the coarsest level: the workgroup's kApB x kApB pixels
+    const int x = (int)blockIdx.x * kApB + (tid % kApB), y = (int)blockIdx.y * kApB + (tid / kApB);
+    if (tid < kApB * kApB && A.depth && x < A.cols[TOP] && y < A.rows[TOP]) {
+        const int v = map[poff + tid];
+        if (v >= 0) ((float *)((char *)A.depth + z * A.zd + (size_t)y * A.dp))[x] = (float)v;
+    }
+}
+
 // paintImage (K7) -- src/GPUImageProcessing.cu:51-70.  Launched over the brush's bounding box only
 // (the reference launches the whole image and discards all but the brush).
 __global__ __launch_bounds__(256) void k_paint(int x0, int y0, int x1, int y1, int color, uint8_t *__restrict__ edited, size_t editedPitch,
@@ -147,7 +227,14 @@ int launch_annotation_pyramid(rtdd_ctx *ctx, int levels, uint8_t *const *scribbl
     }
     if (top == 0) { gx = (cols[0] + kApB - 1) / kApB; gy = (rows[0] + kApB - 1) / kApB; }
     if (gx < 1 || gy < 1) return RTDD_OK;
-    hipLaunchKernelGGL(k_annotation_pyramid, dim3(gx, gy, images), dim3(256), 0, ctx->stream, A);
+    const dim3 grid(gx, gy, images);
+    const int lds = ctx->opt.annotation_lds;
+    if (lds && top == 1) hipLaunchKernelGGL(k_annotation_pyramid_lds<1>, grid, dim3(256), 0, ctx->stream, A);
+    else if (lds && top == 2) hipLaunchKernelGGL(k_annotation_pyramid_lds<2>, grid, dim3(256), 0, ctx->stream, A);
+    else if (lds && top == 3) hipLaunchKernelGGL(k_annotation_pyramid_lds<3>, grid, dim3(256), 0, ctx->stream, A);
+    else if (lds && top == 4) hipLaunchKernelGGL(k_annotation_pyramid_lds<4>, grid, dim3(256), 0, ctx->stream, A);
+    else if (lds && top == 5) hipLaunchKernelGGL(k_annotation_pyramid_lds<5>, grid, dim3(256), 0, ctx->stream, A);
+    else hipLaunchKernelGGL(k_annotation_pyramid, grid, dim3(256), 0, ctx->stream, A);      // (deeper pyramids: the levels through global memory)
     RTDD_LAUNCH_CHECK(ctx, "k_annotation_pyramid");
     return RTDD_OK;
 }

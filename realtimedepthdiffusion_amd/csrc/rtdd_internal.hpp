@@ -77,6 +77,7 @@ struct Options {
     int debug_poll_limit_us = 0;     // RTDD_OPT_DEBUG_POLL_LIMIT_US: exchange poll limit (0 = default, 200 ms)
     int debug_force_status = 0;      // RTDD_OPT_DEBUG_FORCE_STATUS: one-shot value for the status word behind the next blocked launch
     int timeout_heal = 1;            // RTDD_OPT_TIMEOUT_HEAL: 1 a timed-out persistent launch is healed (calls logged, run again); 0 it is reported
+    int annotation_lds = 1;          // RTDD_OPT_ANNOTATION_LDS: the annotation pyramid's chain of levels in LDS (pyramids of up to 6 levels); 0: through global memory
     int live_zero_copy = 1;          // RTDD_OPT_LIVE_ZERO_COPY: a live frame's u8 map is stored by the copy-back kernel straight into the host's page-locked buffer (0 never, 1 when no other frame is in flight, 2 always)
     int rearm_after = 64;            // RTDD_OPT_PERSISTENT_REARM_AFTER: solves without persistence after the first heal, doubling with every further one
 };

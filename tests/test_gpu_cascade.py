@@ -247,16 +247,18 @@ def test_live_frame_into_a_window_of_a_wider_page_locked_image(oracle, lut, zero
         assert (frame == 77).all()
 
 
-def test_annotation_pyramid_follows_every_write(oracle, lut):
-    """The coarse annotation levels are rebuilt by the first estimate after the annotation changed, not by every estimate
+@pytest.mark.parametrize("rows,cols,lds", [(270, 480, 1), (270, 480, 0), (333, 517, 1), (333, 517, 0), (67, 120, 1), (40, 33, 1)])
+def test_annotation_pyramid_follows_every_write(oracle, lut, rows, cols, lds):
+    """(Both forms of the one-launch pyramid kernel: levels walked in LDS / read back from global memory -- RTDD_OPT_ANNOTATION_LDS.)
+    The coarse annotation levels are rebuilt by the first estimate after the annotation changed, not by every estimate
     (src/main.cpp:249-259 does it every time; K6 only ever adds, so the images are the same).  Every library call that writes the
     annotation must be noticed: rtdd_paint_image on the pyramid's own level-0 images, rtdd_upload, set_annotation; and a caller
     that writes through the raw pointers says so (rtdd_pyramid_annotation_changed)."""
-    rows, cols = 270, 480
     bgr, ann = _bgr(rows, cols, 5)
     ref = Cascade(oracle, bgr, ann, lut, 1, threads=4)
     with rt.Context(0) as c:
         c.GPULoadWeights(0.4)
+        c.set_option(rt.OPT_ANNOTATION_LDS, lds)
         levels = c.pyramid_create(rows, cols)
         c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann))
 
@@ -269,18 +271,18 @@ def test_annotation_pyramid_follows_every_write(oracle, lut):
 
         check("cold"); check("unchanged annotation")
         sp, spitch, _, _ = c.pyramid_image(rt.IMG_SCRIBBLE, 0); ep, epitch, _, _ = c.pyramid_image(rt.IMG_EDITED, 0)
-        oracle.paint_image(100, 90, 64, 11, ref.edited[0], ref.scribble[0])
-        c.GPUPaintImage(100, 90, 64, 11, (ep, epitch), (sp, spitch), rows, cols)
+        oracle.paint_image(cols // 5, rows // 3, 64, 11, ref.edited[0], ref.scribble[0])
+        c.GPUPaintImage(cols // 5, rows // 3, 64, 11, (ep, epitch), (sp, spitch), rows, cols)
         check("after rtdd_paint_image")
         def upload(ctx_, host, ptr, pitch, width):
             host = np.ascontiguousarray(host)
             ctx_._check(rt.lib().rtdd_upload(ctx_._h, C.c_void_p(ptr), C.c_size_t(pitch), C.c_void_p(host.ctypes.data), C.c_size_t(width), C.c_size_t(width), C.c_int(rows)))
 
-        oracle.paint_image(300, 200, 192, 15, ref.edited[0], ref.scribble[0])
+        oracle.paint_image(cols * 5 // 8, rows * 3 // 4, 192, 15, ref.edited[0], ref.scribble[0])
         upload(c, ref.scribble[0], sp, spitch, cols); upload(c, ref.edited[0], ep, epitch, cols * 3)
         check("after rtdd_upload into the pyramid's images")
         # through the raw pointers, behind this context's back (another context's copy): the caller has to say so
-        oracle.paint_image(40, 30, 0, 21, ref.edited[0], ref.scribble[0])
+        oracle.paint_image(cols // 12, rows // 9, 0, 21, ref.edited[0], ref.scribble[0])
         with rt.Context(0) as other:
             upload(other, ref.scribble[0], sp, spitch, cols); upload(other, ref.edited[0], ep, epitch, cols * 3)
         c.pyramid_annotation_changed()
