@@ -331,7 +331,9 @@ int rtdd_pyrdown_gray(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, int ro
 int rtdd_pyrup_depth(rtdd_ctx *ctx, const float *src, size_t srcPitch, int rows, int cols,
                      float *dst, size_t dstPitch, int dstRows, int dstCols);
 int rtdd_depth_to_u8(rtdd_ctx *ctx, const float *src, size_t srcPitch, uint8_t *dst, size_t dstPitch, int rows, int cols);
-/* pitched host<->device copies on the context's stream, then a stream sync (harness / binding convenience) */
+/* pitched host<->device copies on the context's stream, then a stream sync (harness / binding convenience).  Any host pitch: a
+ * contiguous host image whose pitch is no multiple of four (an odd-width cv::Mat) goes as one linear copy through a device buffer --
+ * the runtime's own 2-D copy takes ~9 us per row for such a pitch.  rtdd_live_submit's copies do the same. */
 int rtdd_upload(rtdd_ctx *ctx, void *dev, size_t devPitch, const void *host, size_t hostPitch, size_t widthBytes, int rows);
 int rtdd_download(rtdd_ctx *ctx, void *host, size_t hostPitch, const void *dev, size_t devPitch, size_t widthBytes, int rows);
 

@@ -289,6 +289,7 @@ int rtdd_ctx_destroy(rtdd_ctx *ctx) {
     if (ctx->residual_dev) (void)hipFree(ctx->residual_dev);
     if (ctx->sync_words) (void)hipFree(ctx->sync_words);
     if (ctx->sat) (void)hipFree(ctx->sat);
+    if (ctx->bounce.ptr) (void)hipFree(ctx->bounce.ptr);
     if (ctx->confirm_host) (void)hipHostFree(ctx->confirm_host);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     delete ctx;

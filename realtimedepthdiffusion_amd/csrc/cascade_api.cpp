@@ -45,6 +45,7 @@ struct Live {
     // frame's u8 map is written by the estimate's copy-back into RTDD_IMG_DEPTH_U8 AND into the frame's slot (k_finish: two targets).
     // The pyramid's own annotation buffers are kept here and put back before the pyramid is freed.
     void *own_scribble = nullptr, *own_edited = nullptr;
+    Bounce bounce_up, bounce_down;          // (copy_h2d / copy_d2h on the upload and the download stream; a lone frame's upload, on the compute stream, takes the context's)
 };
 
 // The device's name for a page-locked host image (every byte of rows x cols at `pitch` inside one registered range), or nullptr.  Asked
@@ -58,6 +59,34 @@ static uint8_t *live_device_view(const uint8_t *host, size_t pitch, int rows, in
         dev = (uint8_t *)a0.devicePointer;
     else (void)hipGetLastError();                                   // (an ordinary host pointer: the query fails, nothing else has)
     return dev;
+}
+
+// hipMemcpy2DAsync between host and device takes ~9 us PER ROW when the host pitch is no multiple of four -- 8 ms for one plane of a 910-pixel-wide
+// image (the dataset's Arara) where an aligned pitch takes 25 us (profiles/r05_copy2d_pitch.txt).  A host image with such a pitch whose
+// rows are contiguous (what a continuous cv::Mat or a numpy array is) moves as ONE linear copy through a contiguous device buffer and a
+// re-pitching kernel on the same stream; any other layout takes the runtime's copy as it is.
+static bool wants_bounce(size_t hostPitch, size_t widthBytes, int rows) { return hostPitch % 4 != 0 && hostPitch == widthBytes && rows > 1; }
+static int bounce_reserve(rtdd_ctx *ctx, Bounce &b, size_t bytes, hipStream_t stream) {
+    if (b.bytes >= bytes) return RTDD_OK;
+    if (b.ptr) { RTDD_HIP(ctx, hipStreamSynchronize(stream)); RTDD_HIP(ctx, hipFree(b.ptr)); b.ptr = nullptr; b.bytes = 0; }
+    RTDD_HIP(ctx, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return RTDD_OK;
+}
+int copy_h2d(rtdd_ctx *ctx, Bounce &b, void *dev, size_t devPitch, const void *host, size_t hostPitch, size_t widthBytes, int rows, hipStream_t stream) {
+    if (!wants_bounce(hostPitch, widthBytes, rows)) { RTDD_HIP(ctx, hipMemcpy2DAsync(dev, devPitch, host, hostPitch, widthBytes, rows, hipMemcpyHostToDevice, stream)); return RTDD_OK; }
+    const int rc = bounce_reserve(ctx, b, widthBytes * (size_t)rows, stream);
+    if (rc != RTDD_OK) return rc;
+    RTDD_HIP(ctx, hipMemcpyAsync(b.ptr, host, widthBytes * (size_t)rows, hipMemcpyHostToDevice, stream));
+    return launch_repitch(ctx, stream, b.ptr, widthBytes, dev, devPitch, widthBytes, rows);
+}
+int copy_d2h(rtdd_ctx *ctx, Bounce &b, void *host, size_t hostPitch, const void *dev, size_t devPitch, size_t widthBytes, int rows, hipStream_t stream) {
+    if (!wants_bounce(hostPitch, widthBytes, rows)) { RTDD_HIP(ctx, hipMemcpy2DAsync(host, hostPitch, dev, devPitch, widthBytes, rows, hipMemcpyDeviceToHost, stream)); return RTDD_OK; }
+    int rc = bounce_reserve(ctx, b, widthBytes * (size_t)rows, stream);
+    if (rc != RTDD_OK) return rc;
+    if ((rc = launch_repitch(ctx, stream, dev, devPitch, b.ptr, widthBytes, widthBytes, rows)) != RTDD_OK) return rc;
+    RTDD_HIP(ctx, hipMemcpyAsync(host, b.ptr, widthBytes * (size_t)rows, hipMemcpyDeviceToHost, stream));
+    return RTDD_OK;
 }
 
 static bool inside(const Image &im, const void *p) {
@@ -100,6 +129,8 @@ static void live_free(Pyramid *p) {
         for (hipEvent_t e : {v->h2d_done[k], v->est_done[k], v->d2h_done[k]}) if (e) (void)hipEventDestroy(e);
     }
     if (v->status_host) (void)hipHostFree(v->status_host);
+    if (v->bounce_up.ptr) (void)hipFree(v->bounce_up.ptr);
+    if (v->bounce_down.ptr) (void)hipFree(v->bounce_down.ptr);
     delete v;
     p->live = nullptr;
 }
@@ -361,7 +392,7 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
     if (v->frame[k].direct) RTDD_HIP(ctx, hipEventSynchronize(v->d2h_done[k]));
     else {
         RTDD_HIP(ctx, hipEventSynchronize(v->est_done[k]));
-        RTDD_HIP(ctx, hipMemcpy2DAsync(v->frame[k].host, v->frame[k].pitch, v->u8_stage[k].ptr, v->u8_stage[k].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, v->copy));
+        { const int rc_ = copy_d2h(ctx, v->bounce_down, v->frame[k].host, v->frame[k].pitch, v->u8_stage[k].ptr, v->u8_stage[k].pitch, (size_t)p->cols, p->rows, v->copy); if (rc_ != RTDD_OK) return rc_; }
         RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
         RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
     }
@@ -383,7 +414,11 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
     for (unsigned long long f = v->waited; f < v->submitted; f++) {
         const int j = (int)(f % 2);
         // (a frame whose map the copy-back kernel stores in the host's buffer itself has just been run again into that buffer)
-        if (!v->frame[j].direct) RTDD_HIP(ctx, hipMemcpy2D(v->frame[j].host, v->frame[j].pitch, v->u8_stage[j].ptr, v->u8_stage[j].pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost));
+        if (!v->frame[j].direct) {
+            const int rc_ = copy_d2h(ctx, v->bounce_down, v->frame[j].host, v->frame[j].pitch, v->u8_stage[j].ptr, v->u8_stage[j].pitch, (size_t)p->cols, p->rows, v->copy);
+            if (rc_ != RTDD_OK) return rc_;
+            RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
+        }
         v->status_host[8 * j + kSyncStatus] = 0;
     }
     v->frame[k].in_flight = false; v->waited++;
@@ -413,8 +448,9 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
         // streams: 1080p 1.335 -> 1.324 ms one frame at a time, 4K 2.21 -> 2.18)
         const bool lone = v->submitted == v->waited;
         hipStream_t us = lone ? ctx->stream : v->up;
-        RTDD_HIP(ctx, hipMemcpy2DAsync(v->scribble_stage[u].ptr, v->scribble_stage[u].pitch, hostScribble, scribblePitch, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, us));
-        RTDD_HIP(ctx, hipMemcpy2DAsync(v->edited_stage[u].ptr, v->edited_stage[u].pitch, hostEdited, editedPitch, (size_t)p->cols * 3, p->rows, hipMemcpyHostToDevice, us));
+        Bounce &bu = lone ? ctx->bounce : v->bounce_up;
+        if ((rc = copy_h2d(ctx, bu, v->scribble_stage[u].ptr, v->scribble_stage[u].pitch, hostScribble, scribblePitch, (size_t)p->cols, p->rows, us)) != RTDD_OK) return rc;
+        if ((rc = copy_h2d(ctx, bu, v->edited_stage[u].ptr, v->edited_stage[u].pitch, hostEdited, editedPitch, (size_t)p->cols * 3, p->rows, us)) != RTDD_OK) return rc;
         if (!lone) {
             RTDD_HIP(ctx, hipEventRecord(v->h2d_done[k], v->up));
             RTDD_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->h2d_done[k], 0));
@@ -593,7 +629,7 @@ int rtdd_upload(rtdd_ctx *ctx, void *dev, size_t devPitch, const void *host, siz
     // the destination may be an input of a logged call that still has to be run again: settle first (this call synchronises anyway)
     { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     pyramid_note_write(ctx, dev, dev);
-    RTDD_HIP(ctx, hipMemcpy2DAsync(dev, devPitch, host, hostPitch, widthBytes, rows, hipMemcpyHostToDevice, ctx->stream));
+    { const int rc_ = copy_h2d(ctx, ctx->bounce, dev, devPitch, host, hostPitch, widthBytes, rows, ctx->stream); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTDD_OK;
 }
@@ -602,12 +638,12 @@ int rtdd_download(rtdd_ctx *ctx, void *host, size_t hostPitch, const void *dev, 
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, dev && host && rows >= 0 && devPitch >= widthBytes && hostPitch >= widthBytes, "bad argument");
     DeviceGuard g(ctx->device);
-    RTDD_HIP(ctx, hipMemcpy2DAsync(host, hostPitch, dev, devPitch, widthBytes, rows, hipMemcpyDeviceToHost, ctx->stream));
+    { const int rc_ = copy_d2h(ctx, ctx->bounce, host, hostPitch, dev, devPitch, widthBytes, rows, ctx->stream); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int heals = ctx->heals;
     const int rc = check_persistent_status(ctx);  // what was just downloaded may come from a persistent launch that gave up ...
     if (rc != RTDD_OK || ctx->heals == heals) return rc;
-    RTDD_HIP(ctx, hipMemcpy2DAsync(host, hostPitch, dev, devPitch, widthBytes, rows, hipMemcpyDeviceToHost, ctx->stream));   // ... and has been run again since
+    { const int rc_ = copy_d2h(ctx, ctx->bounce, host, hostPitch, dev, devPitch, widthBytes, rows, ctx->stream); if (rc_ != RTDD_OK) return rc_; }   // ... and has been run again since
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTDD_OK;
 }

@@ -192,6 +192,23 @@ __global__ __launch_bounds__(256) void k_paint(int x0, int y0, int x1, int y1, i
     scribble[(size_t)y * scribblePitch + x] = 255;
 }
 
+// rows of `width` bytes from one pitch to another (copy_h2d / copy_d2h: one side is a contiguous buffer whose row length is no multiple
+// of four, so bytes; 3 MB in ~6 us)
+__global__ __launch_bounds__(256) void k_repitch(const uint8_t *__restrict__ src, size_t sp, uint8_t *__restrict__ dst, size_t dp, size_t width, int rows) {
+    const size_t x = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int y0 = blockIdx.y * 8;
+    if (x >= width) return;
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (y0 + i < rows) dst[(size_t)(y0 + i) * dp + x] = src[(size_t)(y0 + i) * sp + x];
+}
+
+int launch_repitch(rtdd_ctx *ctx, hipStream_t stream, const void *src, size_t srcPitch, void *dst, size_t dstPitch, size_t widthBytes, int rows) {
+    if (rows <= 0 || widthBytes == 0) return RTDD_OK;
+    hipLaunchKernelGGL(k_repitch, dim3((unsigned)((widthBytes + 255) / 256), (unsigned)((rows + 7) / 8)), dim3(256), 0, stream, (const uint8_t *)src, srcPitch, (uint8_t *)dst, dstPitch, widthBytes, rows);
+    RTDD_LAUNCH_CHECK(ctx, "k_repitch");
+    return RTDD_OK;
+}
+
 static inline dim3 grid64x4(int rows, int cols, int images = 1) { return dim3((cols + 63) / 64, (rows + 3) / 4, images); }
 
 int launch_convert(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, float *dst, size_t dstPitch,

@@ -116,6 +116,12 @@ constexpr int kMaxRearms = 4;             // heals after which persistence stays
 
 namespace rtdd { struct Pyramid; struct MgState; }
 
+namespace rtdd {
+// A contiguous device buffer a host image with an unaligned pitch goes through (one per stream that copies: uses of one buffer are
+// ordered by that stream).
+struct Bounce { void *ptr = nullptr; size_t bytes = 0; };
+}
+
 struct rtdd_ctx {
     int device = 0;
     rtdd::Pyramid *pyr = nullptr;       // whole-estimate driver state (cascade_api.cpp)
@@ -166,6 +172,7 @@ struct rtdd_ctx {
     int guard_seq = 0;              // sequence number the next guarded copy-back kernel reports when it finds the status word set
     bool persistent_used = false;   // a launch that can set the status word (sync_words[kSyncStatus]) happened since the last status check
     signed char persist_fit[17][2];  // per (tile id, contraction): does one workgroup of the persistent kernel fit a CU of THIS device (-1 = not asked yet)
+    rtdd::Bounce bounce;            // host <-> device 2-D copies with an unaligned host pitch, on ctx->stream (copy_h2d / copy_d2h, cascade_api.cpp)
     uint32_t *sat = nullptr;        // defocus summed-area table scratch
     size_t sat_elems = 0;
     int sat_rows = 0, sat_cols = 0;     // the geometry the table's zero padding was laid out for (effect_kernels.hip)
@@ -254,6 +261,9 @@ int launch_pyrdown_annotation(rtdd_ctx *ctx, const uint8_t *ps, size_t psp, cons
 // the annotation pyramid of an estimate (levels 1 .. levels-1 from level 0) and the coarsest level's injection, one launch (image_kernels.hip)
 int launch_annotation_pyramid(rtdd_ctx *ctx, int levels, uint8_t *const *scribble, const size_t *sp, const size_t *zs, uint8_t *const *edited, const size_t *ep, const size_t *ze,
                               const int *rows, const int *cols, float *depth, size_t dp, size_t zd, int images);
+int launch_repitch(rtdd_ctx *ctx, hipStream_t stream, const void *src, size_t srcPitch, void *dst, size_t dstPitch, size_t widthBytes, int rows);
+int copy_h2d(rtdd_ctx *ctx, Bounce &b, void *dev, size_t devPitch, const void *host, size_t hostPitch, size_t widthBytes, int rows, hipStream_t stream);
+int copy_d2h(rtdd_ctx *ctx, Bounce &b, void *host, size_t hostPitch, const void *dev, size_t devPitch, size_t widthBytes, int rows, hipStream_t stream);
 int launch_paint(rtdd_ctx *ctx, int x, int y, int color, int radius, uint8_t *edited, size_t editedPitch,
                  uint8_t *scribble, size_t scribblePitch, int rows, int cols);
 

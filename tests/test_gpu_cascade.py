@@ -223,6 +223,52 @@ def test_live_frames_pipelined_match_the_oracle(oracle, lut, withhold, out_kind)
             c.live_wait()                                                           # nothing in flight
 
 
+@pytest.mark.parametrize("width,host_pitch", [(910, 910), (2730, 2730), (517, 517), (33, 33), (910, 912), (911, 915), (1, 1), (64, 64)])
+def test_upload_and_download_with_any_host_pitch(width, host_pitch):
+    """rtdd_upload / rtdd_download move a host image whose pitch is no multiple of four through a contiguous device buffer (the runtime's 2-D
+    copy takes ~9 us per ROW then: 8 ms for the dataset's 910-pixel-wide Arara); whatever the route, the bytes arrive, and only they."""
+    import torch
+    rows = 37
+    rng = np.random.default_rng(width)
+    host = rng.integers(0, 256, (rows, host_pitch), dtype=np.uint8)
+    with rt.Context(0) as c:
+        dev = torch.full((rows + 2, 1024 if width <= 1024 else 3072), 7, dtype=torch.uint8, device="cuda:0")
+        dp = dev.stride(0)
+        c._check(rt.lib().rtdd_upload(c._h, C.c_void_p(dev[1].data_ptr()), C.c_size_t(dp), C.c_void_p(host.ctypes.data), C.c_size_t(host_pitch), C.c_size_t(width), C.c_int(rows)))
+        got = dev.cpu().numpy()
+        assert np.array_equal(got[1:1 + rows, :width], host[:, :width])
+        assert (got[0] == 7).all() and (got[-1] == 7).all() and (got[1:1 + rows, width:] == 7).all()
+        back = np.full((rows, host_pitch), 9, np.uint8)
+        c._check(rt.lib().rtdd_download(c._h, C.c_void_p(back.ctypes.data), C.c_size_t(host_pitch), C.c_void_p(dev[1].data_ptr()), C.c_size_t(dp), C.c_size_t(width), C.c_int(rows)))
+        assert np.array_equal(back[:, :width], host[:, :width]) and (back[:, width:] == 9).all()
+
+
+@pytest.mark.parametrize("pageable", [False, True])
+def test_live_frames_of_an_odd_width(oracle, lut, pageable):
+    """Pipelined live frames of an image whose width is no multiple of four (contiguous host images: pitches 241 and 723): uploads and the
+    staged download take the contiguous route; every map is the oracle's."""
+    rows, cols = 135, 241
+    bgr, ann = _bgr(rows, cols, 12)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=4)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        c.pyramid_create(rows, cols)
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann)); c.synchronize()
+        mk = _Pageable if pageable else rt.host_image
+        scr = mk((rows, cols)); ed = mk((rows, cols, 3)); out = [mk((rows, cols)) for _ in range(2)]
+        scr.a[...] = ref.scribble[0]; ed.a[...] = ref.edited[0]
+        got = []
+        for n in range(4):
+            if n >= 2:
+                c.live_wait(); got.append(out[n % 2].a.copy())
+            c.live_submit(scr.a, ed.a, out[n % 2].a, 1000)
+        while c.live_pending():
+            k = len(got); c.live_wait(); got.append(out[k % 2].a.copy())
+        for n in range(4):
+            ref.estimate(1000)
+            assert np.array_equal(got[n], ref.depth_u8), f"frame {n}"
+
+
 @pytest.mark.parametrize("zero_copy", [1, 2])
 def test_live_frame_into_a_window_of_a_wider_page_locked_image(oracle, lut, zero_copy):
     """The host's map may be a window of a larger page-locked image (a pitch of its own, an interior first pixel): the copy-back kernel
