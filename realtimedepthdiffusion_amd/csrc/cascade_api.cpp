@@ -1,6 +1,7 @@
 // cascade_api.cpp -- pyramid state and the whole-estimate driver (include/rtdd.h, "whole-estimate
 // driver").  Follows /root/reference/src/main.cpp:92-155 (setup) and :232-295 (estimate).
 #include <cmath>
+#include <cstring>
 #include <new>
 
 #include "rtdd_internal.hpp"
@@ -45,7 +46,8 @@ struct Live {
     // frame's u8 map is written by the estimate's copy-back into RTDD_IMG_DEPTH_U8 AND into the frame's slot (k_finish: two targets).
     // The pyramid's own annotation buffers are kept here and put back before the pyramid is freed.
     void *own_scribble = nullptr, *own_edited = nullptr;
-    Bounce bounce_up, bounce_down;          // (copy_h2d / copy_d2h on the upload and the download stream; a lone frame's upload, on the compute stream, takes the context's)
+    Bounce bounce_up[2][2];                 // ([frame parity][scribble, edited]: uploads of images with an unaligned host pitch, rtdd_live_submit)
+    uint8_t *host_bounce = nullptr; size_t host_bounce_bytes = 0;      // page-locked: a staged map on its way to a host image with an unaligned pitch (live_fetch)
 };
 
 // The device's name for a page-locked host image (every byte of rows x cols at `pitch` inside one registered range), or nullptr.  Asked
@@ -129,8 +131,8 @@ static void live_free(Pyramid *p) {
         for (hipEvent_t e : {v->h2d_done[k], v->est_done[k], v->d2h_done[k]}) if (e) (void)hipEventDestroy(e);
     }
     if (v->status_host) (void)hipHostFree(v->status_host);
-    if (v->bounce_up.ptr) (void)hipFree(v->bounce_up.ptr);
-    if (v->bounce_down.ptr) (void)hipFree(v->bounce_down.ptr);
+    for (auto &bb : v->bounce_up) for (Bounce &b : bb) if (b.ptr) (void)hipFree(b.ptr);
+    if (v->host_bounce) (void)hipHostFree(v->host_bounce);
     delete v;
     p->live = nullptr;
 }
@@ -382,6 +384,30 @@ int rtdd_live_pending(rtdd_ctx *ctx) {
     return (int)(ctx->pyr->live->submitted - ctx->pyr->live->waited);
 }
 
+// Frame k's staged u8 map (and the control words) to the host, on the copy stream, and wait.  A host image whose pitch is no multiple of
+// four: the staged image comes over WHOLE -- its rows, padding included, are one contiguous block -- into a page-locked buffer and
+// the host copies the rows out; the runtime's 2-D copy takes 9 us per row for such a pitch, and a re-pitching kernel on the copy stream
+// would queue behind the next frame's persistent launches (1921 x 1081: 1.39 ms per pipelined frame).
+static int live_fetch(rtdd_ctx *ctx, Live *v, int k) {
+    Pyramid *p = ctx->pyr;
+    const Live::Frame &f = v->frame[k];
+    const Image &st = v->u8_stage[k];
+    const bool via_host = f.pitch % 4 != 0 && p->rows > 1;
+    if (via_host) {
+        const size_t bytes = st.pitch * (size_t)p->rows;
+        if (v->host_bounce_bytes < bytes) {
+            if (v->host_bounce) { RTDD_HIP(ctx, hipStreamSynchronize(v->copy)); RTDD_HIP(ctx, hipHostFree(v->host_bounce)); v->host_bounce = nullptr; v->host_bounce_bytes = 0; }
+            RTDD_HIP(ctx, hipHostMalloc((void **)&v->host_bounce, bytes, hipHostMallocDefault));
+            v->host_bounce_bytes = bytes;
+        }
+        RTDD_HIP(ctx, hipMemcpyAsync(v->host_bounce, st.ptr, bytes, hipMemcpyDeviceToHost, v->copy));
+    } else RTDD_HIP(ctx, hipMemcpy2DAsync(f.host, f.pitch, st.ptr, st.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, v->copy));
+    RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
+    RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
+    if (via_host) for (int y = 0; y < p->rows; y++) std::memcpy(f.host + (size_t)y * f.pitch, v->host_bounce + (size_t)y * st.pitch, (size_t)p->cols);
+    return RTDD_OK;
+}
+
 int rtdd_live_wait(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     if (!ctx->pyr || !ctx->pyr->live || ctx->pyr->live->submitted == ctx->pyr->live->waited) return fail(ctx, RTDD_ERR_STATE, "no frame in flight");
@@ -392,9 +418,7 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
     if (v->frame[k].direct) RTDD_HIP(ctx, hipEventSynchronize(v->d2h_done[k]));
     else {
         RTDD_HIP(ctx, hipEventSynchronize(v->est_done[k]));
-        { const int rc_ = copy_d2h(ctx, v->bounce_down, v->frame[k].host, v->frame[k].pitch, v->u8_stage[k].ptr, v->u8_stage[k].pitch, (size_t)p->cols, p->rows, v->copy); if (rc_ != RTDD_OK) return rc_; }
-        RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
-        RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
+        { const int rc_ = live_fetch(ctx, v, k); if (rc_ != RTDD_OK) return rc_; }
     }
     if (v->status_host[8 * k + kSyncStatus] == 0) {                                 // the usual case: the frame is good, and so is everything logged before it
         size_t n = 0;
@@ -414,11 +438,7 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
     for (unsigned long long f = v->waited; f < v->submitted; f++) {
         const int j = (int)(f % 2);
         // (a frame whose map the copy-back kernel stores in the host's buffer itself has just been run again into that buffer)
-        if (!v->frame[j].direct) {
-            const int rc_ = copy_d2h(ctx, v->bounce_down, v->frame[j].host, v->frame[j].pitch, v->u8_stage[j].ptr, v->u8_stage[j].pitch, (size_t)p->cols, p->rows, v->copy);
-            if (rc_ != RTDD_OK) return rc_;
-            RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
-        }
+        if (!v->frame[j].direct) { const int rc_ = live_fetch(ctx, v, j); if (rc_ != RTDD_OK) return rc_; }
         v->status_host[8 * j + kSyncStatus] = 0;
     }
     v->frame[k].in_flight = false; v->waited++;
@@ -448,13 +468,25 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
         // streams: 1080p 1.335 -> 1.324 ms one frame at a time, 4K 2.21 -> 2.18)
         const bool lone = v->submitted == v->waited;
         hipStream_t us = lone ? ctx->stream : v->up;
-        Bounce &bu = lone ? ctx->bounce : v->bounce_up;
-        if ((rc = copy_h2d(ctx, bu, v->scribble_stage[u].ptr, v->scribble_stage[u].pitch, hostScribble, scribblePitch, (size_t)p->cols, p->rows, us)) != RTDD_OK) return rc;
-        if ((rc = copy_h2d(ctx, bu, v->edited_stage[u].ptr, v->edited_stage[u].pitch, hostEdited, editedPitch, (size_t)p->cols * 3, p->rows, us)) != RTDD_OK) return rc;
+        // A host image whose pitch is no multiple of four (copy_h2d above) goes as one linear copy into a contiguous buffer of this
+        // frame's parity on the upload stream, and is re-pitched into the staging image by a kernel on the COMPUTE stream, behind the
+        // upload's event: on the upload stream that kernel would queue behind the running frame's persistent launches.  (The buffer is
+        // written again two frames later, after this frame has been waited for.)
+        struct { const uint8_t *host; size_t hp, width; Image *dst; Bounce *b; bool bounce; } ups[2] = {
+            {hostScribble, scribblePitch, (size_t)p->cols, &v->scribble_stage[u], &v->bounce_up[k][0], false},
+            {hostEdited, editedPitch, (size_t)p->cols * 3, &v->edited_stage[u], &v->bounce_up[k][1], false}};
+        for (auto &q : ups) {
+            q.bounce = wants_bounce(q.hp, q.width, p->rows);
+            if (!q.bounce) { RTDD_HIP(ctx, hipMemcpy2DAsync(q.dst->ptr, q.dst->pitch, q.host, q.hp, q.width, p->rows, hipMemcpyHostToDevice, us)); continue; }
+            if ((rc = bounce_reserve(ctx, *q.b, q.width * (size_t)p->rows, ctx->stream)) != RTDD_OK) return rc;
+            RTDD_HIP(ctx, hipMemcpyAsync(q.b->ptr, q.host, q.width * (size_t)p->rows, hipMemcpyHostToDevice, us));
+        }
         if (!lone) {
             RTDD_HIP(ctx, hipEventRecord(v->h2d_done[k], v->up));
             RTDD_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->h2d_done[k], 0));
         }
+        for (auto &q : ups)
+            if (q.bounce && (rc = launch_repitch(ctx, ctx->stream, q.b->ptr, q.width, q.dst->ptr, q.dst->pitch, q.width, p->rows)) != RTDD_OK) return rc;
         p->scribble[0].ptr = v->scribble_stage[u].ptr; p->edited[0].ptr = v->edited_stage[u].ptr;      // the pyramid's level-0 annotation IS the uploaded pair: no copy
         p->annotation_dirty = true;
     }
