@@ -476,3 +476,50 @@ def test_a_healed_older_live_frame_runs_on_its_own_annotation(oracle, lut):
         assert np.array_equal(c.pyramid_download(rt.IMG_SCRIBBLE, 0), s2) and np.array_equal(c.pyramid_download(rt.IMG_DEPTH_U8), m2)
         for x in h + out:
             x.free()
+
+
+def test_no_device_memory_is_lost_over_context_lifetimes():
+    """Forty contexts come and go -- single pyramids with pipelined live frames (page-locked and odd-pitch host images, both defocus paths)
+    and batched pyramids, five sizes -- and the device's free memory afterwards is what it was before."""
+    import torch
+    probs = {}
+
+    def lifetime(i):
+        rows, cols = [(270, 480), (135, 241), (333, 517), (540, 960), (91, 90)][i % 5]
+        if (rows, cols) not in probs:
+            probs[(rows, cols)] = _bgr(rows, cols, 3)
+        bgr, ann = probs[(rows, cols)]
+        with rt.Context(0) as c:
+            c.GPULoadWeights(0.4)
+            dimg, dann = up(bgr), up(ann)
+            if i % 3 == 0:
+                c.pyramid_create_batch(rows, cols, 3)
+                for b in range(3):
+                    c.pyramid_select(b); c.pyramid_set_image(dimg); c.pyramid_set_annotation(dann)
+                c.estimate_depth_batch(100)
+            else:
+                c.pyramid_create(rows, cols); c.pyramid_set_image(dimg); c.pyramid_set_annotation(dann)
+                scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3)); out = rt.host_image((rows, cols))
+                scr.a[...] = c.pyramid_download(rt.IMG_SCRIBBLE, 0); ed.a[...] = c.pyramid_download(rt.IMG_EDITED, 0)
+                for _ in range(3):
+                    c.live_submit(scr.a, ed.a, out.a, 100)
+                while c.live_pending():
+                    c.live_wait()
+                d, dp, _, _ = c.pyramid_image(rt.IMG_DEPTH, 0); art = up(np.zeros_like(bgr))
+                c.GPUSimulateDefocus(dimg, (d, dp), art, rows, cols)
+                c.set_option(rt.OPT_DEFOCUS_PATH, 1); c.GPUSimulateDefocus(dimg, (d, dp), art, rows, cols)
+                c.synchronize()
+                for h in (scr, ed, out):
+                    h.free()
+            c.synchronize()
+
+    def free_bytes():
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+
+    for i in range(6):
+        lifetime(i)                                                      # (the runtime's own pools fill on first use)
+    before = free_bytes()
+    for i in range(40):
+        lifetime(i)
+    assert before - free_bytes() < (8 << 20)
