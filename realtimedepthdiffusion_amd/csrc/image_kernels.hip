@@ -192,19 +192,27 @@ __global__ __launch_bounds__(256) void k_paint(int x0, int y0, int x1, int y1, i
     scribble[(size_t)y * scribblePitch + x] = 255;
 }
 
-// rows of `width` bytes from one pitch to another (copy_h2d / copy_d2h: one side is a contiguous buffer whose row length is no multiple
-// of four, so bytes; 3 MB in ~6 us)
+// rows of `width` bytes from one pitch to another (copy_h2d / copy_d2h, rtdd_live_submit: one side is a contiguous buffer whose row length is
+// no multiple of four).  Four bytes per thread: one dword on whichever side allows it (gfx950 loads and stores dwords at any address:
+// the dword goes to the side whose rows are NOT aligned only if that is the only way), bytes on the other; 8 MB in ~10 us.
+typedef uint32_t __attribute__((aligned(1))) u32_any;
 __global__ __launch_bounds__(256) void k_repitch(const uint8_t *__restrict__ src, size_t sp, uint8_t *__restrict__ dst, size_t dp, size_t width, int rows) {
-    const size_t x = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t x = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const int y0 = blockIdx.y * 8;
     if (x >= width) return;
 #pragma unroll
-    for (int i = 0; i < 8; i++) if (y0 + i < rows) dst[(size_t)(y0 + i) * dp + x] = src[(size_t)(y0 + i) * sp + x];
+    for (int i = 0; i < 8; i++) {
+        if (y0 + i >= rows) break;
+        const uint8_t *s = src + (size_t)(y0 + i) * sp + x;
+        uint8_t *d = dst + (size_t)(y0 + i) * dp + x;
+        if (x + 3 < width) *(u32_any *)d = *(const u32_any *)s;
+        else for (size_t k = 0; x + k < width; k++) d[k] = s[k];
+    }
 }
 
 int launch_repitch(rtdd_ctx *ctx, hipStream_t stream, const void *src, size_t srcPitch, void *dst, size_t dstPitch, size_t widthBytes, int rows) {
     if (rows <= 0 || widthBytes == 0) return RTDD_OK;
-    hipLaunchKernelGGL(k_repitch, dim3((unsigned)((widthBytes + 255) / 256), (unsigned)((rows + 7) / 8)), dim3(256), 0, stream, (const uint8_t *)src, srcPitch, (uint8_t *)dst, dstPitch, widthBytes, rows);
+    hipLaunchKernelGGL(k_repitch, dim3((unsigned)((widthBytes + 1023) / 1024), (unsigned)((rows + 7) / 8)), dim3(256), 0, stream, (const uint8_t *)src, srcPitch, (uint8_t *)dst, dstPitch, widthBytes, rows);
     RTDD_LAUNCH_CHECK(ctx, "k_repitch");
     return RTDD_OK;
 }
