@@ -220,8 +220,28 @@ def estimate_ms(rt, ctx, p, rows, cols, dev, n=20):
         ctx.live_wait()
     ms_live = (time.perf_counter() - t) / frames * 1e3
     ctx.synchronize()
+    # the reference's frame WITH a sticky effect (src/main.cpp:190-230 in every iteration of the loop at :180, next to the estimate):
+    # the same pipelined loop, every frame also rendering the effect from its own depth map and bringing the artistic image to the host
+    arts = [rt.host_image((rows, cols, 3)) for _ in range(2)]
+    live_fx = {}
+    for name, code in (("defocus", rt.EFFECT_DEFOCUS), ("desaturation", rt.EFFECT_DESATURATION), ("haze", rt.EFFECT_HAZE)):
+        for f in range(4):
+            ctx.live_submit_ex(scr.a, ed.a, outs[f % 2].a, code, arts[f % 2].a, 1000); ctx.live_wait()
+        t = time.perf_counter()
+        for f in range(frames):
+            if f >= 2:
+                ctx.live_wait()
+            ctx.live_submit_ex(scr.a, ed.a, outs[f % 2].a, code, arts[f % 2].a, 1000)
+        while ctx.live_pending():
+            ctx.live_wait()
+        live_fx[name] = (time.perf_counter() - t) / frames * 1e3
+    t = time.perf_counter()
+    for _ in range(n):
+        ctx.live_submit_ex(scr.a, ed.a, outs[0].a, rt.EFFECT_DEFOCUS, arts[0].a, 1000); ctx.live_wait()
+    ms_e2e_fx = (time.perf_counter() - t) / n * 1e3
+    ctx.synchronize()
     ctx.pyramid_destroy()
-    for h in [scr, ed] + outs:
+    for h in [scr, ed] + outs + arts:
         h.free()
     h2d, d2h = rows * cols * 4, rows * cols
     return {"what": f"{cols}x{rows} {P}-level cascade, {pxit / 1e6:.1f} Mpixel-iterations, device-resident, annotation unchanged between estimates: the annotation pyramid is NOT rebuilt "
@@ -229,7 +249,111 @@ def estimate_ms(rt, ctx, p, rows, cols, dev, n=20):
             "Mpixel_iterations_per_s": pxit / ms / 1e3, "finest_level": kernels[0],
             "ms_end_to_end": ms_e2e, "end_to_end_is": f"src/main.cpp:234-293 as the reference clocks it: H2D of scribble + edited ({h2d / 1e6:.1f} MB, page-locked), annotation pyramid, cascade, "
                                                       f"D2H of the u8 map ({d2h / 1e6:.1f} MB), host waits for every frame",
-            "live_ms_per_frame": ms_live, "live_fps": 1e3 / ms_live, "live_is": "the same frames, two in flight: copies on a second stream overlap the other frame's arithmetic (rtdd_live_submit)"}
+            "live_ms_per_frame": ms_live, "live_fps": 1e3 / ms_live, "live_is": "the same frames, two in flight: copies on a second stream overlap the other frame's arithmetic (rtdd_live_submit)",
+            "live_ms_per_frame_defocus": live_fx["defocus"], "live_fps_defocus": 1e3 / live_fx["defocus"],
+            "live_ms_per_frame_desaturation": live_fx["desaturation"], "live_ms_per_frame_haze": live_fx["haze"], "ms_end_to_end_defocus": ms_e2e_fx,
+            "live_effect_is": f"the reference's frame with a sticky effect (src/main.cpp:190-230 + 232-295; rtdd_live_submit_ex): the same pipelined frames, each also rendering the effect from its own "
+                              f"depth map and downloading the artistic image ({rows * cols * 3 / 1e6:.1f} MB); ms_end_to_end_defocus: one such frame at a time"}
+
+
+def estimate_dataset(rt, dev, n=10):
+    """ms per estimate on the twelve bundled photographs at their own resolution (tests/golden/dataset: the reference's dataset/ pairs,
+    decoded): device-resident, warm-started, the annotation pyramid rebuilt every estimate as src/main.cpp:239-259 does.  Real photographs
+    cost more than the synthetic image of `estimate` (waves that meet denormal edge weights take the IEEE divide): the line says how much."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import dataset_util
+    except Exception as e:                       # (no PIL on this box, or the fixtures are absent)
+        return {"skipped": f"{type(e).__name__}: {e}"}
+    per = {}
+    ctx = rt.Context(int(dev.split(":")[1])); ctx.set_stream(torch.cuda.current_stream().cuda_stream); ctx.GPULoadWeights(0.4)
+    for name in dataset_util.PAIRS:
+        bgr, ann, _ = dataset_util.load_pair(name)
+        rows, cols = ann.shape
+        ctx.pyramid_create(rows, cols)
+        ctx.pyramid_set_image(rt.device_image(bgr, dev)); ctx.pyramid_set_annotation(rt.device_image(ann, dev))
+        for _ in range(3):
+            ctx.estimate_depth(1000)
+        ctx.synchronize(); t = time.perf_counter()
+        for _ in range(n):
+            ctx.pyramid_annotation_changed(); ctx.estimate_depth(1000)
+        ctx.synchronize()
+        per[name] = {"ms": round((time.perf_counter() - t) / n * 1e3, 4), "size": f"{cols}x{rows}"}
+    ctx.close()
+    ms = [v["ms"] for v in per.values()]
+    lo, hi = min(per, key=lambda k: per[k]["ms"]), max(per, key=lambda k: per[k]["ms"])
+    return {"min_ms": per[lo]["ms"], "min_is": f"{lo} {per[lo]['size']}", "max_ms": per[hi]["ms"], "max_is": f"{hi} {per[hi]['size']}", "mean_ms": sum(ms) / len(ms), "pairs": per,
+            "what": "the twelve bundled image / annotation pairs at their own resolution, device-resident whole estimates (annotation pyramid rebuilt every estimate), warm-started"}
+
+
+def dropin_frame(rt, dev, p, rows, cols, n=20):
+    """What an UNCHANGED main.cpp pays per depth estimate (src/main.cpp:239-291): the reference's ten functions through their Itanium-mangled
+    symbols (csrc/dropin.cpp, the process-global context on the null stream), one call after the other in main.cpp's order, the caller's own
+    pitched device images, GPUMatrixFreeSolver returning synchronised at every level (src/GPUSolver.cu:314) -- 4 x GPUPyrDownAnnotation,
+    GPUConvertToFloat, 5 x (GPUMatrixFreeSolver, pyrUp, GPUConvertToFloat), convertTo.  cv::cuda::pyrUp (:273) and GpuMat::convertTo (:290) are
+    OpenCV's on the reference side; the library's rtdd_pyrup_depth / rtdd_depth_to_u8 on the shim's context stand in for them.  Device-resident
+    like `estimate.ms` (no upload / download), warm-started, timed host-side over n frames.  Reported beside the fused rtdd_estimate_depth."""
+    import ctypes as C
+    import math
+    import numpy as np
+    import torch
+    L = rt.lib()
+    vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+
+    def fn(name):
+        f = getattr(L, name); f.restype = None
+        return f
+
+    def img(t):
+        return vp(t.data_ptr()), sz(t.stride(0) * t.element_size())
+    P = int(math.log2(max(min(cols, rows) // 45, 1)) + 1)
+    sizes = [(int(np.float32(rows) / np.float32(2.0) ** l), int(np.float32(cols) / np.float32(2.0) ** l)) for l in range(P)]
+    L.rtdd_dropin_context.restype = vp
+    h = vp(L.rtdd_dropin_context())
+    fn("_Z23GPUAllocateDeviceMemoryiii")(i32(rows), i32(cols), i32(P))
+    fn("_Z14GPULoadWeightsf")(f32(0.4))
+    # the caller's images (main.cpp:117-137), gray pyramid built once through the library's restated cv::pyrDown
+    gray = [rt.device_image(p["gray"], dev)]
+    for l in range(1, P):
+        gr, gc = gray[-1].shape
+        gray.append(rt.device_image(np.zeros(((gr + 1) // 2, (gc + 1) // 2), np.uint8), dev))
+        a, ap = img(gray[-2]); b, bp = img(gray[-1])
+        assert L.rtdd_pyrdown_gray(h, a, ap, i32(gr), i32(gc), b, bp) == 0
+    gray = [g[:s[0], :s[1]] for g, s in zip(gray, sizes)]                      # (the ceil chain's images, used at the floor sizes like main.cpp does)
+    edited = [rt.device_image(np.zeros(s + (3,), np.uint8), dev) for s in sizes]; scribble = [rt.device_image(np.zeros(s, np.uint8), dev) for s in sizes]
+    edited[0] = rt.device_image(p["edited"], dev); scribble[0] = rt.device_image(p["mask"], dev)
+    depth = [rt.device_image(np.full(s, 255.0, np.float32), dev) for s in sizes]
+    u8 = rt.device_image(np.zeros(sizes[0], np.uint8), dev)
+    pyrdown = fn("_Z20GPUPyrDownAnnotationPhmS_miiS_mS_mii"); convert = fn("_Z17GPUConvertToFloatPhmPfmS_mii"); solve = fn("_Z19GPUMatrixFreeSolverPfmPhmS0_miififi")
+
+    def frame():
+        for l in range(1, P):                                                   # :249-253
+            pyrdown(*img(scribble[l - 1]), *img(edited[l - 1]), i32(sizes[l - 1][0]), i32(sizes[l - 1][1]), *img(scribble[l]), *img(edited[l]), i32(sizes[l][0]), i32(sizes[l][1]))
+        convert(*img(edited[P - 1]), *img(depth[P - 1]), *img(scribble[P - 1]), i32(sizes[P - 1][0]), i32(sizes[P - 1][1]))      # :257
+        for l in range(P - 1, -1, -1):
+            iters = int(np.float32(1000) / np.float32(2.0) ** ((P - 1) - l))
+            solve(*img(depth[l]), *img(scribble[l]), *img(gray[l]), i32(sizes[l][0]), i32(sizes[l][1]), f32(0.4), i32(iters), f32(1e-5), i32(l))     # :266, returns synchronised
+            if l > 0:
+                a, ap = img(depth[l]); b, bp = img(depth[l - 1])
+                assert L.rtdd_pyrup_depth(h, a, ap, i32(sizes[l][0]), i32(sizes[l][1]), b, bp, i32(sizes[l - 1][0]), i32(sizes[l - 1][1])) == 0       # cv::cuda::pyrUp, :273
+                convert(*img(edited[l - 1]), *img(depth[l - 1]), *img(scribble[l - 1]), i32(sizes[l - 1][0]), i32(sizes[l - 1][1]))                  # :281
+        a, ap = img(depth[0]); b, bp = img(u8)
+        assert L.rtdd_depth_to_u8(h, a, ap, b, bp, i32(rows), i32(cols)) == 0      # convertTo, :290
+    for _ in range(3):
+        frame()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n):
+        frame()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / n * 1e3
+    info = rt.SolveInfo(); L.rtdd_last_solve_info(h, C.byref(info))
+    sha = __import__("hashlib").sha256(rt.to_host(u8).tobytes()).hexdigest()[:16]
+    fn("_Z19GPUFreeDeviceMemoryi")(i32(P))
+    return {"ms": ms, "what": f"the ten mangled symbols of include/*.h in main.cpp's order (src/main.cpp:239-291), {cols}x{rows}, {P} levels, device-resident, the caller's own pitched images, "
+                              "every GPUMatrixFreeSolver returning synchronised; rtdd_pyrup_depth / rtdd_depth_to_u8 stand in for cv::cuda::pyrUp / convertTo",
+            "calls_per_frame": (P - 1) + 1 + P + 2 * (P - 1) + 1, "device_syncs_per_frame": P, "finest_level": f"tile {info.tile}, persistent {info.persistent}", "u8_sha256_16": sha}
 
 
 def batch_estimates(rt, dev, rows=1080, cols=1920, images=64, reps=3):
@@ -264,6 +388,41 @@ def batch_estimates(rt, dev, rows=1080, cols=1920, images=64, reps=3):
             "batched_ms": ms_b, "batched_estimates_per_s": images / ms_b * 1e3, "batched_ms_per_estimate": ms_b / images,
             "sequential_ms": ms_s, "sequential_estimates_per_s": images / ms_s * 1e3, "speedup": ms_s / ms_b,
             "Mpixel_iterations_per_s": pxit / ms_b / 1e3}
+
+
+def verify_estimates(rt, ctx, problems, my_images, iters, levels, dev, world, sample=(0, 1, 7, 8, 31, 32, 62, 63)):
+    """The checker of the estimate workloads (outside the timed region): a sample of this rank's images -- the batch positions VERDICT r5
+    names where the rank owns them, else its first and last ones, 8 at most -- is put back into its cold state (rtdd_pyramid_set_image
+    resets the warm start), the WHOLE batch runs once more (same launches, same per-level choices as the timed steps: the choice depends on
+    the level's size and the batch size only), and every level + the u8 map of the sampled images is compared with the oracle's cascade
+    (src/main.cpp:232-295); then once more warm-started.  Returns (global indices that differ, global indices checked)."""
+    import numpy as np
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cascade_ref import Cascade
+    lut = oracle.load_weights(0.4)
+    local = [k for k, g in enumerate(my_images) if g in sample]
+    if len(local) < min(4, len(my_images)):
+        local = sorted(set(local) | set(range(min(2, len(my_images)))) | set(range(max(0, len(my_images) - 2), len(my_images))))
+    local = local[:8]
+    refs = {}
+    for k in local:
+        p = problems[k]
+        bgr = np.repeat(p["gray"][..., None], 3, 2); ann = np.where(p["mask"] == 255, p["edited"][..., 0], 32).astype(np.uint8)
+        ctx.pyramid_select(k); ctx.pyramid_set_image(rt.device_image(bgr, dev)); ctx.pyramid_set_annotation(rt.device_image(ann, dev))
+        refs[k] = Cascade(oracle, bgr, ann, lut, 1, threads=max(1, oracle.max_threads() // world))
+    bad = set()
+    for _ in range(2):
+        ctx.estimate_depth_batch(iters); ctx.synchronize()
+        for k in local:
+            refs[k].estimate(iters)
+            ctx.pyramid_select(k)
+            same = np.array_equal(ctx.pyramid_download(rt.IMG_DEPTH_U8), refs[k].depth_u8)
+            for l in range(levels):
+                same = same and np.array_equal(ctx.pyramid_download(rt.IMG_DEPTH, l).view(np.uint32), refs[k].depth[l].view(np.uint32))
+            if not same:
+                bad.add(my_images[k])
+    return sorted(bad), [my_images[k] for k in local]
 
 
 def sustained(step, sync, px_iter_per_step, seconds=3.0, window=0.5):
@@ -669,7 +828,16 @@ def main():
         out["estimates_per_s"] = batch * args.steps / elapsed if batch else None
         out.pop("roofline", None)              # (a chain of five levels' kernels: the per-kernel roofline is the single-level workloads')
     if args.verify and not dry and w.get("estimate"):
-        out["verified"] = {"against": "not available for estimate workloads here: tests/test_gpu_batch.py compares every level of every image with the single-image path and the oracle"}
+        bad, checked = verify_estimates(rt, ctx, problems, my_images, iters, levels_, dev, world)
+        flag = torch.tensor([len(bad), len(checked)], dtype=torch.float64, device=agg_dev)
+        if dist is not None:
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=tgroup)
+        out["verified"] = {"against": "the oracle's cascade (tests/cascade_ref.py over oracle/), bit for bit: every pyramid level's depth image and the u8 map of the sampled images, "
+                                      "in the batch the timed steps ran (same images, same per-level kernel choices): the sampled images reset to their cold state, one more batched "
+                                      "estimate (cold for them), then one warm-started", "images_differing_all_ranks": int(flag[0].item()), "images_checked_all_ranks": int(flag[1].item()),
+                           "rank0_images_checked": checked, "levels": levels_,
+                           "rank0_level_choices": {str(l): dict(zip(("tile", "sweeps_per_launch", "persistent", "images_per_launch"), (i.tile, i.temporal_depth, i.persistent, n)))
+                                                   for l in range(levels_) for i, n in [ctx.pyramid_level_info(l)]}}
     elif args.verify and not dry:
         # the checker (outside the timed region): each rank's results of the LAST step against the oracle on the host cores
         import hashlib
@@ -708,6 +876,10 @@ def main():
         out["estimate"] = estimate_ms(rt, c2, problems[0], rows, cols, dev)      # second half of BASELINE's metric
         out["estimate_4k"] = estimate_ms(rt, c2, make_problem(2160, 3840, seed=1234), 2160, 3840, dev, n=10)   # the 6-level 4K cascade (src/main.cpp:95,261-288)
         c2.close()
+        out["estimate_dataset"] = estimate_dataset(rt, dev)                        # what real photographs cost (beside the synthetic `estimate`)
+        out["dropin_frame"] = dropin_frame(rt, dev, problems[0], rows, cols)     # what an unchanged main.cpp pays: the ten symbols one by one
+        out["dropin_frame"]["vs_fused_estimate"] = out["dropin_frame"]["ms"] / out["estimate"]["ms_annotation_changed"]
+        out["dropin_frame"]["fused_is"] = "estimate.ms_annotation_changed (rtdd_estimate_depth with the annotation pyramid rebuilt every frame, as main.cpp does)"
         out["sweep_4k"] = sweep_4k(rt, dev)                                      # the north star's 4K stencil sweep
         out["sweep_8k"] = sweep_4k(rt, dev, steps=5, rows=4320, cols=7680, iters=200, name="8k_jacobi200")   # HBM-resident (564 MB working set)
         out["effects"] = effects(rt, dev)

@@ -146,8 +146,9 @@ int rtdd_version(void);                                  /* major * 100 + minor.
                                                           * rtdd_solve_ex / rtdd_refine_depth / rtdd_last_solve_info write the whole struct, so a
                                                           * caller compiled against a 1xx header must be rebuilt (#define RTDD_VERSION below).  210 adds
                                                           * rtdd_pyramid_annotation_changed, RTDD_OPT_TIMEOUT_HEALS and the self-healing time-out; 220: RTDD_OPT_TIMEOUT_HEAL,
-                                                          * persistence re-armed after a time-out, rtdd_estimate_depth_batch, RTDD_OPT_LIVE_ZERO_COPY */
-#define RTDD_VERSION 220
+                                                          * persistence re-armed after a time-out, rtdd_estimate_depth_batch, RTDD_OPT_LIVE_ZERO_COPY;
+                                                          * 230: rtdd_pyramid_level_info, rtdd_live_submit_ex */
+#define RTDD_VERSION 230
 
 /* ---- solver (include/GPUSolver.h:6-10) ------------------------------------------------------ */
 
@@ -286,6 +287,13 @@ int rtdd_pyramid_create_batch(rtdd_ctx *ctx, int rows, int cols, int images);
 int rtdd_pyramid_select(rtdd_ctx *ctx, int index);
 int rtdd_pyramid_batch(rtdd_ctx *ctx);                   /* the number of images of the context's pyramid (0: none) */
 int rtdd_estimate_depth_batch(rtdd_ctx *ctx, int maxIterations);   /* rtdd_estimate_depth for every image of the batch; asynchronous */
+/* What the most recent estimate ran on pyramid level `level` (0 = finest): the rtdd_solve_info of that level's solve, and how many images
+ * each of its sweep launches covered (a batch: all of them in the same launches, or 1 = image after image, each with the launch a single
+ * solve gets).  The choice is a function of the level's size AND of the batch size, so that a log line / a test can name the kernel
+ * configuration a timed batch actually ran (tests/test_gpu_batch.py pins the ones bench.py times).  info->temporal_depth is the NOMINAL
+ * number of sweeps per launch / exchange here (rtdd_last_solve_info reports the last launch's, which may be the short tail block; a level
+ * that is one tile runs all its sweeps in one launch).  imagesPerLaunch may be NULL. */
+int rtdd_pyramid_level_info(rtdd_ctx *ctx, int level, rtdd_solve_info *info, int *imagesPerLaunch);
 /* image: DEVICE pointer to an interleaved BGR u8 image; builds the gray pyramid, edited[0] := image, scribble[0] := 0 */
 int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch);
 /* annotation: DEVICE pointer to a 1-channel u8 map; decode rule of src/main.cpp:160-168 (value != 32 -> label, mask 255) */
@@ -313,9 +321,23 @@ int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations);
  * which only ever accumulate, may by then hold the newer frame's strokes too).  Results: hostDepthU8, and RTDD_IMG_DEPTH /
  * RTDD_IMG_DEPTH_U8 on the device as after rtdd_estimate_depth.  No staging copies: an uploaded annotation pair BECOMES the pyramid's
  * level-0 RTDD_IMG_SCRIBBLE / RTDD_IMG_EDITED -- pointers obtained from rtdd_pyramid_image for those two images are good until the
- * next rtdd_live_submit that uploads: ask again after it (every other image keeps its address). */
+ * next rtdd_live_submit that uploads: ask again after it (every other image keeps its address; a library call handed such a retired
+ * pointer -- rtdd_paint_image, rtdd_upload, rtdd_convert_to_float, rtdd_pyrdown_annotation -- fails with RTDD_ERR_STATE instead of
+ * writing a buffer no estimate reads). */
 int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribblePitch, const uint8_t *hostEdited, size_t editedPitch,
                      int maxIterations, uint8_t *hostDepthU8, size_t depthPitch);
+/* The reference's frame WITH a sticky depth effect (src/main.cpp:190-230: once 'b' / 'g' / 'h' has been pressed the effect is rendered
+ * and its image downloaded in every iteration of the loop at :180, next to the estimate at :232).  rtdd_live_submit plus: `effect` is
+ * rendered from the frame's own depth map (RTDD_IMG_ORIGINAL, RTDD_IMG_GRAY, RTDD_IMG_DEPTH level 0) by the effect's kernel queued
+ * right behind the estimate's copy-back, and the artistic image lands in hostArtistic (u8 x 3, page-locked for an asynchronous copy)
+ * by the time rtdd_live_wait returns for the frame: downloaded by rtdd_live_wait while the next frame computes when frames are
+ * pipelined, queued on the compute stream when no other frame is in flight.  RTDD_IMG_ARTISTIC then names the newest frame's image
+ * on the device (like the annotation pair: ask rtdd_pyramid_image again after a submit with an effect).  The reference renders the
+ * effect at the TOP of the next loop iteration from the same depth map -- the same sequence of artistic images, shown one iteration
+ * later.  RTDD_EFFECT_NONE: exactly rtdd_live_submit (hostArtistic ignored).  A healed time-out renders the effect again too. */
+enum rtdd_effect { RTDD_EFFECT_NONE = 0, RTDD_EFFECT_DEFOCUS = 1, RTDD_EFFECT_DESATURATION = 2, RTDD_EFFECT_HAZE = 3 };
+int rtdd_live_submit_ex(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribblePitch, const uint8_t *hostEdited, size_t editedPitch,
+                        int maxIterations, uint8_t *hostDepthU8, size_t depthPitch, int effect, uint8_t *hostArtistic, size_t artisticPitch);
 int rtdd_live_wait(rtdd_ctx *ctx);
 int rtdd_live_pending(rtdd_ctx *ctx);                    /* frames submitted and not yet waited for: 0..2 */
 int rtdd_host_alloc(void **ptr, size_t bytes);           /* page-locked host memory (hipHostMalloc) / its release */

@@ -47,9 +47,10 @@ C_ABI_SYMBOLS = [
     "rtdd_pyramid_set_annotation", "rtdd_pyramid_image", "rtdd_pyramid_annotation_changed", "rtdd_estimate_depth", "rtdd_refine_depth", "rtdd_bgr2gray", "rtdd_pyrdown_gray",
     "rtdd_pyrup_depth", "rtdd_depth_to_u8", "rtdd_upload", "rtdd_download",
     "rtdd_live_submit", "rtdd_live_wait", "rtdd_live_pending", "rtdd_host_alloc", "rtdd_host_free",
-    "rtdd_pyramid_create_batch", "rtdd_pyramid_select", "rtdd_pyramid_batch", "rtdd_estimate_depth_batch",
+    "rtdd_pyramid_create_batch", "rtdd_pyramid_select", "rtdd_pyramid_batch", "rtdd_estimate_depth_batch", "rtdd_pyramid_level_info", "rtdd_live_submit_ex",
 ]
 IMG_ORIGINAL, IMG_GRAY, IMG_SCRIBBLE, IMG_EDITED, IMG_DEPTH, IMG_DEPTH_U8, IMG_ARTISTIC = range(7)
+EFFECT_NONE, EFFECT_DEFOCUS, EFFECT_DESATURATION, EFFECT_HAZE = range(4)
 # Itanium-mangled names of the reference's ten free functions
 DROPIN_SYMBOLS = [
     "_Z23GPUAllocateDeviceMemoryiii", "_Z19GPUFreeDeviceMemoryi", "_Z14GPULoadWeightsf",
@@ -312,6 +313,12 @@ class Context:
     def estimate_depth_batch(self, maxIterations=1000):
         self._check(lib().rtdd_estimate_depth_batch(self._h, C.c_int(maxIterations)))
 
+    def pyramid_level_info(self, level):
+        """(SolveInfo, images per sweep launch) of what the most recent estimate ran on pyramid level `level`."""
+        info = SolveInfo(); n = C.c_int()
+        self._check(lib().rtdd_pyramid_level_info(self._h, C.c_int(level), C.byref(info), C.byref(n)))
+        return info, n.value
+
     def pyramid_destroy(self):
         self._check(lib().rtdd_pyramid_destroy(self._h))
 
@@ -351,6 +358,14 @@ class Context:
         ep = (C.c_void_p(edited.ctypes.data), C.c_size_t(edited.strides[0])) if edited is not None else (None, C.c_size_t(0))
         self._check(lib().rtdd_live_submit(self._h, sp[0], sp[1], ep[0], ep[1], C.c_int(maxIterations),
                                            C.c_void_p(depth_u8.ctypes.data), C.c_size_t(depth_u8.strides[0])))
+
+    def live_submit_ex(self, scribble, edited, depth_u8, effect, artistic, maxIterations=1000):
+        """rtdd_live_submit_ex: the frame with a sticky depth effect (EFFECT_*), its artistic image into the host array `artistic`."""
+        sp = (C.c_void_p(scribble.ctypes.data), C.c_size_t(scribble.strides[0])) if scribble is not None else (None, C.c_size_t(0))
+        ep = (C.c_void_p(edited.ctypes.data), C.c_size_t(edited.strides[0])) if edited is not None else (None, C.c_size_t(0))
+        ap = (C.c_void_p(artistic.ctypes.data), C.c_size_t(artistic.strides[0])) if artistic is not None else (None, C.c_size_t(0))
+        self._check(lib().rtdd_live_submit_ex(self._h, sp[0], sp[1], ep[0], ep[1], C.c_int(maxIterations),
+                                              C.c_void_p(depth_u8.ctypes.data), C.c_size_t(depth_u8.strides[0]), C.c_int(effect), ap[0], ap[1]))
 
     def live_wait(self):
         self._check(lib().rtdd_live_wait(self._h))

@@ -73,10 +73,8 @@ static int replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
     ctx->opt.debug_force_status = op.opt.debug_force_status == 3 ? 1 : 0;      // (3: the testing aid that makes the REPLAY fail as well)
     int rc = RTDD_OK;
     if (op.kind == PendingOp::kSolve) {
-        uint8_t *u8 = ctx->finish_u8; const size_t u8p = ctx->finish_u8_pitch;
-        ctx->finish_u8 = op.finish_u8; ctx->finish_u8_pitch = op.finish_u8_pitch;
-        rc = rtdd_solve_ex(ctx, op.depth, op.depthPitch, op.scribble, op.scribblePitch, op.gray, op.grayPitch, op.rows, op.cols, op.level, &op.params, nullptr);
-        ctx->finish_u8 = u8; ctx->finish_u8_pitch = u8p;
+        rc = solve_with(ctx, op.depth, op.depthPitch, op.scribble, op.scribblePitch, op.gray, op.grayPitch, op.rows, op.cols, op.level,
+                        &op.params, nullptr, op.targets, nullptr);
     } else if (op.kind == PendingOp::kEstimate) {
         rc = estimate_replay(ctx, op, failed_seq);
     } else if (op.kind == PendingOp::kDefocus) {
@@ -494,6 +492,7 @@ struct Solve {
     size_t ip;
     int rows, cols;
     const rtdd_solve_params *p;
+    int images;                                    // a batched solve: the images every launch covers (blockIdx.z)
     int done = 0, launches = 0, cycles = 0;
     int pk = 0, pm = 1;                            // planes holding x_k and x_{k-1}
     float residual = NAN;
@@ -517,7 +516,7 @@ struct Solve {
         while (done < p->maxIterations) {
             const int n = p->maxIterations - done < chunk ? p->maxIterations - done : chunk;
             int ln = 0;
-            rc = blocked ? launch_sweeps_blocked(ctx, L, ip, rows, cols, omegas_dev + done, n, &pk, &pm, &ln)
+            rc = blocked ? launch_sweeps_blocked(ctx, L, ip, rows, cols, omegas_dev + done, n, &pk, &pm, &ln, images)
                          : launch_sweeps(ctx, L, ip, rows, cols, omegas.data() + done, n, &pk, &pm, &ln);
             if (rc != RTDD_OK) return rc;
             done += n; launches += ln;
@@ -616,20 +615,21 @@ struct Solve {
 
 // one attempt: stage + edge weights, the sweeps, the (guarded) copy-back
 static int solve_once(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
-                      const uint8_t *gray, size_t grayPitch, int rows, int cols, int level, const rtdd_solve_params *params, int seq) {
-    const Level L = ctx->levels[level].view(ctx->batch.first);      // (the first image of the batch in progress: image 0 of 1 unless cascade_api.cpp says otherwise)
+                      const uint8_t *gray, size_t grayPitch, int rows, int cols, int level, const rtdd_solve_params *params, int seq,
+                      const SolveTargets &t, SolveOutcome *out) {
+    const Level L = ctx->levels[level].view(t.batch.first);      // (the first image the launches cover: image 0 of 1 unless the caller says otherwise)
     const size_t ip = plane_pitch(cols);
     const bool prof = ctx->profile_on;
     hipEvent_t *ev = ctx->ev + 4 * (ctx->prof_pending % rtdd_ctx::kProfSlots);
 
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
-    int rc = launch_prepare(ctx, L, ip, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
+    int rc = launch_prepare(ctx, L, ip, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, t.batch);
     if (rc != RTDD_OK) return rc;
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
 
     ctx->last_info = rtdd_solve_info{};
     ctx->last_info.residual = NAN;
-    Solve s{ctx, L, ip, rows, cols, params};
+    Solve s{ctx, L, ip, rows, cols, params, t.batch.n};
     switch (params->method) {
         case RTDD_METHOD_CHEBYSHEV_JACOBI: rc = s.chebyshev_jacobi(); break;
         case RTDD_METHOD_MULTIGRID:
@@ -642,10 +642,9 @@ static int solve_once(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint
     if (rc != RTDD_OK) return rc;
 
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-    ctx->deferred_plane = s.pk;
-    ctx->guard_seq = seq;                           // (a deferred copy-back is k_pyrup_inject's: cascade_api.cpp hands it the same number)
-    if (!ctx->defer_finish) {
-        rc = launch_finish(ctx, L, ip, s.pk, depth, depthPitch, rows, cols, ctx->finish_u8, ctx->finish_u8_pitch);
+    if (out) { out->plane = s.pk; out->seq = seq; }     // (a deferred copy-back is k_pyrup_inject's: estimate_levels hands it the same number)
+    if (!t.defer_finish) {
+        rc = launch_finish(ctx, L, ip, s.pk, depth, depthPitch, rows, cols, t, seq);
         if (rc != RTDD_OK) return rc;
     }
     if (prof) {
@@ -662,6 +661,17 @@ static int solve_once(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint
 int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
                   const uint8_t *gray, size_t grayPitch, int rows, int cols, int level,
                   const rtdd_solve_params *params, rtdd_solve_info *info) {
+    return solve_with(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, info, SolveTargets(), nullptr);
+}
+
+}  // extern "C"
+#pragma GCC visibility pop
+
+// rtdd_solve_ex, plus what the library's own callers add to it (SolveTargets: a batch of images in the same launches, a deferred
+// copy-back, the u8 copies of the result, whether the call is logged on its own).
+int rtdd::solve_with(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
+                     const uint8_t *gray, size_t grayPitch, int rows, int cols, int level,
+                     const rtdd_solve_params *params, rtdd_solve_info *info, const SolveTargets &t, SolveOutcome *out) {
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, params != nullptr, "null params");
     REQUIRE(ctx, params->maxIterations >= 0, "maxIterations must be >= 0");
@@ -672,8 +682,9 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
             "relaxation must be in [0,2) or RTDD_RELAXATION_AUTO");
     int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
     if (rc != RTDD_OK) return rc;
-    REQUIRE(ctx, ctx->batch.first >= 0 && ctx->batch.n >= 1 && ctx->batch.first + ctx->batch.n <= ctx->levels_images, "the batch exceeds what the context's levels were allocated for");
-    REQUIRE(ctx, ctx->batch.n == 1 || (params->method == RTDD_METHOD_CHEBYSHEV_JACOBI && params->tolerance <= 0.0f && ctx->opt.sweep_kernel != 1),
+    REQUIRE(ctx, t.batch.first >= 0 && t.batch.n >= 1 && t.batch.first + t.batch.n <= ctx->levels_images,
+            "the batch exceeds what the context's levels were allocated for");
+    REQUIRE(ctx, t.batch.n == 1 || (params->method == RTDD_METHOD_CHEBYSHEV_JACOBI && params->tolerance <= 0.0f && ctx->opt.sweep_kernel != 1),
             "a batched solve runs the reference's scheme with the temporally blocked kernel only");
     DeviceGuard g(ctx->device);
     if (ctx->solve_seq >= (1 << 30)) {              // (once in 10^9 solves) the sequence numbers start over: nothing may be left that compares against them
@@ -684,28 +695,31 @@ int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t 
     }
     const int seq = ++ctx->solve_seq;
     const Options asked = ctx->opt;
-    rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq);
+    rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq, t, out);
     // A residual check inside the solve found the status word set, and the calls before this one have been healed (check_persistent_status):
     // nothing of this solve has reached the caller's buffers (its copy-back is the last thing it does), so it simply starts over --
     // persistence is off by now.
-    if (rc == kRestartSolve) rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq);
+    if (rc == kRestartSolve) rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq, t, out);
     if (rc == kRestartSolve) rc = fail(ctx, RTDD_ERR_TIMEOUT, "the solve was restarted after a timed-out persistent launch and failed again");
     if (rc != RTDD_OK) return rc;
     if (!ctx->healing && ctx->persist_suspend > 0 && --ctx->persist_suspend == 0 && ctx->persistent_wanted) ctx->opt.persistent = 1;     // re-armed (check_persistent_status)
-    if (!ctx->healing && !ctx->in_estimate && ctx->opt.timeout_heal) {       // remembered until a copy-back kernel or a synchronising call has confirmed it
+    if (!ctx->healing && t.logged && ctx->opt.timeout_heal) {       // remembered until a copy-back kernel or a synchronising call has confirmed it
         prune_confirmed(ctx);
         if (ctx->pending.size() >= kMaxPendingOps) { ctx->pending.clear(); ctx->pending_overflow = true; }
         PendingOp op;
         op.kind = PendingOp::kSolve; op.opt = asked; op.seq = seq;
         op.depth = depth; op.depthPitch = depthPitch; op.scribble = scribble; op.scribblePitch = scribblePitch; op.gray = gray; op.grayPitch = grayPitch;
         op.rows = rows; op.cols = cols; op.level = level; op.params = *params;
-        op.finish_u8 = ctx->finish_u8; op.finish_u8_pitch = ctx->finish_u8_pitch;
+        op.targets = t;
         op.id = ++ctx->op_counter;
         ctx->pending.push_back(op);
     }
     if (info) *info = ctx->last_info;
     return RTDD_OK;
 }
+
+#pragma GCC visibility push(default)
+extern "C" {
 
 int rtdd_last_solve_info(rtdd_ctx *ctx, rtdd_solve_info *info) {
     if (!ctx || !info) return RTDD_ERR_INVALID;
@@ -756,7 +770,9 @@ int rtdd_convert_to_float(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, fl
     if (rows == 0 || cols == 0) return RTDD_OK;
     REQUIRE(ctx, srcPitch >= (size_t)cols * 3 && dstPitch >= (size_t)cols * 4 && maskPitch >= (size_t)cols, "pitch smaller than a row");
     DeviceGuard g(ctx->device);
-    pyramid_note_write(ctx, dst, dst);             // (the coarsest depth image of the context's pyramid? then the next estimate injects again)
+    // (the coarsest depth image of the context's pyramid? then the next estimate injects again; stale annotation pointers: RTDD_ERR_STATE)
+    { const int rc_ = pyramid_check_read(ctx, src, mask); if (rc_ != RTDD_OK) return rc_; }
+    { const int rc_ = pyramid_note_write(ctx, dst, dst); if (rc_ != RTDD_OK) return rc_; }
     return launch_convert(ctx, src, srcPitch, dst, dstPitch, mask, maskPitch, rows, cols);
 }
 
@@ -770,7 +786,8 @@ int rtdd_pyrdown_annotation(rtdd_ctx *ctx, const uint8_t *prevScribble, size_t p
     REQUIRE(ctx, prevScribblePitch >= (size_t)previousCols && prevEditedPitch >= (size_t)previousCols * 3 &&
                  currScribblePitch >= (size_t)currentCols && currEditedPitch >= (size_t)currentCols * 3, "pitch smaller than a row");
     DeviceGuard g(ctx->device);
-    pyramid_note_write(ctx, currScribble, currEdited);
+    { const int rc_ = pyramid_check_read(ctx, prevScribble, prevEdited); if (rc_ != RTDD_OK) return rc_; }
+    { const int rc_ = pyramid_note_write(ctx, currScribble, currEdited); if (rc_ != RTDD_OK) return rc_; }
     return launch_pyrdown_annotation(ctx, prevScribble, prevScribblePitch, prevEdited, prevEditedPitch, previousRows, previousCols,
                                      currScribble, currScribblePitch, currEdited, currEditedPitch, currentRows, currentCols);
 }
@@ -783,7 +800,7 @@ int rtdd_paint_image(rtdd_ctx *ctx, int x, int y, int scribbleColor, int scribbl
     if (rows == 0 || cols == 0) return RTDD_OK;
     REQUIRE(ctx, editedPitch >= (size_t)cols * 3 && scribblePitch >= (size_t)cols, "pitch smaller than a row");
     DeviceGuard g(ctx->device);
-    pyramid_note_write(ctx, scribble, edited);
+    { const int rc_ = pyramid_note_write(ctx, scribble, edited); if (rc_ != RTDD_OK) return rc_; }
     return launch_paint(ctx, x, y, scribbleColor, scribbleRadius, edited, editedPitch, scribble, scribblePitch, rows, cols);
 }
 

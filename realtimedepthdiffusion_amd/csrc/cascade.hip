@@ -246,11 +246,11 @@ int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, in
     return RTDD_OK;
 }
 int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
-                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out, size_t cp, bool guarded, const PyrupBatch *pb) {
+                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out, size_t cp, int guard_seq, const PyrupBatch *pb) {
     static const PyrupBatch one;
     const PyrupBatch &Z = pb ? *pb : one;
-    int *sw = guarded ? ctx->sync_words : nullptr;
-    const int seq = ctx->guard_seq;
+    int *sw = guard_seq != 0 ? ctx->sync_words : nullptr;
+    const int seq = guard_seq;
     if (coarse_out && (drows < 2 * rows || dcols < 2 * cols)) return fail(ctx, RTDD_ERR_INVALID, "pyrUp: the fine level must be at least twice the coarse one");
     const bool doubling = drows == 2 * rows && dcols == 2 * cols && dcols % 4 == 0 && rows >= 2 && cols >= 2;
     const bool aligned = (uintptr_t)dst % 16 == 0 && dp % 16 == 0 && Z.dst % 16 == 0 && (!mask || ((uintptr_t)mask % 4 == 0 && mp % 4 == 0 && (uintptr_t)edited % 4 == 0 && ep % 4 == 0 && Z.mask % 4 == 0 && Z.edited % 4 == 0));

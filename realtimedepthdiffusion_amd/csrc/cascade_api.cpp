@@ -28,6 +28,8 @@ struct Pyramid {
     // by the first estimate after the annotation changed, not by every estimate.
     bool annotation_dirty = true;         // (of ANY image of a batch: bringing an up-to-date image up to date again changes nothing)
     int images = 1, sel = 0;              // batch size; the image the single-image entry points address (rtdd_pyramid_select)
+    std::vector<rtdd_solve_info> level_info;      // what the most recent estimate ran per level (rtdd_pyramid_level_info)
+    std::vector<int> level_launch_images;
     struct Live *live = nullptr;          // rtdd_live_submit's second stream, staging images and events (created on first use)
 };
 
@@ -39,13 +41,22 @@ struct Live {
     Image scribble_stage[2], edited_stage[2], u8_stage[2];
     hipEvent_t h2d_done[2] = {nullptr, nullptr}, est_done[2] = {nullptr, nullptr}, d2h_done[2] = {nullptr, nullptr};
     int *status_host = nullptr;           // page-locked, 2 x 8 ints: the kernels' control words as they were behind each frame's estimate
-    struct Frame { uint8_t *host = nullptr; size_t pitch = 0; bool in_flight = false, direct = false; unsigned long long op_id = 0; } frame[2];
+    Image art_stage[2];                   // a frame's sticky depth effect (rtdd_live_submit_ex) renders here; allocated with the first such frame
+    struct Frame {
+        uint8_t *host = nullptr; size_t pitch = 0;
+        bool in_flight = false, direct = false;
+        unsigned long long op_id = 0;
+        int effect = 0;                   // RTDD_EFFECT_*: the frame carries an artistic image too
+        uint8_t *art_host = nullptr; size_t art_pitch = 0;
+        bool art_queued = false;          // its download was queued at submit on the compute stream (no other frame in flight); else rtdd_live_wait issues it
+    } frame[2];
     unsigned long long submitted = 0, waited = 0;
     // Round 5: no device-to-device staging copies.  A frame's annotation is uploaded into the staging pair that is NOT the pyramid's
     // current level-0 annotation, and the pyramid's level-0 scribble / edited images then simply BECOME that pair (pointer swap); the
     // frame's u8 map is written by the estimate's copy-back into RTDD_IMG_DEPTH_U8 AND into the frame's slot (k_finish: two targets).
     // The pyramid's own annotation buffers are kept here and put back before the pyramid is freed.
-    void *own_scribble = nullptr, *own_edited = nullptr;
+    void *own_scribble = nullptr, *own_edited = nullptr, *own_artistic = nullptr;
+    Bounce bounce_art;                      // (an artistic image on its way to a host image with an unaligned pitch, compute stream)
     Bounce bounce_up[2][2];                 // ([frame parity][scribble, edited]: uploads of images with an unaligned host pitch, rtdd_live_submit)
     uint8_t *host_bounce = nullptr; size_t host_bounce_bytes = 0;      // page-locked: a staged map on its way to a host image with an unaligned pitch (live_fetch)
 };
@@ -95,15 +106,42 @@ static bool inside(const Image &im, const void *p) {
     return im.ptr && (const char *)p >= (const char *)im.ptr && (const char *)p < (const char *)im.ptr + im.stride * (size_t)im.images;
 }
 
-// called by the entry points that write an annotation image: is it one of this context's pyramid?
-void pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited) {
+// Called by the entry points that write an annotation image: is it one of this context's pyramid?  After an uploading live frame the
+// pyramid's level-0 scribble / edited images ARE the uploaded staging pair (Live, below), so a pointer rtdd_pyramid_image handed out
+// before that frame names a buffer no estimate reads any more: writing it through the library would lose the strokes silently --
+// RTDD_ERR_STATE instead (ask rtdd_pyramid_image again).
+static bool stale_live_pointer(const Pyramid *p, const void *q) {
+    const Live *v = p->live;
+    if (!v || !q) return false;
+    auto in_image = [](const void *base, const Image &like, const void *r) {
+        return base && (const char *)r >= (const char *)base && (const char *)r < (const char *)base + like.pitch * (size_t)(like.rows > 0 ? like.rows : 1);
+    };
+    const void *olds[3] = {v->own_scribble, v->scribble_stage[0].ptr, v->scribble_stage[1].ptr};
+    const void *olde[3] = {v->own_edited, v->edited_stage[0].ptr, v->edited_stage[1].ptr};
+    for (int i = 0; i < 3; i++)
+        if ((olds[i] != p->scribble[0].ptr && in_image(olds[i], p->scribble[0], q)) || (olde[i] != p->edited[0].ptr && in_image(olde[i], p->edited[0], q)))
+            return true;
+    return false;
+}
+static const char *kStaleText = "this level-0 annotation image is no longer the pyramid's: a live frame has uploaded a new pair since "
+                                "rtdd_pyramid_image handed the pointer out -- ask rtdd_pyramid_image again";
+// (an entry point that only READS annotation images: the same staleness rule)
+int pyramid_check_read(rtdd_ctx *ctx, const void *a, const void *b) {
+    if (ctx->pyr && (stale_live_pointer(ctx->pyr, a) || stale_live_pointer(ctx->pyr, b))) return fail(ctx, RTDD_ERR_STATE, kStaleText);
+    return RTDD_OK;
+}
+int pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited) {
     Pyramid *p = ctx->pyr;
-    if (!p) return;
+    if (!p) return RTDD_OK;
+    if (stale_live_pointer(p, scribble) || stale_live_pointer(p, edited)) return fail(ctx, RTDD_ERR_STATE, kStaleText);
     for (int l = 0; l < p->levels; l++)
-        if (inside(p->scribble[l], scribble) || inside(p->edited[l], edited) || inside(p->scribble[l], edited) || inside(p->edited[l], scribble)) p->annotation_dirty = true;
+        if (inside(p->scribble[l], scribble) || inside(p->edited[l], edited) || inside(p->scribble[l], edited) || inside(p->edited[l], scribble))
+            p->annotation_dirty = true;
     // the coarsest depth image carries the injected labels of src/main.cpp:257-259, which an estimate only renews when the annotation
-    // changed: whoever overwrites it through the library (rtdd_upload, rtdd_convert_to_float, rtdd_pyrup_depth) makes the next estimate inject again
+    // changed: whoever overwrites it through the library (rtdd_upload, rtdd_convert_to_float, rtdd_pyrup_depth) makes the next
+    // estimate inject again
     if (p->levels > 0 && (inside(p->depth[p->levels - 1], scribble) || inside(p->depth[p->levels - 1], edited))) p->annotation_dirty = true;
+    return RTDD_OK;
 }
 
 static int alloc_image(rtdd_ctx *ctx, Image &im, int rows, int cols, int elem, int fill, int images = 1) {
@@ -124,15 +162,17 @@ static void live_free(Pyramid *p) {
     Live *v = p->live;
     if (!v) return;
     if (v->own_scribble) { p->scribble[0].ptr = v->own_scribble; p->edited[0].ptr = v->own_edited; }
+    if (v->own_artistic) p->artistic.ptr = v->own_artistic;
     if (v->up) { (void)hipStreamSynchronize(v->up); (void)hipStreamDestroy(v->up); }
     if (v->copy) { (void)hipStreamSynchronize(v->copy); (void)hipStreamDestroy(v->copy); }
     for (int k = 0; k < 2; k++) {
-        free_image(v->scribble_stage[k]); free_image(v->edited_stage[k]); free_image(v->u8_stage[k]);
+        free_image(v->scribble_stage[k]); free_image(v->edited_stage[k]); free_image(v->u8_stage[k]); free_image(v->art_stage[k]);
         for (hipEvent_t e : {v->h2d_done[k], v->est_done[k], v->d2h_done[k]}) if (e) (void)hipEventDestroy(e);
     }
     if (v->status_host) (void)hipHostFree(v->status_host);
     for (auto &bb : v->bounce_up) for (Bounce &b : bb) if (b.ptr) (void)hipFree(b.ptr);
     if (v->host_bounce) (void)hipHostFree(v->host_bounce);
+    if (v->bounce_art.ptr) (void)hipFree(v->bounce_art.ptr);
     delete v;
     p->live = nullptr;
 }
@@ -189,6 +229,7 @@ int rtdd_pyramid_create_batch(rtdd_ctx *ctx, int rows, int cols, int images) {
     if (!p) return fail(ctx, RTDD_ERR_NOMEM, "pyramid");
     ctx->pyr = p;
     p->rows = rows; p->cols = cols; p->levels = rtdd_pyramid_levels(rows, cols); p->images = images;
+    p->level_info.assign(p->levels, rtdd_solve_info{}); p->level_launch_images.assign(p->levels, 0);
     p->gray.resize(p->levels); p->scribble.resize(p->levels); p->edited.resize(p->levels); p->depth.resize(p->levels);
     int rc;
     if ((rc = alloc_image(ctx, p->original, rows, cols, 3, 0, images)) != RTDD_OK) return rc;
@@ -284,6 +325,15 @@ int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *p
     return RTDD_OK;
 }
 
+int rtdd_pyramid_level_info(rtdd_ctx *ctx, int level, rtdd_solve_info *info, int *imagesPerLaunch) {
+    if (!ctx || !info) return RTDD_ERR_INVALID;
+    if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
+    REQUIRE(ctx, level >= 0 && level < ctx->pyr->levels, "level out of range");
+    *info = ctx->pyr->level_info[level];
+    if (imagesPerLaunch) *imagesPerLaunch = ctx->pyr->level_launch_images[level];
+    return RTDD_OK;
+}
+
 int rtdd_pyramid_annotation_changed(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
@@ -291,8 +341,9 @@ int rtdd_pyramid_annotation_changed(rtdd_ctx *ctx) {
     return RTDD_OK;
 }
 
-// first, n: the images of the context's (batched) pyramid the estimate covers -- the selected one, or all of them in the same launches
-static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, size_t u8_copy_pitch, unsigned long long *op_id, bool whole_batch = false) {
+// first, n: the images of the context's (batched) pyramid the estimate covers -- the selected one, or all of them in the same launches.
+// live: a live frame's own images (its annotation pair, the second target of its u8 map, its depth effect); default: not a live frame.
+static int estimate_submit(rtdd_ctx *ctx, int maxIterations, unsigned long long *op_id, bool whole_batch, const LiveTargets &live) {
     if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
     REQUIRE(ctx, maxIterations >= 0, "maxIterations must be >= 0");
     Pyramid *p = ctx->pyr;
@@ -310,20 +361,16 @@ static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, s
             zs[l] = p->scribble[l].stride; ze[l] = p->edited[l].stride; lr[l] = p->edited[l].rows; lc[l] = p->edited[l].cols;
         }
         // src/main.cpp:249-259: the P - 1 annotation levels and the coarsest level's injection, one launch (image_kernels.hip)
-        rc = launch_annotation_pyramid(ctx, P, sc, sp, zs, ed, ep, ze, lr, lc, (float *)p->depth[P - 1].ptr, p->depth[P - 1].pitch, p->depth[P - 1].stride, p->images);
+        rc = launch_annotation_pyramid(ctx, P, sc, sp, zs, ed, ep, ze, lr, lc, (float *)p->depth[P - 1].ptr, p->depth[P - 1].pitch,
+                                       p->depth[P - 1].stride, p->images);
         if (rc != RTDD_OK) return rc;
         p->annotation_dirty = false;
     }
     PendingOp op;
     op.kind = PendingOp::kEstimate; op.opt = ctx->opt; op.maxIterations = maxIterations;
-    op.u8_copy = u8_copy; op.u8_copy_pitch = u8_copy_pitch; op.batch_first = first; op.batch_n = n;
-    for (int i = 0; i < 3; i++) op.live_images[i] = ctx->live_images[i];       // a live frame: the level-0 annotation pair and the u8 slot it ran on
-    op.live_u8_pitch = ctx->live_u8_pitch;
-    rc = estimate_levels(ctx, maxIterations, P - 1, op.level_seq, first, n);
-    if (rc == RTDD_OK && u8_copy) {
-        DeviceGuard g(ctx->device);
-        RTDD_HIP(ctx, hipMemcpy2DAsync(u8_copy, u8_copy_pitch, p->depth_u8.at(first), p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
-    }
+    op.batch_first = first; op.batch_n = n; op.live = live;
+    rc = estimate_levels(ctx, maxIterations, P - 1, op.level_seq, first, n, live);
+    if (rc == RTDD_OK && live.effect) rc = live_effect(ctx, live);      // src/main.cpp:190-230: the sticky effect, on this frame's map
     if (rc == RTDD_OK && !ctx->healing && ctx->opt.timeout_heal) {
         prune_confirmed(ctx);
         if (ctx->pending.size() >= kMaxPendingOps) { ctx->pending.clear(); ctx->pending_overflow = true; }
@@ -336,12 +383,12 @@ static int estimate_submit(rtdd_ctx *ctx, int maxIterations, uint8_t *u8_copy, s
 
 int rtdd_estimate_depth(rtdd_ctx *ctx, int maxIterations) {
     if (!ctx) return RTDD_ERR_INVALID;
-    return estimate_submit(ctx, maxIterations, nullptr, 0, nullptr);
+    return estimate_submit(ctx, maxIterations, nullptr, /*whole_batch=*/false, LiveTargets());
 }
 
 int rtdd_estimate_depth_batch(rtdd_ctx *ctx, int maxIterations) {
     if (!ctx) return RTDD_ERR_INVALID;
-    return estimate_submit(ctx, maxIterations, nullptr, 0, nullptr, /*whole_batch=*/true);
+    return estimate_submit(ctx, maxIterations, nullptr, /*whole_batch=*/true, LiveTargets());
 }
 
 // ---- live mode ---------------------------------------------------------------------------------------------------------------------
@@ -384,27 +431,37 @@ int rtdd_live_pending(rtdd_ctx *ctx) {
     return (int)(ctx->pyr->live->submitted - ctx->pyr->live->waited);
 }
 
-// Frame k's staged u8 map (and the control words) to the host, on the copy stream, and wait.  A host image whose pitch is no multiple of
-// four: the staged image comes over WHOLE -- its rows, padding included, are one contiguous block -- into a page-locked buffer and
-// the host copies the rows out; the runtime's 2-D copy takes 9 us per row for such a pitch, and a re-pitching kernel on the copy stream
-// would queue behind the next frame's persistent launches (1921 x 1081: 1.39 ms per pipelined frame).
-static int live_fetch(rtdd_ctx *ctx, Live *v, int k) {
+// Frame k's staged u8 map (`map`) and / or its artistic image (`art`), and the control words, to the host on the copy stream, and wait.
+// A host image whose pitch is no multiple of four: the staged image comes over WHOLE -- its rows, padding included, are one contiguous
+// block -- into a page-locked buffer and the host copies the rows out; the runtime's 2-D copy takes 9 us per row for such a pitch, and
+// a re-pitching kernel on the copy stream would queue behind the next frame's persistent launches (1921 x 1081: 1.39 ms per pipelined
+// frame).
+static int live_fetch(rtdd_ctx *ctx, Live *v, int k, bool map, bool art) {
     Pyramid *p = ctx->pyr;
     const Live::Frame &f = v->frame[k];
-    const Image &st = v->u8_stage[k];
-    const bool via_host = f.pitch % 4 != 0 && p->rows > 1;
-    if (via_host) {
-        const size_t bytes = st.pitch * (size_t)p->rows;
-        if (v->host_bounce_bytes < bytes) {
-            if (v->host_bounce) { RTDD_HIP(ctx, hipStreamSynchronize(v->copy)); RTDD_HIP(ctx, hipHostFree(v->host_bounce)); v->host_bounce = nullptr; v->host_bounce_bytes = 0; }
-            RTDD_HIP(ctx, hipHostMalloc((void **)&v->host_bounce, bytes, hipHostMallocDefault));
-            v->host_bounce_bytes = bytes;
+    struct Part { bool on; uint8_t *host; size_t pitch, width; const Image *st; size_t off; } parts[2] = {
+        {map, f.host, f.pitch, (size_t)p->cols, &v->u8_stage[k], 0}, {art && f.effect != 0, f.art_host, f.art_pitch, (size_t)p->cols * 3, &v->art_stage[k], 0}};
+    size_t bounce = 0;
+    for (Part &q : parts)
+        if (q.on && q.pitch % 4 != 0 && p->rows > 1) { q.off = bounce + 1; bounce += q.st->pitch * (size_t)p->rows; }     // (off - 1: its place in the bounce buffer)
+    if (bounce > v->host_bounce_bytes) {
+        if (v->host_bounce) {
+            RTDD_HIP(ctx, hipStreamSynchronize(v->copy)); RTDD_HIP(ctx, hipHostFree(v->host_bounce));
+            v->host_bounce = nullptr; v->host_bounce_bytes = 0;
         }
-        RTDD_HIP(ctx, hipMemcpyAsync(v->host_bounce, st.ptr, bytes, hipMemcpyDeviceToHost, v->copy));
-    } else RTDD_HIP(ctx, hipMemcpy2DAsync(f.host, f.pitch, st.ptr, st.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToHost, v->copy));
+        RTDD_HIP(ctx, hipHostMalloc((void **)&v->host_bounce, bounce, hipHostMallocDefault));
+        v->host_bounce_bytes = bounce;
+    }
+    for (const Part &q : parts) {
+        if (!q.on) continue;
+        if (q.off) RTDD_HIP(ctx, hipMemcpyAsync(v->host_bounce + q.off - 1, q.st->ptr, q.st->pitch * (size_t)p->rows, hipMemcpyDeviceToHost, v->copy));
+        else RTDD_HIP(ctx, hipMemcpy2DAsync(q.host, q.pitch, q.st->ptr, q.st->pitch, q.width, p->rows, hipMemcpyDeviceToHost, v->copy));
+    }
     RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
     RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
-    if (via_host) for (int y = 0; y < p->rows; y++) std::memcpy(f.host + (size_t)y * f.pitch, v->host_bounce + (size_t)y * st.pitch, (size_t)p->cols);
+    for (const Part &q : parts)
+        if (q.on && q.off)
+            for (int y = 0; y < p->rows; y++) std::memcpy(q.host + (size_t)y * q.pitch, v->host_bounce + q.off - 1 + (size_t)y * q.st->pitch, q.width);
     return RTDD_OK;
 }
 
@@ -415,10 +472,13 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
     Live *v = p->live;
     DeviceGuard g(ctx->device);
     const int k = (int)(v->waited % 2);
-    if (v->frame[k].direct) RTDD_HIP(ctx, hipEventSynchronize(v->d2h_done[k]));
+    const Live::Frame &fr = v->frame[k];
+    const bool fetch_map = !fr.direct, fetch_art = fr.effect != 0 && !fr.art_queued;
+    if (!fetch_map && !fetch_art) RTDD_HIP(ctx, hipEventSynchronize(v->d2h_done[k]));
     else {
-        RTDD_HIP(ctx, hipEventSynchronize(v->est_done[k]));
-        { const int rc_ = live_fetch(ctx, v, k); if (rc_ != RTDD_OK) return rc_; }
+        // (a frame with one part stored / queued on the compute stream and the other staged: the one event behind both was recorded there)
+        RTDD_HIP(ctx, hipEventSynchronize(fr.direct ? v->d2h_done[k] : v->est_done[k]));
+        { const int rc_ = live_fetch(ctx, v, k, fetch_map, fetch_art); if (rc_ != RTDD_OK) return rc_; }
     }
     if (v->status_host[8 * k + kSyncStatus] == 0) {                                 // the usual case: the frame is good, and so is everything logged before it
         size_t n = 0;
@@ -428,7 +488,8 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
         return RTDD_OK;
     }
     // A sweep launch in front of this frame's download gave up (include/rtdd.h, RTDD_ERR_TIMEOUT): drain both streams, let the
-    // status check run the logged estimates again (each brings its staged u8 map with it), then fetch every frame in flight again.
+    // status check run the logged estimates again (each brings its staged u8 map and its effect with it), then fetch every frame in
+    // flight again.
     RTDD_HIP(ctx, hipStreamSynchronize(v->up));
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
@@ -437,8 +498,9 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
     if (rc != RTDD_OK) return rc;
     for (unsigned long long f = v->waited; f < v->submitted; f++) {
         const int j = (int)(f % 2);
-        // (a frame whose map the copy-back kernel stores in the host's buffer itself has just been run again into that buffer)
-        if (!v->frame[j].direct) { const int rc_ = live_fetch(ctx, v, j); if (rc_ != RTDD_OK) return rc_; }
+        // (a frame whose map the copy-back kernel stores in the host's buffer itself has just been run again into that buffer; an
+        // artistic image is always rendered into its staging slot)
+        { const int rc_ = live_fetch(ctx, v, j, !v->frame[j].direct, true); if (rc_ != RTDD_OK) return rc_; }
         v->status_host[8 * j + kSyncStatus] = 0;
     }
     v->frame[k].in_flight = false; v->waited++;
@@ -447,12 +509,19 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
 
 int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribblePitch, const uint8_t *hostEdited, size_t editedPitch,
                      int maxIterations, uint8_t *hostDepthU8, size_t depthPitch) {
+    return rtdd_live_submit_ex(ctx, hostScribble, scribblePitch, hostEdited, editedPitch, maxIterations, hostDepthU8, depthPitch, RTDD_EFFECT_NONE, nullptr, 0);
+}
+
+int rtdd_live_submit_ex(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribblePitch, const uint8_t *hostEdited, size_t editedPitch,
+                        int maxIterations, uint8_t *hostDepthU8, size_t depthPitch, int effect, uint8_t *hostArtistic, size_t artisticPitch) {
     if (!ctx) return RTDD_ERR_INVALID;
     if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
     Pyramid *p = ctx->pyr;
     REQUIRE(ctx, (hostScribble == nullptr) == (hostEdited == nullptr), "scribble and edited images come together (or neither: the annotation is unchanged)");
     REQUIRE(ctx, !hostScribble || (scribblePitch >= (size_t)p->cols && editedPitch >= (size_t)p->cols * 3), "pitch smaller than a row");
     REQUIRE(ctx, hostDepthU8 && depthPitch >= (size_t)p->cols && maxIterations >= 0, "bad output buffer or iteration count");
+    REQUIRE(ctx, effect >= RTDD_EFFECT_NONE && effect <= RTDD_EFFECT_HAZE, "unknown effect");
+    REQUIRE(ctx, effect == RTDD_EFFECT_NONE || (hostArtistic && artisticPitch >= (size_t)p->cols * 3), "an effect needs a host image for its result");
     REQUIRE(ctx, p->images == 1, "live frames run on a single-image pyramid (rtdd_pyramid_create)");
     DeviceGuard g(ctx->device);
     int rc = live_create(ctx);
@@ -460,13 +529,19 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
     Live *v = p->live;
     if (v->submitted - v->waited >= 2 && (rc = rtdd_live_wait(ctx)) != RTDD_OK) return rc;   // two frames in flight at most: the slot is free again
     const int k = (int)(v->submitted % 2);
+    const bool lone = v->submitted == v->waited;          // no other frame in flight: nothing for a copy to overlap
+    if (effect != RTDD_EFFECT_NONE && !v->art_stage[0].ptr) {          // the first frame with an effect: its two staging images
+        for (int j = 0; j < 2; j++)
+            if ((rc = alloc_image(ctx, v->art_stage[j], p->rows, p->cols, 3, 0)) != RTDD_OK) return rc;
+        if (v->art_stage[0].pitch != p->artistic.pitch) return fail(ctx, RTDD_ERR_STATE, "live staging images and pyramid images differ in pitch");
+        v->own_artistic = p->artistic.ptr;
+    }
     if (hostScribble) {
         // upload into the staging pair the pyramid is NOT looking at: the only frame that can still be in flight reads the other one
         // (at most two frames in flight, and the older one has been waited for above)
         const int u = p->scribble[0].ptr == v->scribble_stage[0].ptr ? 1 : 0;
-        // (no other frame in flight: nothing for the upload to overlap -- it goes on the compute stream itself, no event between the
-        // streams: 1080p 1.335 -> 1.324 ms one frame at a time, 4K 2.21 -> 2.18)
-        const bool lone = v->submitted == v->waited;
+        // (no other frame in flight: the upload goes on the compute stream itself, no event between the streams: 1080p 1.335 -> 1.324 ms
+        // one frame at a time, 4K 2.21 -> 2.18)
         hipStream_t us = lone ? ctx->stream : v->up;
         // A host image whose pitch is no multiple of four (copy_h2d above) goes as one linear copy into a contiguous buffer of this
         // frame's parity on the upload stream, and is re-pitched into the staging image by a kernel on the COMPUTE stream, behind the
@@ -487,7 +562,8 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
         }
         for (auto &q : ups)
             if (q.bounce && (rc = launch_repitch(ctx, ctx->stream, q.b->ptr, q.width, q.dst->ptr, q.dst->pitch, q.width, p->rows)) != RTDD_OK) return rc;
-        p->scribble[0].ptr = v->scribble_stage[u].ptr; p->edited[0].ptr = v->edited_stage[u].ptr;      // the pyramid's level-0 annotation IS the uploaded pair: no copy
+        // the pyramid's level-0 annotation IS the uploaded pair: no copy
+        p->scribble[0].ptr = v->scribble_stage[u].ptr; p->edited[0].ptr = v->edited_stage[u].ptr;
         p->annotation_dirty = true;
     }
     unsigned long long op_id = ctx->op_counter;
@@ -499,14 +575,26 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
     //   * no other frame in flight (one frame at a time: nothing could overlap a download) and a page-locked host buffer (rtdd_host_alloc,
     //     hipHostMalloc, hipHostRegister: device-visible): the estimate's copy-back kernel stores the u8 map straight into it, ~20 us
     //     per MB of posted writes, and the frame ends with an event on the compute stream (1080p 1.42 -> 1.33 ms, 4K 2.31 -> 2.20).
-    const bool want_direct = ctx->opt.live_zero_copy == 2 || (ctx->opt.live_zero_copy == 1 && v->submitted == v->waited);
+    // The artistic image of a frame with an effect (6.2 MB at 1080p) is rendered into the frame's staging slot and follows the same
+    // rule: downloaded by rtdd_live_wait from the host when pipelined, queued behind the effect on the compute stream when alone.
+    const bool want_direct = ctx->opt.live_zero_copy == 2 || (ctx->opt.live_zero_copy == 1 && lone);
     uint8_t *direct = want_direct ? live_device_view(hostDepthU8, depthPitch, p->rows, p->cols) : nullptr;
     // (the estimate's copy-back writes this frame's map into RTDD_IMG_DEPTH_U8 and into the frame's second target: estimate_levels)
-    ctx->live_images[0] = p->scribble[0].ptr; ctx->live_images[1] = p->edited[0].ptr;
-    ctx->live_images[2] = direct ? (void *)direct : v->u8_stage[k].ptr; ctx->live_u8_pitch = direct ? depthPitch : 0;
-    rc = estimate_submit(ctx, maxIterations, nullptr, 0, &op_id);
-    ctx->live_images[0] = ctx->live_images[1] = ctx->live_images[2] = nullptr; ctx->live_u8_pitch = 0;
+    LiveTargets lt;
+    lt.scribble = p->scribble[0].ptr; lt.edited = p->edited[0].ptr;
+    lt.u8 = direct ? direct : (uint8_t *)v->u8_stage[k].ptr; lt.u8_pitch = direct ? depthPitch : 0;
+    lt.effect = effect;
+    if (effect != RTDD_EFFECT_NONE) {
+        lt.artistic = (uint8_t *)v->art_stage[k].ptr; lt.artistic_pitch = v->art_stage[k].pitch;
+        p->artistic.ptr = v->art_stage[k].ptr;          // RTDD_IMG_ARTISTIC names the newest frame's image (like the annotation pair: no copy)
+    }
+    rc = estimate_submit(ctx, maxIterations, &op_id, /*whole_batch=*/false, lt);
     if (rc != RTDD_OK) return rc;
+    const bool art_queued = effect != RTDD_EFFECT_NONE && lone;
+    if (art_queued) {
+        rc = copy_d2h(ctx, v->bounce_art, hostArtistic, artisticPitch, v->art_stage[k].ptr, v->art_stage[k].pitch, (size_t)p->cols * 3, p->rows, ctx->stream);
+        if (rc != RTDD_OK) return rc;
+    }
     if (direct) {
         RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         RTDD_HIP(ctx, hipEventRecord(v->d2h_done[k], ctx->stream));
@@ -516,7 +604,9 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
         // pipelined frame), and the copy still overlaps the next frame's arithmetic
         RTDD_HIP(ctx, hipEventRecord(v->est_done[k], ctx->stream));
     }
-    v->frame[k].host = hostDepthU8; v->frame[k].pitch = depthPitch; v->frame[k].in_flight = true; v->frame[k].op_id = op_id; v->frame[k].direct = direct != nullptr;
+    Live::Frame &fr = v->frame[k];
+    fr.host = hostDepthU8; fr.pitch = depthPitch; fr.in_flight = true; fr.op_id = op_id; fr.direct = direct != nullptr;
+    fr.effect = effect; fr.art_host = hostArtistic; fr.art_pitch = artisticPitch; fr.art_queued = art_queued;
     v->submitted++;
     return RTDD_OK;
 }
@@ -526,62 +616,90 @@ int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribble
 
 namespace rtdd {
 
-int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq, int first, int n) {
+int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq, int first, int n, const LiveTargets &live) {
     Pyramid *p = ctx->pyr;
     if (!p) return fail(ctx, RTDD_ERR_STATE, "the pyramid is gone");
     if (first < 0 || n < 1 || first + n > p->images) return fail(ctx, RTDD_ERR_INVALID, "images outside the pyramid's batch");
     const int P = p->levels;
     if (from_level > P - 1) from_level = P - 1;
     int rc = RTDD_OK;
-    const bool was_in = ctx->in_estimate;
-    ctx->in_estimate = true;
-    const Batch no_batch;
     for (int l = from_level; l >= 0 && rc == RTDD_OK; l--) {                   // src/main.cpp:261-288
         const int iters = (int)(maxIterations / powf(2.0, (P - 1) - l));       // :263
         const bool solved = p->depth[l].rows > 0 && p->depth[l].cols > 0;
         // Two launches less per level than the calls spelt out: above the finest level the solver's copy-back is left to the pyrUp
         // kernel (which reads the result plane directly and writes depth[l] on the side); at the finest level the copy-back also
         // writes the u8 map (:290).  Same values in the same buffers (tests/test_gpu_cascade.py compares every level's image).
-        ctx->defer_finish = solved && l > 0;
-        ctx->finish_u8 = l == 0 ? (uint8_t *)p->depth_u8.at(first) : nullptr; ctx->finish_u8_pitch = p->depth_u8.pitch;
-        ctx->finish_u8b = l == 0 ? (uint8_t *)ctx->live_images[2] : nullptr; ctx->finish_u8b_pitch = ctx->live_u8_pitch ? ctx->live_u8_pitch : p->depth_u8.pitch;     // (a live frame: its staging slot, or the host's buffer, too)
-        if (solved) {
-            // the level of images first .. first + n - 1 in the same launches (blockIdx.z = image: Batch, rtdd_internal.hpp)
-            ctx->batch.n = n; ctx->batch.first = first;
-            ctx->batch.depth = p->depth[l].stride; ctx->batch.scribble = p->scribble[l].stride; ctx->batch.gray = p->gray[l].stride; ctx->batch.u8 = p->depth_u8.stride;
-            rc = rtdd_matrix_free_solver(ctx, (float *)p->depth[l].at(first), p->depth[l].pitch, (const uint8_t *)p->scribble[l].at(first), p->scribble[l].pitch,
-                                         (const uint8_t *)p->gray[l].at(first), p->gray[l].pitch, p->depth[l].rows, p->depth[l].cols, 0.4f, iters, 1e-5f, l);
-            ctx->batch = no_batch;
-            if (level_seq && l < 32) level_seq[l] = ctx->solve_seq;
+        SolveTargets t;
+        t.logged = false;                                                       // (the estimate is logged as one call)
+        t.defer_finish = solved && l > 0;
+        if (l == 0) {
+            t.u8 = (uint8_t *)p->depth_u8.at(first); t.u8_pitch = p->depth_u8.pitch;
+            t.u8b = live.u8; t.u8b_pitch = live.u8_pitch ? live.u8_pitch : p->depth_u8.pitch;     // (a live frame: its staging slot, or the host's buffer, too)
         }
-        const bool deferred = ctx->defer_finish;
-        ctx->defer_finish = false; ctx->finish_u8 = nullptr; ctx->finish_u8b = nullptr;
+        // the level of images first .. first + n - 1 in the same launches (blockIdx.z = image: Batch, rtdd_internal.hpp)
+        t.batch.n = n; t.batch.first = first;
+        t.batch.depth = p->depth[l].stride; t.batch.scribble = p->scribble[l].stride; t.batch.gray = p->gray[l].stride; t.batch.u8 = p->depth_u8.stride;
+        SolveOutcome done;
+        if (solved) {
+            rtdd_solve_params sp;                   // GPUMatrixFreeSolver(..., beta, CUDAIteration, CUDAThreshold, level): exactly `iters` sweeps (:266-268)
+            sp.method = RTDD_METHOD_CHEBYSHEV_JACOBI; sp.maxIterations = iters; sp.tolerance = 0.0f; sp.checkEvery = 0; sp.relaxation = 0.0f;
+            rc = solve_with(ctx, (float *)p->depth[l].at(first), p->depth[l].pitch, (const uint8_t *)p->scribble[l].at(first), p->scribble[l].pitch,
+                            (const uint8_t *)p->gray[l].at(first), p->gray[l].pitch, p->depth[l].rows, p->depth[l].cols, l, &sp, nullptr, t, &done);
+            if (level_seq && l < 32) level_seq[l] = done.seq;
+            if (rc == RTDD_OK) {
+                p->level_info[l] = ctx->last_info; p->level_launch_images[l] = ctx->last_launch_images;
+                if (ctx->last_info.kernel == 2) p->level_info[l].temporal_depth = ctx->last_nominal_depth;
+            }
+        }
         if (rc == RTDD_OK && l > 0) {
             DeviceGuard g(ctx->device);
             const float *src = (const float *)p->depth[l].at(first); size_t sp = p->depth[l].pitch;
             float *coarse_out = nullptr;
             PyrupBatch pb;
-            pb.n = n; pb.src = p->depth[l].stride; pb.dst = p->depth[l - 1].stride; pb.edited = p->edited[l - 1].stride; pb.mask = p->scribble[l - 1].stride; pb.coarse = p->depth[l].stride;
-            if (deferred) {                                                     // the level's result is still in the solver's plane
+            pb.n = n; pb.src = p->depth[l].stride; pb.dst = p->depth[l - 1].stride; pb.edited = p->edited[l - 1].stride;
+            pb.mask = p->scribble[l - 1].stride; pb.coarse = p->depth[l].stride;
+            if (t.defer_finish) {                                               // the level's result is still in the solver's plane
                 const size_t ip = plane_pitch(p->depth[l].cols);
                 const Level Lv = ctx->levels[l].view(first);
-                src = Lv.P(ctx->deferred_plane, ip); sp = ip * sizeof(float); pb.src = Lv.elems * sizeof(float);
+                src = Lv.P(done.plane, ip); sp = ip * sizeof(float); pb.src = Lv.elems * sizeof(float);
                 coarse_out = (float *)p->depth[l].at(first);
             }
-            // guarded like k_finish: when level l's sweeps gave up it stores nothing, depth[l] keeps level l's input and the level can be run again
+            // guarded like k_finish (with the solve's sequence number): when level l's sweeps gave up it stores nothing, depth[l] keeps level
+            // l's input and the level can be run again
             rc = launch_pyrup_inject(ctx, src, sp, p->depth[l].rows, p->depth[l].cols,
                                      (float *)p->depth[l - 1].at(first), p->depth[l - 1].pitch, p->depth[l - 1].rows, p->depth[l - 1].cols,
                                      (const uint8_t *)p->edited[l - 1].at(first), p->edited[l - 1].pitch,
-                                     (const uint8_t *)p->scribble[l - 1].at(first), p->scribble[l - 1].pitch, coarse_out, p->depth[l].pitch, /*guarded=*/solved, &pb);     // :272-283
+                                     (const uint8_t *)p->scribble[l - 1].at(first), p->scribble[l - 1].pitch, coarse_out, p->depth[l].pitch,
+                                     /*guard_seq=*/solved ? done.seq : 0, &pb);     // :272-283
         }
     }
-    ctx->in_estimate = was_in;
     if (rc != RTDD_OK) return rc;
     if (p->depth[0].rows > 0 && p->depth[0].cols > 0) return RTDD_OK;         // the u8 map left the solver's copy-back (above)
     DeviceGuard g(ctx->device);
     for (int b = first; b < first + n && rc == RTDD_OK; b++)                    // (an image too small for a finest level: nothing above ran either)
-        rc = launch_depth_to_u8(ctx, (const float *)p->depth[0].at(b), p->depth[0].pitch, (uint8_t *)p->depth_u8.at(b), p->depth_u8.pitch, p->rows, p->cols);   // :290
+        rc = launch_depth_to_u8(ctx, (const float *)p->depth[0].at(b), p->depth[0].pitch, (uint8_t *)p->depth_u8.at(b), p->depth_u8.pitch,
+                                p->rows, p->cols);   // :290
     return rc;
+}
+
+// A live frame's sticky effect (src/main.cpp:190-230) on the pyramid's level-0 images, into the frame's staging image.  Queued on the
+// compute stream right behind the estimate's copy-back: the f32 map it reads is still in the L2s / the Infinity Cache.
+int live_effect(rtdd_ctx *ctx, const LiveTargets &live) {
+    Pyramid *p = ctx->pyr;
+    if (!p) return fail(ctx, RTDD_ERR_STATE, "the pyramid is gone");
+    if (p->rows <= 0 || p->cols <= 0 || !live.artistic) return RTDD_OK;
+    DeviceGuard g(ctx->device);
+    const uint8_t *orig = (const uint8_t *)p->original.ptr; const float *depth = (const float *)p->depth[0].ptr;
+    switch (live.effect) {
+        case RTDD_EFFECT_DEFOCUS:
+            return launch_defocus(ctx, orig, p->original.pitch, depth, p->depth[0].pitch, live.artistic, live.artistic_pitch, p->rows, p->cols);
+        case RTDD_EFFECT_DESATURATION:
+            return launch_desaturate(ctx, orig, p->original.pitch, (const uint8_t *)p->gray[0].ptr, p->gray[0].pitch, depth, p->depth[0].pitch,
+                                     live.artistic, live.artistic_pitch, p->rows, p->cols);
+        case RTDD_EFFECT_HAZE:
+            return launch_haze(ctx, orig, p->original.pitch, depth, p->depth[0].pitch, live.artistic, live.artistic_pitch, p->rows, p->cols);
+        default: return RTDD_OK;
+    }
 }
 
 int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
@@ -590,14 +708,12 @@ int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
     int from = -1;                                  // the level whose solve gave up; an estimate queued behind the failed call: every level
     for (int l = 0; l < 32; l++) if (failed_seq != 0 && op.level_seq[l] == failed_seq) from = l;
     if (from < 0) for (int l = 31; l >= 0 && from < 0; l--) if (op.level_seq[l] != 0) from = l;
-    if (op.live_images[0]) {                        // a live frame is run again on ITS annotation pair into ITS u8 slot (the newest frame's replay comes last: the pyramid ends up naming its images)
-        p->scribble[0].ptr = op.live_images[0]; p->edited[0].ptr = op.live_images[1];
-        ctx->live_images[2] = op.live_images[2]; ctx->live_u8_pitch = op.live_u8_pitch;
-    }
-    int rc = from >= 0 ? estimate_levels(ctx, op.maxIterations, from, nullptr, op.batch_first, op.batch_n) : RTDD_OK;
-    ctx->live_images[2] = nullptr; ctx->live_u8_pitch = 0;
-    if (rc == RTDD_OK && op.u8_copy)
-        RTDD_HIP(ctx, hipMemcpy2DAsync(op.u8_copy, op.u8_copy_pitch, p->depth_u8.at(op.batch_first), p->depth_u8.pitch, (size_t)p->cols, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
+    // a live frame is run again on ITS annotation pair into ITS u8 slot and ITS artistic image (the newest frame's replay comes last: the
+    // pyramid ends up naming its images)
+    if (op.live.scribble) { p->scribble[0].ptr = op.live.scribble; p->edited[0].ptr = op.live.edited; }
+    if (op.live.effect && op.live.artistic) p->artistic.ptr = op.live.artistic;
+    int rc = from >= 0 ? estimate_levels(ctx, op.maxIterations, from, nullptr, op.batch_first, op.batch_n, op.live) : RTDD_OK;
+    if (rc == RTDD_OK && op.live.effect) rc = live_effect(ctx, op.live);
     return rc;
 }
 
@@ -613,12 +729,11 @@ int rtdd_refine_depth(rtdd_ctx *ctx, const rtdd_solve_params *params, rtdd_solve
     // the u8 map is written by the solve's own copy-back (k_finish: the same rounding as k_depth_to_u8), so that a solve that has to be
     // run again after a timed-out persistent launch brings the map with it
     const int b = p->sel;
-    ctx->finish_u8 = (uint8_t *)p->depth_u8.at(b); ctx->finish_u8_pitch = p->depth_u8.pitch;
-    ctx->batch = Batch(); ctx->batch.first = b;
-    const int rc = rtdd_solve_ex(ctx, (float *)p->depth[0].at(b), p->depth[0].pitch, (const uint8_t *)p->scribble[0].at(b), p->scribble[0].pitch,
-                                 (const uint8_t *)p->gray[0].at(b), p->gray[0].pitch, p->rows, p->cols, 0, params, info);
-    ctx->finish_u8 = nullptr; ctx->batch = Batch();
-    return rc;
+    SolveTargets t;
+    t.u8 = (uint8_t *)p->depth_u8.at(b); t.u8_pitch = p->depth_u8.pitch;
+    t.batch.first = b;
+    return solve_with(ctx, (float *)p->depth[0].at(b), p->depth[0].pitch, (const uint8_t *)p->scribble[0].at(b), p->scribble[0].pitch,
+                      (const uint8_t *)p->gray[0].at(b), p->gray[0].pitch, p->rows, p->cols, 0, params, info, t, nullptr);
 }
 
 int rtdd_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bgrPitch, uint8_t *gray, size_t grayPitch, int rows, int cols) {
@@ -642,7 +757,7 @@ int rtdd_pyrup_depth(rtdd_ctx *ctx, const float *src, size_t srcPitch, int rows,
     // (as rtdd_index_to_weight: `src` may be the output of a logged solve whose persistent launch gave up -- the spelt-out cascade,
     // solve -> pyrUp -> inject -> solve, queued asynchronously)
     { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
-    pyramid_note_write(ctx, dst, dst);
+    { const int rc_ = pyramid_note_write(ctx, dst, dst); if (rc_ != RTDD_OK) return rc_; }
     return launch_pyrup_inject(ctx, src, srcPitch, rows, cols, dst, dstPitch, dstRows, dstCols, nullptr, 0, nullptr, 0);
 }
 
@@ -660,7 +775,7 @@ int rtdd_upload(rtdd_ctx *ctx, void *dev, size_t devPitch, const void *host, siz
     DeviceGuard g(ctx->device);
     // the destination may be an input of a logged call that still has to be run again: settle first (this call synchronises anyway)
     { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
-    pyramid_note_write(ctx, dev, dev);
+    { const int rc_ = pyramid_note_write(ctx, dev, dev); if (rc_ != RTDD_OK) return rc_; }
     { const int rc_ = copy_h2d(ctx, ctx->bounce, dev, devPitch, host, hostPitch, widthBytes, rows, ctx->stream); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTDD_OK;

@@ -406,11 +406,11 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
         ya[i] = max(y - h, 0); yb[i] = min(y + h, rows);
         xa[i] = max(xc - h, 0); xb[i] = min(xc + h, cols);
         // T(ya - 1, xa - 1) = T'[ya][xa + 3], ...: byte offsets row * pitch8 + 8 * col + 24
-        const uint32_t ra = (uint32_t)__umul24(ya[i], pitch8), rb = (uint32_t)__umul24(yb[i], pitch8);       // rows <= 2^14, pitch8 < 2^24: exact in 32 bits (check_effect)
+        const uint32_t ra = (uint32_t)__umul24(ya[i], pitch8), rb = (uint32_t)__umul24(yb[i], pitch8);       // both factors < 2^24 and (rows + 1) * pitch8 < 2^32: launch_defocus refuses any larger table
         const uint32_t ca = 8u * (uint32_t)xa[i] + 24u, cb = 8u * (uint32_t)xb[i] + 24u;
         C[i][0] = tab_load(rsrc, ra + ca); C[i][1] = tab_load(rsrc, ra + cb); C[i][2] = tab_load(rsrc, rb + ca); C[i][3] = tab_load(rsrc, rb + cb);
         const int wd = xb[i] - xa[i], ht = yb[i] - ya[i];
-        cnt[i] = (wd > 0 && ht > 0) ? (uint32_t)__umul24(ht, wd) : 0u;   // (both <= 2^14)
+        cnt[i] = (wd > 0 && ht > 0) ? (uint32_t)__umul24(ht, wd) : 0u;   // (both < 2^16: rows^2 + cols^2 < 2^31, check_effect)
     }
 #pragma unroll
     for (int i = 0; i < kLk2Rows; i++) {
@@ -751,6 +751,11 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
     const int RB = rb_env >= 4 && rb_env <= 32 && rb_env % 4 == 0 ? rb_env : rows <= 1536 ? 4 : rows <= 3072 ? 16 : 32;
     const int nbands = (rows + RB - 1) / RB;
     const size_t table_entries = ((size_t)rows + 1) * tpitch;
+    // k_defocus addresses the padded table with 32-bit BYTE offsets (one 24-bit multiply per corner row) through a buffer resource whose
+    // num_records is a 32-bit byte count: the table must stay below 4 GiB and both factors of that multiply below 2^24.  check_effect
+    // only bounds rows^2 + cols^2 < 2^31, which admits rows x cols up to 2^30 -- an 8.6 GB table whose offsets would wrap and read zeros.
+    if (table_entries * sizeof(u64) >= (1ull << 32) || (size_t)tpitch * sizeof(u64) >= (1u << 24) || (size_t)rows + 1 >= (1u << 24))
+        return fail(ctx, RTDD_ERR_INVALID, "image too large for the defocus table (its 8 bytes per pixel must stay below 4 GiB: about 536 million pixels)");
     const size_t need = ((table_entries + (size_t)nbands * tp) * sizeof(u64) + 256) / sizeof(uint32_t);   // padded table + band bases, in u32 words
     if (ctx->sat_elems < need) {
         if (ctx->sat) { RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream)); RTDD_HIP(ctx, hipFree(ctx->sat)); ctx->sat = nullptr; ctx->sat_elems = 0; }

@@ -59,6 +59,28 @@ struct Batch {
 };
 #define RTDD_Z(ptr, stride) ptr = (decltype(ptr))((const char *)(ptr) + (size_t)blockIdx.z * (size_t)(stride))
 
+// What a solve is told BESIDES the reference's own arguments (GPUMatrixFreeSolver's, src/GPUSolver.cu:274-275).  Passed down the call
+// chain by value or const reference -- estimate_levels -> solve_with -> the launchers -- and stored by value in the pending-call log
+// (PendingOp): nothing is parked in the context around a call, so a replay restores nothing by hand.
+struct SolveTargets {
+    Batch batch;                                    // the images the launches cover (n = 1, first = 0: one image)
+    bool defer_finish = false;                      // leave the result in its plane: the next level's pyrUp kernel reads it there
+    uint8_t *u8 = nullptr; size_t u8_pitch = 0;     // the copy-back kernel also writes the u8 map here (src/main.cpp:290) ...
+    uint8_t *u8b = nullptr; size_t u8b_pitch = 0;   // ... and a second copy here (a live frame's staging slot or the host's buffer)
+    bool logged = true;                             // false: a step of a larger logged call (an estimate's per-level solves)
+};
+// What a solve hands back to a caller inside the library: its sequence number (what the guarded copy-back kernels report) and the
+// plane its result is in (defer_finish).
+struct SolveOutcome { int seq = 0, plane = -1; };
+// A live frame's own images (cascade_api.cpp): the level-0 annotation pair its estimate ran on, the second target of its u8 map
+// (u8_pitch 0: a staging slot with the pyramid's pitch), and the sticky depth effect behind it (src/main.cpp:190-230) with its target.
+struct LiveTargets {
+    void *scribble = nullptr, *edited = nullptr;
+    uint8_t *u8 = nullptr; size_t u8_pitch = 0;
+    int effect = 0;                                 // RTDD_EFFECT_*
+    uint8_t *artistic = nullptr; size_t artistic_pitch = 0;     // device image the effect writes (the frame's staging slot)
+};
+
 struct Options {
     int fp_contract = 1;
     int sweep_kernel = 0;
@@ -94,14 +116,12 @@ struct PendingOp {
     const uint8_t *gray = nullptr; size_t grayPitch = 0;
     int rows = 0, cols = 0, level = 0, seq = 0;
     rtdd_solve_params params{};
-    uint8_t *finish_u8 = nullptr; size_t finish_u8_pitch = 0;
+    SolveTargets targets;                 // (rtdd_refine_depth: the selected image of a batch, the u8 copy of the result)
     // kEstimate
     int maxIterations = 0;
     int level_seq[32] = {};               // sequence number of level l's solve (0: the level is empty)
     int batch_first = 0, batch_n = 1;     // the images of the context's batched pyramid the estimate covers
-    void *live_images[3] = {nullptr, nullptr, nullptr};   // a live frame: the level-0 scribble / edited pair it ran on and the u8 staging slot its map is also written to (cascade_api.cpp)
-    size_t live_u8_pitch = 0;                             // ... that target's pitch when it is the host's own buffer (0: the staging slot)
-    uint8_t *u8_copy = nullptr; size_t u8_copy_pitch = 0;   // live mode: the u8 map is copied here (device) behind the estimate
+    LiveTargets live;                     // a live frame: its annotation pair, its map's second target, its effect (scribble == nullptr: not one)
     unsigned long long id = 0;            // position in the context's call order (live mode drops the confirmed prefix of the log)
     // kDefocus / kDesaturate / kHaze: a depth effect queued BEHIND an unconfirmed solve (it may have read that solve's input instead of
     // its result); `depth` / `depthPitch` / `gray` / `grayPitch` / `rows` / `cols` above, and:
@@ -130,8 +150,6 @@ struct rtdd_ctx {
     std::vector<rtdd::Level> levels;
     int alloc_images = 1;               // how many images' planes the NEXT rtdd_allocate makes every level hold (rtdd_pyramid_create_batch; one shot)
     int levels_images = 1;              // ... and how many the levels hold now
-    void *live_images[3] = {nullptr, nullptr, nullptr};   // set by rtdd_live_submit around its estimate (logged with it)
-    rtdd::Batch batch;                  // the images the launches of the call in progress cover (cascade_api.cpp); n = 1, first = 0 otherwise
     int maxLevel = -1;
     bool weights_loaded = false;
     float lut_host[257];
@@ -140,26 +158,17 @@ struct rtdd_ctx {
     int omega_cap = 0;
     float *residual_dev = nullptr;  // extension: residual reduction target
     int *sync_words = nullptr;      // control words of the persistent kernels (persist_sync.hpp); allocated with the context
-    // The estimate driver (cascade_api.cpp) takes two launches out of every pyramid level: with `defer_finish` set rtdd_solve_ex leaves
-    // its result in plane `deferred_plane` (the pyrUp kernel of the next level then reads it there and writes the caller's buffer on
-    // the side), and a non-null `finish_u8` makes the final copy-back write the u8 depth map too.
-    bool defer_finish = false;
-    int deferred_plane = -1;
-    uint8_t *finish_u8 = nullptr;
-    size_t finish_u8_pitch = 0;
-    uint8_t *finish_u8b = nullptr;       // ... and a second copy of that map (a live frame's staging slot)
-    size_t finish_u8b_pitch = 0;
-    size_t live_u8_pitch = 0;            // a live frame whose second target is the HOST's own page-locked buffer: its pitch (0: the staging slot's)
     int defocus_last_path = 0;           // RTDD_OPT_DEFOCUS_LAST_PATH: what the most recent rtdd_simulate_defocus launched (1 table, 2 tile kernel)
     bool defocus_table_sticky = false;   // a tile-kernel defocus met out-of-range depths (seen at a synchronisation): automatic choice = the table from then on
     int flag_epoch = 0;             // the per-tile flags of the persistent kernels only ever grow: base value of the next persistent launch (api.cpp)
     int sync_header[2] = {0, 0};    // what sync_words[kSyncWithhold], [kSyncLimit] currently hold on the device
+    int last_nominal_depth = 0;     // sweeps per launch / exchange the most recent blocked solve was configured with (its last launch may be shorter)
+    int last_launch_images = 1;     // images each sweep launch of the most recent solve covered (sweep_blocked.hip: a batch in the same launches, or image after image)
     rtdd_solve_info last_info{};    // of the most recent solve; kernel/tile/temporal_depth/persistent are filled in by the sweep launchers
     // Self-healing after RTDD_ERR_TIMEOUT (api.cpp heal_pending): every solve / estimate since the last status check, in call order
     int solve_seq = 0;              // sequence number of the most recent rtdd_solve_ex (1 .. 2^30, never 0)
     std::vector<rtdd::PendingOp> pending;
     bool pending_overflow = false;  // more than kMaxPendingOps calls without a synchronisation: a timeout among them is reported, not healed
-    bool in_estimate = false;       // rtdd_estimate_depth logs itself; its per-level solves do not
     bool healing = false;           // a replay is running: nothing is logged, a second timeout is final
     bool heal_warned = false;
     int heals = 0;                  // RTDD_OPT_TIMEOUT_HEALS
@@ -169,7 +178,6 @@ struct rtdd_ctx {
     int persist_suspend = 0;        // RTDD_OPT_PERSISTENT_SUSPENDED
     int *confirm_host = nullptr;    // page-locked: sequence number of the latest solve whose copy-back kernel published its result (persist_sync.hpp)
     unsigned long long op_counter = 0;
-    int guard_seq = 0;              // sequence number the next guarded copy-back kernel reports when it finds the status word set
     bool persistent_used = false;   // a launch that can set the status word (sync_words[kSyncStatus]) happened since the last status check
     signed char persist_fit[17][2];  // per (tile id, contraction): does one workgroup of the persistent kernel fit a CU of THIS device (-1 = not asked yet)
     rtdd::Bounce bounce;            // host <-> device 2-D copies with an unaligned host pitch, on ctx->stream (copy_h2d / copy_d2h, cascade_api.cpp)
@@ -226,19 +234,22 @@ struct DeviceGuard {
 };
 
 // ---- solver_kernels.hip -------------------------------------------------------------------------
+// (B: the images a batched launch covers; L is image B.first's view of the level)
 int launch_prepare(rtdd_ctx *ctx, const Level &L, size_t ip, const float *depth, size_t depthPitch,
                    const uint8_t *scribble, size_t scribblePitch, const uint8_t *gray, size_t grayPitch,
-                   int rows, int cols, int level);
+                   int rows, int cols, int level, const Batch &B);
 // Both sweep launchers advance n sweeps from (plane *pk = x_k, plane *pm = x_{k-1}) and update *pk / *pm to
 // the planes holding x_{k+n} / x_{k+n-1}.
 int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_host, int n,
                   int *pk, int *pm, int *launches);
 // sweep_blocked.hip
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
-                          int *pk, int *pm, int *launches);
+                          int *pk, int *pm, int *launches, int images = 1);
 // (k_finish and k_pyrup_inject store NOTHING when the status word is set: a timed-out solve leaves the caller's buffers as they were;
 // the first of them to find it set records ctx->guard_seq in sync_words[kSyncFailedSeq])
-int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols, uint8_t *u8 = nullptr, size_t u8Pitch = 0);
+// (seq: the solve's sequence number, reported by the kernel either as confirmed or as the first failed one; t: the batch and the u8 targets)
+int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols,
+                  const SolveTargets &t, int seq);
 int launch_index_to_weight(rtdd_ctx *ctx, const uint8_t *gray, size_t grayPitch, const float *depth, size_t depthPitch,
                            int32_t *index2, int level, int rows, int cols);
 int launch_residual(rtdd_ctx *ctx, const Level &L, size_t ip, int plane, int rows, int cols, float *host_out);
@@ -278,14 +289,16 @@ int launch_bgr2gray(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, uint8_t *gray,
 int launch_pyrdown_u8(rtdd_ctx *ctx, const uint8_t *src, size_t sp, int rows, int cols, uint8_t *dst, size_t dp);
 struct PyrupBatch { int n = 1; size_t src = 0, dst = 0, edited = 0, mask = 0, coarse = 0; };      // images and byte strides of a batched pyrUp
 int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, int cols, float *dst, size_t dp, int drows, int dcols,
-                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out = nullptr, size_t cp = 0, bool guarded = false,
-                        const PyrupBatch *batch = nullptr);
+                        const uint8_t *edited, size_t ep, const uint8_t *mask, size_t mp, float *coarse_out = nullptr, size_t cp = 0,
+                        int guard_seq = 0 /* != 0: guarded like k_finish, reporting this sequence number */, const PyrupBatch *batch = nullptr);
 int launch_depth_to_u8(rtdd_ctx *ctx, const float *src, size_t sp, uint8_t *dst, size_t dp, int rows, int cols);
 int launch_decode_annotation(rtdd_ctx *ctx, const uint8_t *bgr, size_t bp, const uint8_t *ann, size_t ap, uint8_t *edited, size_t ep,
                              uint8_t *scribble, size_t sp, int rows, int cols);
 int launch_fill_f32(rtdd_ctx *ctx, float *dst, size_t dp, int rows, int cols, float v);
 void pyramid_free(rtdd_ctx *ctx);
-void pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited);   // an annotation image is about to be written: one of the pyramid's?
+// an annotation image is about to be written: one of the pyramid's?  RTDD_ERR_STATE for a level-0 pointer a live frame has retired
+int pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited);
+int pyramid_check_read(rtdd_ctx *ctx, const void *a, const void *b);     // ... about to be read
 
 // persistent kernels (persist_sync.hpp): reserve the launch's flag values and refresh the debug words before a persistent launch;
 // read the status word where the stream has just been synchronised (-> RTDD_ERR_TIMEOUT, status cleared)
@@ -295,7 +308,12 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve = false);
 void prune_confirmed(rtdd_ctx *ctx);    // drop the logged calls a copy-back kernel has confirmed (no synchronisation)
 int settle_pending(rtdd_ctx *ctx);      // before a call changes what the logged calls ran on: synchronise + check (+ heal) while that state still exists
 // cascade_api.cpp: levels from_level .. 0 of an estimate (src/main.cpp:261-291); level_seq (optional) receives each level's solve sequence number
-int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq, int first = 0, int n = 1);
+int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level_seq, int first, int n, const LiveTargets &live);
+// api.cpp: rtdd_solve_ex with everything the library's own callers add to it
+int solve_with(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch, const uint8_t *gray, size_t grayPitch,
+               int rows, int cols, int level, const rtdd_solve_params *params, rtdd_solve_info *info, const SolveTargets &t, SolveOutcome *out);
+// cascade_api.cpp: a live frame's effect (again, on a replay): RTDD_EFFECT_* on the pyramid's level-0 images into live.artistic
+int live_effect(rtdd_ctx *ctx, const LiveTargets &live);
 // an estimate of the pending log again, from the level whose solve has sequence number failed_seq (0: every level)
 int estimate_replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq);
 

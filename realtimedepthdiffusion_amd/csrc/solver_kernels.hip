@@ -401,10 +401,10 @@ static inline dim3 grid64x4(int rows, int cols, int images = 1) { return dim3((c
 
 int launch_prepare(rtdd_ctx *ctx, const Level &L, size_t ip, const float *depth, size_t depthPitch,
                    const uint8_t *scribble, size_t scribblePitch, const uint8_t *gray, size_t grayPitch,
-                   int rows, int cols, int level) {
+                   int rows, int cols, int level, const Batch &B) {
     const int gated = level != ctx->maxLevel;
     const int thr = level == 0 ? 0 : 4;
-    const Batch &B = ctx->batch;                // (n = 1: one image, strides unused; L is already image B.first's view)
+    // (B.n = 1: one image, strides unused; L is already image B.first's view)
     const size_t zP = L.elems * sizeof(float);
     const bool aligned = ((uintptr_t)depth % 16 == 0) && depthPitch % 16 == 0 && ((uintptr_t)gray % 4 == 0) && grayPitch % 4 == 0 &&
                          ((uintptr_t)scribble % 4 == 0) && scribblePitch % 4 == 0 && B.depth % 16 == 0 && B.gray % 4 == 0 && B.scribble % 4 == 0;
@@ -462,13 +462,16 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
     return RTDD_OK;
 }
 
-int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols, uint8_t *u8, size_t u8Pitch) {
-    const Batch &B = ctx->batch;
+int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float *depth, size_t depthPitch, int rows, int cols,
+                  const SolveTargets &t, int seq) {
+    const Batch &B = t.batch;
     const size_t zP = L.elems * sizeof(float);
     if ((uintptr_t)depth % 16 == 0 && depthPitch % 16 == 0 && B.depth % 16 == 0 && B.u8 % 4 == 0)
-        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq, zP, B.depth, B.u8, ctx->finish_u8b, ctx->finish_u8b_pitch);
+        hipLaunchKernelGGL(k_finish4, grid64x4(rows, (cols + 3) / 4, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch,
+                           rows, cols, t.u8, t.u8_pitch, ctx->sync_words, seq, zP, B.depth, B.u8, t.u8b, t.u8b_pitch);
     else
-        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch, rows, cols, u8, u8Pitch, ctx->sync_words, ctx->guard_seq, zP, B.depth, B.u8, ctx->finish_u8b, ctx->finish_u8b_pitch);
+        hipLaunchKernelGGL(k_finish, grid64x4(rows, cols, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch,
+                           rows, cols, t.u8, t.u8_pitch, ctx->sync_words, seq, zP, B.depth, B.u8, t.u8b, t.u8b_pitch);
     ctx->persistent_used = true;                  // (the guard may have recorded a failed solve: the next synchronising call looks)
     RTDD_LAUNCH_CHECK(ctx, "k_finish");
     return RTDD_OK;

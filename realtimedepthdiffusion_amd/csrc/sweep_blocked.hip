@@ -553,9 +553,9 @@ static bool persistent_possible(rtdd_ctx *ctx, int tile, int nthreads) {
 
 template <int LX, int NT, int G>
 static void launch_cfg(rtdd_ctx *ctx, dim3 grid, int xcd_tiles, int nthreads, float *Xk, float *Xm, float *Yk, float *Ym, const uint32_t *M,
-                       const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma, int block_sweeps, int flag_base, size_t zPlane) {
+                       const float *omegas, int ip, int rows, int cols, int hx, int hy, int n, float gamma, int block_sweeps, int flag_base, size_t zPlane, int images) {
     const bool persist = block_sweeps < n;
-    const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles, 1, ctx->batch.n) : dim3(grid.x, grid.y, ctx->batch.n);
+    const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles, 1, images) : dim3(grid.x, grid.y, images);
 #define RTDD_LAUNCH(C, P) hipLaunchKernelGGL((k_sweep_blocked<LX, NT, G, C, P>), launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, M, ctx->lut_dev, omegas, ip, rows, cols, hx, hy, n, gamma, block_sweeps, ctx->sync_words, (int)grid.x, (int)grid.y, xcd_tiles, flag_base, zPlane)
     if (ctx->opt.fp_contract) { if (persist) RTDD_LAUNCH(true, true); else RTDD_LAUNCH(true, false); }
     else { if (persist) RTDD_LAUNCH(false, true); else RTDD_LAUNCH(false, false); }
@@ -623,7 +623,7 @@ static double config_cost(const rtdd_ctx *ctx, int rows, int cols, int n, int ti
     return t / T;
 }
 
-static double choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fixed_tile, int fixed_T, int *tile, int *T, bool *persist) {
+static double choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int fixed_tile, int fixed_T, int *tile, int *T, bool *persist, int images) {
     static const int tiles[] = {4, 8, 9, 14, 6, 5, 7, 12};
     static const int depths[] = {4, 8, 12, 16, 24, 28};
     double best = 1e30;
@@ -634,7 +634,7 @@ static double choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int 
             if (fixed_T && d != fixed_T) continue;
             for (int p = 0; p < 2; p++) {
                 if (p && !ctx->opt.persistent) continue;
-                const double c = config_cost(ctx, rows, cols, n, ti, d, p != 0, ctx->batch.n);
+                const double c = config_cost(ctx, rows, cols, n, ti, d, p != 0, images);
                 if (c < best) { best = c; *tile = ti; *T = d; *persist = p != 0; }
             }
         }
@@ -642,7 +642,7 @@ static double choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int 
     if (fixed_tile && best >= 1e30) *tile = fixed_tile;
     if (fixed_T && best >= 1e30) *T = fixed_T;
     if (getenv("RTDD_DEBUG_CONFIG"))
-        fprintf(stderr, "[rtdd] %dx%d x %d image(s) n=%d -> tile %d depth %d persistent %d (model %.3f us/sweep)\n", cols, rows, ctx->batch.n, n, *tile, *T, (int)*persist, best);
+        fprintf(stderr, "[rtdd] %dx%d x %d image(s) n=%d -> tile %d depth %d persistent %d (model %.3f us/sweep)\n", cols, rows, images, n, *tile, *T, (int)*persist, best);
     return best;
 }
 
@@ -651,32 +651,31 @@ static double choose_config(const rtdd_ctx *ctx, int rows, int cols, int n, int 
     RTDD_TILE_CASE(6, 16, 512, 3) RTDD_TILE_CASE(7, 16, 256, 3) RTDD_TILE_CASE(8, 32, 1024, 2) RTDD_TILE_CASE(9, 16, 1024, 1) RTDD_TILE_CASE(10, 16, 512, 2) \
     RTDD_TILE_CASE(11, 32, 1024, 1) RTDD_TILE_CASE(12, 32, 768, 4) RTDD_TILE_CASE(13, 32, 512, 6)
 
-static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n, int *pk, int *pm, int *launches);
+static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n, int *pk, int *pm, int *launches, int images);
 
 // Runs n sweeps starting from planes (pk = x_k, pm = x_{k-1}); on return *pk / *pm name the planes
 // holding x_{k+n} / x_{k+n-1}.  omegas_dev[0..n) must already be on the device.
-// A batch (ctx->batch.n images, rtdd_estimate_depth_batch) runs as ONE sequence of launches over all images (blockIdx.z) -- unless one
+// A batch (`images` images, rtdd_estimate_depth_batch) runs as ONE sequence of launches over all images (blockIdx.z) -- unless one
 // image alone already fills the chip and would run persistently (1080p: 252 tiles): then image after image, each with the launch a
 // single solve gets, which the model prices lower than a launch per block over the whole batch.
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
-                          int *pk, int *pm, int *launches) {
-    const int images = ctx->batch.n;
+                          int *pk, int *pm, int *launches, int images) {
 #ifdef RTDD_FORCE_CFG_HOOK
     {   // developer's hook (A/B builds only): RTDD_FORCE_CFG="cols,rows,tile,depth,persistent,per_image;..." pins the choice for a level size
         static const char *env = getenv("RTDD_FORCE_CFG");
         for (const char *q = env; q && *q;) {
             int c = 0, r = 0, ti = 0, d = 0, pe = 0, pi = 0;
             if (sscanf(q, "%d,%d,%d,%d,%d,%d", &c, &r, &ti, &d, &pe, &pi) == 6 && c == cols && r == rows) {
-                const Options saved_opt = ctx->opt; const Batch saved = ctx->batch;
+                const Options saved_opt = ctx->opt;
                 ctx->opt.tile = ti; ctx->opt.temporal_depth = d; ctx->opt.persistent = pe;
                 int rc = RTDD_OK, a = *pk, b = *pm, total = 0;
                 if (pi) {
                     for (int i = 0; i < images && rc == RTDD_OK; i++) {
-                        a = *pk; b = *pm; int ln = 0; ctx->batch.n = 1;
-                        rc = launch_sweeps_blocked_impl(ctx, L.view(i), ip, rows, cols, omegas_dev, n, &a, &b, &ln); total += ln;
+                        a = *pk; b = *pm; int ln = 0;
+                        rc = launch_sweeps_blocked_impl(ctx, L.view(i), ip, rows, cols, omegas_dev, n, &a, &b, &ln, 1); total += ln;
                     }
-                } else rc = launch_sweeps_blocked_impl(ctx, L, ip, rows, cols, omegas_dev, n, &a, &b, &total);
-                ctx->opt = saved_opt; ctx->batch = saved;
+                } else rc = launch_sweeps_blocked_impl(ctx, L, ip, rows, cols, omegas_dev, n, &a, &b, &total, images);
+                ctx->opt = saved_opt;
                 *pk = a; *pm = b; *launches = total;
                 return rc;
             }
@@ -686,11 +685,8 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
 #endif
     if (images > 1 && ctx->opt.tile == 0 && ctx->opt.temporal_depth == 0 && !(cols <= 128 && rows <= 96)) {
         int t1, T1, tb, Tb; bool p1, pb;
-        const Batch saved = ctx->batch;
-        ctx->batch.n = 1;
-        const double c1 = choose_config(ctx, rows, cols, n, 0, 0, &t1, &T1, &p1);
-        ctx->batch = saved;
-        const double cb = choose_config(ctx, rows, cols, n, 0, 0, &tb, &Tb, &pb);
+        const double c1 = choose_config(ctx, rows, cols, n, 0, 0, &t1, &T1, &p1, 1);
+        const double cb = choose_config(ctx, rows, cols, n, 0, 0, &tb, &Tb, &pb, images);
         // (the model prices a persistent 1080p launch at 2.5 us per sweep; it runs at 1.5 -- profiles/r05_1080p_jacobi1000_* -- and 64 images
         // one after the other take 5.96 ms where one launch per block over the batch takes 6.83: scripts/batch_level_ab.py)
         if (p1 && 0.6 * c1 * images < cb) {
@@ -698,20 +694,18 @@ int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, in
             for (int i = 0; i < images && rc == RTDD_OK; i++) {
                 a = *pk; b = *pm;
                 int ln = 0;
-                ctx->batch.n = 1;
-                rc = launch_sweeps_blocked_impl(ctx, L.view(i), ip, rows, cols, omegas_dev, n, &a, &b, &ln);
+                rc = launch_sweeps_blocked_impl(ctx, L.view(i), ip, rows, cols, omegas_dev, n, &a, &b, &ln, 1);
                 total += ln;
             }
-            ctx->batch = saved;
             *pk = a; *pm = b; *launches = total;
             return rc;
         }
     }
-    return launch_sweeps_blocked_impl(ctx, L, ip, rows, cols, omegas_dev, n, pk, pm, launches);
+    return launch_sweeps_blocked_impl(ctx, L, ip, rows, cols, omegas_dev, n, pk, pm, launches, images);
 }
 
 static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
-                                      int *pk, int *pm, int *launches) {
+                                      int *pk, int *pm, int *launches, int images) {
     const float gamma = 0.99;
     // Tile / depth / persistence choice: a small cost model calibrated on MI355X measurements
     // (scripts/tile_sweep*.sh, scripts/size_sweep.sh, scripts/ubench/*; tables in profiles/).
@@ -724,8 +718,8 @@ static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, 
         // a batch whose images each fit ONE 128 x 96 tile: a workgroup per image, every sweep in one launch, no halo and no exchange
         // (64 x 120x67 x 1000 sweeps: 0.76 ms against 1.92 for four persistent tiles per image; a single image is better off spread
         // over the chip in the column layout, 0.46 ms)
-        else if (ctx->batch.n > 1 && cols <= 128 && rows <= 96) { bt = 4; bT = 8; }
-        else choose_config(ctx, rows, cols, n, tile, T, &bt, &bT, &bp);
+        else if (images > 1 && cols <= 128 && rows <= 96) { bt = 4; bT = 8; }
+        else choose_config(ctx, rows, cols, n, tile, T, &bt, &bT, &bp, images);
         if (tile == 0) tile = bt;
         if (T == 0) T = bT;
         if (ctx->opt.tile == 0 && ctx->opt.temporal_depth == 0) want_persistent = want_persistent && bp;
@@ -737,6 +731,7 @@ static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, 
     while (T > 1 && (EW - 2 * ((T + 3) / 4 * 4) < 8 || EH - 2 * T < 8)) T--;   // keep a non-degenerate written-back region
     int done = 0;
     *launches = 0;
+    ctx->last_nominal_depth = single ? n : T;     // (last_info.temporal_depth reports the LAST launch: possibly the short tail block)
     while (done < n) {
         int m = single ? n - done : (n - done < T ? n - done : T);
         const int hy = single ? 0 : (n - done < T ? n - done : T);
@@ -754,7 +749,6 @@ static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, 
         // PERSISTENT mode: all remaining sweeps in ONE launch, neighbouring workgroups trade halo strips every T sweeps.
         // Only when every workgroup is certainly co-resident (grid <= #CUs), T is even, and there is more than one block.
         int block_sweeps = m;
-        const int images = ctx->batch.n;
         bool persistent = !single && want_persistent && (int)(grid.x * grid.y) * images <= ctx->num_cus && grid.x * grid.y * images <= (unsigned)kSyncMaxTiles &&
                                 (T % 2 == 0) && n - done > T && hy == T &&
                                 hx <= TW && hy <= TH;      // the halo must lie inside the 8 immediate neighbours' centres
@@ -782,7 +776,7 @@ static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, 
         float *Yk = L.P(free0, ip), *Ym = L.P(free1, ip);
         const size_t zPlane = L.elems * sizeof(float);
 #define RTDD_TILE_CASE(id, LX_, NT_, G_) \
-    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps, flag_base, zPlane); break;
+    case id: launch_cfg<LX_, NT_, G_>(ctx, grid, xcd_tiles, nthreads, Xk, Xm, Yk, Ym, L.M(ip), omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, block_sweeps, flag_base, zPlane, images); break;
         if (is_col_tile(tile)) {
             const dim3 launch_grid = xcd_tiles > 0 ? dim3(8 * xcd_tiles, 1, images) : dim3(grid.x, grid.y, images);
             if (ctx->opt.fp_contract) hipLaunchKernelGGL(k_sweep_col<true>, launch_grid, dim3(nthreads), 0, ctx->stream, Xk, Xm, Yk, Ym, L.M(ip), ctx->lut_dev, omegas_dev + done, (int)ip, rows, cols, hx, hy, m, gamma, (int)grid.x, (int)grid.y, xcd_tiles, ctx->sync_words, zPlane);
@@ -798,6 +792,7 @@ static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, 
             ctx->opt.debug_force_status = 0;
         }
         ctx->last_info.kernel = 2; ctx->last_info.tile = tile; ctx->last_info.temporal_depth = persistent ? block_sweeps : m; ctx->last_info.persistent = persistent ? 1 : 0;
+        ctx->last_launch_images = images;
         // where the results are: the plain launch writes the spare pair; the persistent one the exchange buffer of its
         // last block's parity (blocks 0,2,.. -> spare pair, 1,3,.. -> the input pair)
         const int nblocks = (m + block_sweeps - 1) / block_sweeps;

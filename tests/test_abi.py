@@ -67,7 +67,7 @@ def test_no_signature_leaks_cxx_or_torch_types():
 
 def test_library_loads_and_reports_status_strings(so):
     L = rt.lib()
-    assert L.rtdd_version() == 220          # 2xx: rtdd_solve_info is 36 bytes; 210: self-healing time-out; 220: re-armed persistence, batched estimates (include/rtdd.h)
+    assert L.rtdd_version() == 230          # 2xx: rtdd_solve_info is 36 bytes; 210: self-healing time-out; 220: re-armed persistence, batched estimates; 230: rtdd_pyramid_level_info (include/rtdd.h)
     assert L.rtdd_status_string(0) == b"ok"
     assert b"no CPU fallback" in L.rtdd_status_string(5)
     assert L.rtdd_ctx_create(C.c_int(0), None) == 1          # null out pointer -> RTDD_ERR_INVALID, no crash

@@ -110,6 +110,19 @@ def test_config4_batch64_on_one_gpu_verified():
 @pytest.mark.gpu
 def test_two_ranks_run_their_share_of_a_batch_as_batched_estimates():
     """Two ranks through the launcher, each its three images of a batch of six as ONE batched pyramid (rtdd_estimate_depth_batch)."""
-    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", "batch6_540x960x400_estimate"], env={"RTDD_BENCH_SHARE_GPU": "1"})
+    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", "batch6_540x960x400_estimate", "--verify"], env={"RTDD_BENCH_SHARE_GPU": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["images_per_step"] == 6 and d["config"]["images_this_rank"] == 3
     assert d["value"] > 0 and d["estimates_per_s"] > 0
+    v = d["verified"]               # every rank's three images, all levels + the u8 map, cold and warm-started, against the oracle's cascade
+    assert v["images_differing_all_ranks"] == 0 and v["images_checked_all_ranks"] == 6 and v["rank0_images_checked"] == [0, 2, 4], v
+
+
+@pytest.mark.gpu
+def test_the_batched_estimate_workload_the_bench_line_quotes_is_verified():
+    """`batch64_1080p_estimate` at N = 1 with --verify: the timed batch's sampled images (0, 1, 7, 8, 31, 32, 62, 63) against the oracle's
+    cascade level by level, and the per-level choices of the timed batch reported next to the figure."""
+    d = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", "batch64_1080p_estimate", "--verify"], timeout=900)
+    v = d["verified"]
+    assert v["images_differing_all_ranks"] == 0 and v["rank0_images_checked"] == [0, 1, 7, 8, 31, 32, 62, 63] and v["levels"] == 5, v
+    assert v["rank0_level_choices"]["0"]["images_per_launch"] == 1 and v["rank0_level_choices"]["4"]["images_per_launch"] == 64
+    assert d["estimates_per_s"] > 0

@@ -122,3 +122,49 @@ def test_a_batch_heals_a_timed_out_persistent_level(capfd):
         assert capfd.readouterr().err.count("rtdd: persistent sweep kernel") == 1
         for b in range(images):
             _compare(c, b, want[b][0], "healed batch")
+
+
+# ---- the batches bench.py TIMES (batch64_1080p_estimate: 64 images at N = 1, 8 per GPU at N = 8) --------------------------------------
+# The per-level tile / depth / persistence choice is a function of the batch size (sweep_blocked.hip config_cost / launch_sweeps_blocked),
+# so the batch sizes of the other tests (2 .. 9) exercise other kernel configurations than the ones the bench line's numbers come from.
+# Pinned here: what each level of those two batches runs -- (tile, sweeps per launch or exchange, persistent, images per sweep launch),
+# level 0 = 1920 x 1080 -- so that a change of the cost model shows up as a failing test next to the figure it would change.
+BENCH_BATCH_CHOICES = {
+    # 120 x 67: a workgroup per image, all 1000 sweeps in one launch; 240 x 135: four persistent tiles per image; 480 x 270 and 960 x 540: one launch
+    # per 8 sweeps over all images; 1920 x 1080: image after image, each the persistent launch a single solve gets (profiles/r05_batch_level_ab.txt)
+    64: {4: (4, 1000, 0, 64), 3: (4, 4, 1, 64), 2: (6, 8, 0, 64), 1: (6, 8, 0, 64), 0: (4, 8, 1, 1)},
+    8: {4: (4, 1000, 0, 8), 3: (9, 12, 1, 8), 2: (8, 8, 1, 8), 1: (6, 12, 0, 8), 0: (4, 8, 1, 1)},
+}
+
+
+def bench_batch_problem(b, rows=1080, cols=1920):
+    """Image b of bench.py's batch (batch_estimates / the batch64_1080p_estimate workload: seeds 1234 + b)."""
+    from realtimedepthdiffusion_amd.synth import make_problem
+    p = make_problem(rows, cols, seed=1234 + b)
+    return np.repeat(p["gray"][..., None], 3, 2), np.where(p["mask"] == 255, p["edited"][..., 0], 32).astype(np.uint8)
+
+
+@pytest.mark.parametrize("images", [64, 8])
+def test_the_batches_the_bench_times_match_the_oracle(images, oracle, lut):
+    """bench.py's 64 x 1080p batch (and the 8 images a rank owns at N = 8), cold and warm-started: the per-level choices are the pinned
+    ones, and every level + the u8 map of the sampled images equals the oracle's cascade bit for bit (src/main.cpp:232-295)."""
+    rows, cols = 1080, 1920
+    sample = [b for b in (0, 1, 7, 8, 31, 32, 62, 63) if b < images] if images > 8 else list(range(images))
+    refs = {}
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        levels = c.pyramid_create_batch(rows, cols, images)
+        for b in range(images):
+            bgr, ann = bench_batch_problem(b)
+            c.pyramid_select(b); c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann))
+            if b in sample:
+                refs[b] = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads())
+        for what in ("cold", "warm start"):
+            c.estimate_depth_batch(1000); c.synchronize()
+            got = {l: (i.tile, i.temporal_depth, i.persistent, n) for l in range(levels) for i, n in [c.pyramid_level_info(l)]}
+            assert got == BENCH_BATCH_CHOICES[images], f"{images} x 1080p, {what}: the per-level kernel choices changed: {got}"
+            assert all(c.pyramid_level_info(l)[0].kernel == 2 for l in range(levels))
+            for b in sample:
+                refs[b].estimate(1000)
+                _compare(c, b, (refs[b].depth, refs[b].depth_u8), f"{images} x 1080p as bench.py times it, {what}, against the oracle")
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 0

@@ -523,3 +523,92 @@ def test_no_device_memory_is_lost_over_context_lifetimes():
     for i in range(40):
         lifetime(i)
     assert before - free_bytes() < (8 << 20)
+
+
+@pytest.mark.parametrize("effect", ["defocus", "desaturation", "haze"])
+@pytest.mark.parametrize("mode", ["pipelined", "one_at_a_time", "pipelined_withhold", "pageable"])
+def test_live_frames_with_a_sticky_effect_match_the_oracle(oracle, lut, effect, mode):
+    """The reference's frame WITH a sticky effect (src/main.cpp:190-230 next to :232-295; rtdd_live_submit_ex): every frame's u8 map is
+    the oracle's n-th warm-started estimate AND every frame's artistic image is the oracle's effect on that estimate's depth map -- two
+    frames in flight (the artistic image staged, downloaded by rtdd_live_wait), one frame at a time (its download queued on the compute
+    stream), with the first frame's persistent launch timing out (both frames healed, effects rendered again), and into ordinary
+    (pageable) host arrays."""
+    rows, cols = 540, 960
+    bgr, ann = _bgr(rows, cols, 77)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads())
+    code = {"defocus": rt.EFFECT_DEFOCUS, "desaturation": rt.EFFECT_DESATURATION, "haze": rt.EFFECT_HAZE}[effect]
+
+    def want_art(depth):
+        if effect == "defocus":
+            return oracle.defocus(bgr, depth, threads=oracle.max_threads())
+        if effect == "desaturation":
+            return oracle.desaturate(bgr, ref.gray[0], depth, 1)
+        return oracle.haze(bgr, depth, 1)
+    withhold = mode == "pipelined_withhold"
+    depth_in_flight = 1 if mode == "one_at_a_time" else 2
+    mk = _Pageable if mode == "pageable" else rt.host_image
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        c.pyramid_create(rows, cols)
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann)); c.synchronize()
+        scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3))
+        out = [mk((rows, cols)) for _ in range(2)]; art = [mk((rows, cols, 3)) for _ in range(2)]
+        scr.a[...] = ref.scribble[0]; ed.a[...] = ref.edited[0]
+        if withhold:
+            c.set_option(rt.OPT_DEBUG_POLL_LIMIT_US, 3000); c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 1)
+        frames = 5
+        got = []
+        for n in range(frames):
+            if n >= depth_in_flight:
+                k = len(got); c.live_wait(); got.append((out[k % 2].a.copy(), art[k % 2].a.copy()))
+            # (the middle frame without an effect: a frame's effect is its own, the slot's previous image must not leak into it)
+            c.live_submit_ex(scr.a, ed.a, out[n % 2].a, code if n != 2 else rt.EFFECT_NONE, art[n % 2].a if n != 2 else None, 1000)
+        while c.live_pending():
+            k = len(got); c.live_wait(); got.append((out[k % 2].a.copy(), art[k % 2].a.copy()))
+        c.synchronize()
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == (1 if withhold else 0)
+        for n in range(frames):
+            ref.estimate(1000)
+            assert np.array_equal(got[n][0], ref.depth_u8), f"frame {n}: u8 map"
+            if n != 2:
+                assert np.array_equal(got[n][1], want_art(ref.depth[0])), f"frame {n}: artistic image ({effect})"
+        # RTDD_IMG_ARTISTIC on the device names the newest frame's artistic image
+        assert np.array_equal(c.pyramid_download(rt.IMG_ARTISTIC), want_art(ref.depth[0]))
+        with pytest.raises(rt.RtddError):
+            c.live_submit_ex(scr.a, ed.a, out[0].a, code, None, 1000)        # an effect needs a host image
+        with pytest.raises(rt.RtddError):
+            c.live_submit_ex(scr.a, ed.a, out[0].a, 4, art[0].a, 1000)       # unknown effect
+
+
+def test_a_retired_live_annotation_pointer_is_refused(oracle, lut):
+    """After an uploading live frame the pyramid's level-0 scribble / edited images ARE the uploaded pair: a pointer rtdd_pyramid_image
+    handed out before names a buffer no estimate reads.  Painting / uploading / converting through it would lose the strokes silently:
+    RTDD_ERR_STATE instead; the pointers asked for again work, and the stroke painted through them reaches the next estimate."""
+    rows, cols = 135, 241
+    bgr, ann = _bgr(rows, cols, 5)
+    ref = Cascade(oracle, bgr, ann, lut, 1, threads=4)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        c.pyramid_create(rows, cols)
+        c.pyramid_set_image(up(bgr)); c.pyramid_set_annotation(up(ann)); c.synchronize()
+        old_s = c.pyramid_image(rt.IMG_SCRIBBLE, 0); old_e = c.pyramid_image(rt.IMG_EDITED, 0)
+        c.GPUPaintImage(10, 10, 64, 3, (old_e[0], old_e[1]), (old_s[0], old_s[1]), rows, cols)     # fine: still the pyramid's
+        oracle.paint_image(10, 10, 64, 3, ref.edited[0], ref.scribble[0])
+        scr = rt.host_image((rows, cols)); ed = rt.host_image((rows, cols, 3)); out = rt.host_image((rows, cols))
+        scr.a[...] = ref.scribble[0]; ed.a[...] = ref.edited[0]
+        c.live_submit(scr.a, ed.a, out.a, 300); c.live_wait()
+        ref.estimate(300)
+        assert np.array_equal(out.a, ref.depth_u8)
+        with pytest.raises(rt.RtddError) as e:
+            c.GPUPaintImage(50, 60, 128, 4, (old_e[0], old_e[1]), (old_s[0], old_s[1]), rows, cols)
+        assert e.value.status == 2 and "rtdd_pyramid_image again" in str(e.value)
+        host = np.zeros((rows, cols), np.uint8)
+        rc = rt.lib().rtdd_upload(c._h, C.c_void_p(old_s[0]), C.c_size_t(old_s[1]), C.c_void_p(host.ctypes.data), C.c_size_t(cols), C.c_size_t(cols), C.c_int(rows))
+        assert rc == 2
+        new_s = c.pyramid_image(rt.IMG_SCRIBBLE, 0); new_e = c.pyramid_image(rt.IMG_EDITED, 0)
+        assert new_s[0] != old_s[0] and new_e[0] != old_e[0]
+        c.GPUPaintImage(50, 60, 128, 4, (new_e[0], new_e[1]), (new_s[0], new_s[1]), rows, cols)
+        oracle.paint_image(50, 60, 128, 4, ref.edited[0], ref.scribble[0])
+        c.estimate_depth(300); c.synchronize()
+        ref.estimate(300)
+        assert_bit_equal(c.pyramid_download(rt.IMG_DEPTH, 0), ref.depth[0], "the stroke painted through the current pointers reached the estimate")

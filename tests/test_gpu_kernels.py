@@ -296,3 +296,21 @@ def test_dropin_cxx_symbols_run(oracle, lut):
     assert np.array_equal(down(d).view(np.uint32), want.view(np.uint32))      # returns synchronised, like the reference
     L._Z19GPUFreeDeviceMemoryi.restype = None
     L._Z19GPUFreeDeviceMemoryi(i32(1))
+
+
+def test_defocus_refuses_a_table_it_cannot_address():
+    """The global-table defocus addresses its padded table (8 bytes per pixel) with 32-bit byte offsets: an image whose table would reach
+    4 GiB (about 536 million pixels; rtdd_simulate_defocus's own size check admits rows x cols up to 2^30) is refused with
+    RTDD_ERR_INVALID before anything is allocated or launched -- not answered with wrapped offsets and zeros."""
+    import ctypes as C
+    import torch
+    rows = cols = 30000                               # rows^2 + cols^2 = 1.8e9 < 2^31: passes the effect's size check; table = 7.2 GB
+    small = torch.zeros(1024, dtype=torch.uint8, device="cuda:0")
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        L = rt.lib()
+        args = (C.c_void_p(small.data_ptr()), C.c_size_t(cols * 3), C.c_void_p(small.data_ptr()), C.c_size_t(cols * 4),
+                C.c_void_p(small.data_ptr() + 512), C.c_size_t(cols * 3), C.c_int(rows), C.c_int(cols))
+        assert L.rtdd_simulate_defocus(c._h, *args) == 1          # RTDD_ERR_INVALID
+        assert b"too large for the defocus table" in L.rtdd_last_error(c._h)
+        c.synchronize()
