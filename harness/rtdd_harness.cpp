@@ -281,11 +281,14 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
     CK(rtdd_pyramid_image(ctx, RTDD_IMG_ARTISTIC, 0, &p_art, &pi_art, nullptr, nullptr));
     CK(rtdd_pyramid_image(ctx, RTDD_IMG_DEPTH_U8, 0, &p_u8, &pi_u8, nullptr, nullptr));
 
-    // --live N without an effect: the reference's frame loop as it clocks it (main.cpp:232-295) -- every frame uploads the host's
-    // scribble and edited images (:236-237), estimates, downloads the u8 map (:290-291) -- two frames in flight (rtdd_live_submit):
-    // the copies of one frame overlap the arithmetic of the other.
-    if (live && job.effect.empty() && job.refine.empty()) {
-        struct Pinned { void *p = nullptr; ~Pinned() { if (p) rtdd_host_free(p); } } h_scr, h_ed, h_u8[2];
+    // --live N: the reference's frame loop as it clocks it (main.cpp:232-295) -- every frame uploads the host's scribble and edited
+    // images (:236-237), estimates, downloads the u8 map (:290-291) -- two frames in flight (rtdd_live_submit_ex): the copies of one frame
+    // overlap the arithmetic of the other.  With --effect X every frame also renders the sticky effect from its own depth map and brings
+    // the artistic image to the host (main.cpp:190-230 runs in every iteration of the loop once a key has switched the effect on).
+    if (live && job.refine.empty()) {
+        struct Pinned { void *p = nullptr; ~Pinned() { if (p) rtdd_host_free(p); } } h_scr, h_ed, h_u8[2], h_art[2];
+        const int fx = job.effect == "defocus" ? RTDD_EFFECT_DEFOCUS : job.effect == "desaturation" ? RTDD_EFFECT_DESATURATION : job.effect == "haze" ? RTDD_EFFECT_HAZE : RTDD_EFFECT_NONE;
+        if (fx != RTDD_EFFECT_NONE) { CK(rtdd_host_alloc(&h_art[0].p, (size_t)rows * cols * 3)); CK(rtdd_host_alloc(&h_art[1].p, (size_t)rows * cols * 3)); art->resize((size_t)rows * cols * 3); }
         CK(rtdd_upload(ctx, d_bgr, (size_t)cols * 3, job.bgr.px.data(), (size_t)cols * 3, (size_t)cols * 3, rows));
         CK(rtdd_pyramid_set_image(ctx, d_bgr, (size_t)cols * 3));
         if (job.has_ann) {
@@ -299,7 +302,11 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
         CK(rtdd_download(ctx, h_scr.p, cols, p_scr, pi_scr, cols, rows));            // the host's Mats (main.cpp:160-168: decoded on the host there)
         CK(rtdd_download(ctx, h_ed.p, (size_t)cols * 3, p_ed, pi_ed, (size_t)cols * 3, rows));
         depth_u8->resize((size_t)rows * cols);
-        auto landed = [&](int f) { std::memcpy(depth_u8->data(), h_u8[f % 2].p, depth_u8->size()); if (every_map) every_map->push_back(*depth_u8); };
+        auto landed = [&](int f) {
+            std::memcpy(depth_u8->data(), h_u8[f % 2].p, depth_u8->size());
+            if (fx != RTDD_EFFECT_NONE) std::memcpy(art->data(), h_art[f % 2].p, art->size());
+            if (every_map) every_map->push_back(*depth_u8);
+        };
         auto t0 = std::chrono::steady_clock::now();
         for (int n = 0; n < count; n++) {
             bool painted = false;
@@ -321,7 +328,8 @@ static int run_device(int device, const Job &job, int count, bool live, std::vec
                 CK(rtdd_download(ctx, h_ed.p, (size_t)cols * 3, p_ed, pi_ed, (size_t)cols * 3, rows));
             }
             if (rtdd_live_pending(ctx) >= 2) { const int f = n - 2; CK(rtdd_live_wait(ctx)); landed(f); }              // frame n-2's buffer is about to be reused
-            CK(rtdd_live_submit(ctx, (const uint8_t *)h_scr.p, cols, (const uint8_t *)h_ed.p, (size_t)cols * 3, job.iters, (uint8_t *)h_u8[n % 2].p, cols));
+            CK(rtdd_live_submit_ex(ctx, (const uint8_t *)h_scr.p, cols, (const uint8_t *)h_ed.p, (size_t)cols * 3, job.iters, (uint8_t *)h_u8[n % 2].p, cols,
+                                   fx, (uint8_t *)h_art[n % 2].p, (size_t)cols * 3));
         }
         while (rtdd_live_pending(ctx) > 0) { const int f = count - rtdd_live_pending(ctx); CK(rtdd_live_wait(ctx)); landed(f); }
         *ms_per_estimate = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (count > 0 ? count : 1);
@@ -438,10 +446,15 @@ int main(int argc, const char *argv[]) {
     for (int d = 0; d < devices; d++) if (rcs[d]) return 4;
 
     const int total = live > 0 ? live : batch;
-    std::printf("Processing Time: %.3f ms per estimate on device 0 (upload + estimate%s + download); %d estimate(s) on %d device(s) in %.1f ms wall incl. setup\n",
-                ms[0], job.effect.empty() ? "" : " + effect", total, devices, wall);
-    if (live > 0 && job.effect.empty() && job.refine.empty())
-        std::printf("Live: %.1f frames/s (%d frames, annotation upload + estimate + map download per frame, two frames in flight)\n", 1e3 / (ms[0] > 0 ? ms[0] : 1), live);
+    // (the reference's clock() brackets the FIRST estimate of the process, first-call costs included: that figure is --cold's; the default
+    // runs a warm-up estimate and the three effects on a throw-away context first, so that what is printed is the steady cost)
+    std::printf("Processing Time: %.3f ms per estimate on device 0 (upload + estimate%s + download; %s); %d estimate(s) on %d device(s) in %.1f ms wall incl. setup\n",
+                ms[0], job.effect.empty() ? "" : " + effect",
+                job.cold ? "COLD: the process's first estimate, first-call costs included, like the reference's clock()" : "WARM: after a warm-up on a throw-away context; --cold for the first-call figure",
+                total, devices, wall);
+    if (live > 0 && job.refine.empty())
+        std::printf("Live: %.1f frames/s (%d frames, annotation upload + estimate%s + map download per frame, two frames in flight)\n", 1e3 / (ms[0] > 0 ? ms[0] : 1), live,
+                    job.effect.empty() ? "" : " + sticky effect and its image's download");
     if (!write_image(out + (png ? "DepthMap.png" : "DepthMap.pgm"), rgb.w, rgb.h, 1, depth[0].data())) { std::printf("cannot write %sDepthMap\n", out.c_str()); return 5; }
     {                                                                    // main.cpp:298-303: editedImage[0] -- the image with the scribbles in it
         std::vector<unsigned char> o(annotated[0]);

@@ -1,6 +1,7 @@
 // api.cpp -- the extern "C" surface of librtdd.so (include/rtdd.h): context management, argument
 // validation, the per-level solve driver (GPUMatrixFreeSolver, /root/reference/src/GPUSolver.cu:274-316)
 // and thin forwards to the kernel launchers.  Host code only; kernels live in the *.hip files.
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -45,6 +46,7 @@ int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
         RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, (size_t)kSyncMaxTiles * kSyncFlagStride * sizeof(int), ctx->stream));
         ctx->flag_epoch = 0;
     }
+    if (ctx->flag_epoch == 0) ctx->flag_epoch = 1;     // (a launch's workgroups announce themselves with its base value: never the zero the flags start from)
     *flag_base = ctx->flag_epoch;
     ctx->flag_epoch += nblocks + 1;
     const int limit = ctx->opt.debug_poll_limit_us > 0 ? ctx->opt.debug_poll_limit_us * 100 : 0;        // 10 ns ticks
@@ -53,7 +55,7 @@ int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
         RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncLimit), limit, 1, ctx->stream));
         ctx->sync_header[0] = ctx->opt.debug_withhold_tile; ctx->sync_header[1] = limit;
     }
-    ctx->persistent_used = true;
+    note_status_writer(ctx);
     return RTDD_OK;
 }
 
@@ -141,12 +143,23 @@ static const char *kTimeoutText = "persistent sweep kernel: a workgroup timed ou
 // The stream has just been synchronised by the caller.  A blocked-sweep launch since the last check may have given up (persist_sync.hpp).
 int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
     if (!ctx->persistent_used || !ctx->sync_words) { if (!ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } return RTDD_OK; }
+    // The newest guarded copy-back kernel has reported its solve published with the status word clear, and nothing that could set a
+    // control word was queued behind it: the words are clear (they are sticky, and that kernel ran behind every launch that could have
+    // set them) -- no need to read them back.
+    if (!ctx->healing && !ctx->status_writer_behind && ctx->publish_seq != 0 && ctx->confirm_host &&
+        *(volatile int *)ctx->confirm_host == ctx->publish_seq) {
+        ctx->persistent_used = false;
+        ctx->pending.clear(); ctx->pending_overflow = false;
+        return RTDD_OK;
+    }
     int words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RTDD_HIP(ctx, hipMemcpy(words, ctx->sync_words, sizeof(words), hipMemcpyDeviceToHost));
     ctx->persistent_used = false;
     const int status = words[kSyncStatus], failed_seq = words[kSyncFailedSeq];
-    if (words[kSyncNonLocal] != 0) {               // the tile defocus kernel summed windows by hand: not a depth map -- the table path from now on
-        ctx->defocus_table_sticky = true;
+    if (words[kSyncNonLocal] != 0) {               // a defocus kernel summed windows by hand: not a depth map -- bit 0: the tile kernel, the table path
+                                                   // from now on; bit 1: a banded table, one whole-image table from now on
+        if (words[kSyncNonLocal] & 1) ctx->defocus_table_sticky = true;
+        if (words[kSyncNonLocal] & 2) ctx->defocus_band_sticky = true;
         RTDD_HIP(ctx, hipMemset(ctx->sync_words + kSyncNonLocal, 0, sizeof(int)));
     }
     if (status == 0) { if (!ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } return RTDD_OK; }
@@ -193,7 +206,7 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
     if (rc == RTDD_OK) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = fail(ctx, RTDD_ERR_HIP, "hipStreamSynchronize (replay)", e);
-        else { ctx->persistent_used = true; rc = check_persistent_status(ctx); }
+        else { note_status_writer(ctx); rc = check_persistent_status(ctx); }
     }
     ctx->healing = false;
     if (rc != RTDD_OK) return rc;
@@ -306,6 +319,20 @@ int rtdd_ctx_set_stream(rtdd_ctx *ctx, rtdd_stream stream) {
 int rtdd_ctx_synchronize(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     DeviceGuard g(ctx->device);
+    // RTDD_OPT_SYNC_SPIN_US: a blocking wait of more than a few tens of microseconds parks the host thread on an interrupt, and waking
+    // it takes 15-25 us (scripts/sync_cost.py: +11 us behind a 9 us solve, +23 us behind a 100 us one).  The drop-in shim synchronises
+    // behind every pyramid level's solve (src/GPUSolver.cu:314): five such wake-ups per 1080p frame.  Polling the stream from user space
+    // for the solve's length first costs the host a busy core for that long and the frame ~15 us per level less.
+    if (ctx->opt.sync_spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }         // (the blocking call below reports whatever it is)
+            (void)hipGetLastError();                                                // (hipErrorNotReady is sticky in hipGetLastError: clear it)
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > ctx->opt.sync_spin_us) break;
+        }
+    }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return check_persistent_status(ctx);           // (a timed-out persistent launch is healed here: the affected calls run again, api.cpp above)
 }
@@ -317,13 +344,15 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
         case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 2, "sweep kernel must be 0..2"); ctx->opt.sweep_kernel = value; break;
         case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 28, "temporal depth must be 0..28"); ctx->opt.temporal_depth = value; break;
         case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
-        case RTDD_OPT_DEFOCUS_PATH: REQUIRE(ctx, value >= 0 && value <= 2, "defocus path must be 0..2"); ctx->opt.defocus_path = value; if (value == 0) ctx->defocus_table_sticky = false; break;      // (setting the automatic choice again forgets what earlier depths made it choose)
+        case RTDD_OPT_DEFOCUS_PATH: REQUIRE(ctx, value >= 0 && value <= 2, "defocus path must be 0..2"); ctx->opt.defocus_path = value; if (value == 0) ctx->defocus_table_sticky = ctx->defocus_band_sticky = false; break;      // (setting the automatic choice again forgets what earlier depths made it choose)
         case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 16, "tile must be 0..16"); ctx->opt.tile = value; break;
         case RTDD_OPT_PERSISTENT: ctx->opt.persistent = ctx->persistent_wanted = value ? 1 : 0; ctx->persist_suspend = 0; break;    // (said explicitly: armed at once, whatever a heal suspended)
         case RTDD_OPT_ANNOTATION_LDS: ctx->opt.annotation_lds = value ? 1 : 0; break;
         case RTDD_OPT_LIVE_ZERO_COPY: REQUIRE(ctx, value >= 0 && value <= 2, "RTDD_OPT_LIVE_ZERO_COPY is 0, 1 or 2"); ctx->opt.live_zero_copy = value; break;
         case RTDD_OPT_TIMEOUT_HEAL: ctx->opt.timeout_heal = value ? 1 : 0; if (!value && !ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } break;
         case RTDD_OPT_PERSISTENT_REARM_AFTER: REQUIRE(ctx, value >= 0 && value <= (1 << 20), "must be 0..2^20"); ctx->opt.rearm_after = value; break;
+        case RTDD_OPT_DEFOCUS_SLICE_MB: REQUIRE(ctx, value >= 0 && value <= 4095, "must be 0..4095 MB"); ctx->opt.defocus_slice_mb = value; break;
+        case RTDD_OPT_SYNC_SPIN_US: REQUIRE(ctx, value >= 0 && value <= 10000000, "must be 0..1e7 us"); ctx->opt.sync_spin_us = value; break;
         case RTDD_OPT_AUTO_CYCLE_FIXED_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fixed_ns = value; break;
         case RTDD_OPT_AUTO_CYCLE_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fs_per_px = value; break;
         case RTDD_OPT_AUTO_SWEEP_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_sweep_fs_per_px = value; break;
@@ -358,6 +387,9 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_LIVE_ZERO_COPY: *value = ctx->opt.live_zero_copy; break;
         case RTDD_OPT_ANNOTATION_LDS: *value = ctx->opt.annotation_lds; break;
         case RTDD_OPT_PERSISTENT_REARM_AFTER: *value = ctx->opt.rearm_after; break;
+        case RTDD_OPT_SYNC_SPIN_US: *value = ctx->opt.sync_spin_us; break;
+        case RTDD_OPT_DEFOCUS_SLICE_MB: *value = ctx->opt.defocus_slice_mb; break;
+        case RTDD_OPT_DEFOCUS_LAST_SLICES: *value = ctx->defocus_last_slices; break;
         case RTDD_OPT_PERSISTENT_SUSPENDED: *value = ctx->persist_suspend; break;
         case RTDD_OPT_PENDING_CALLS: prune_confirmed(ctx); *value = (int)ctx->pending.size(); break;
         case RTDD_OPT_DEFOCUS_LAST_PATH: *value = ctx->defocus_last_path; break;
@@ -691,7 +723,7 @@ int rtdd::solve_with(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8
         if (!ctx->healing) { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
         RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         *(volatile int *)ctx->confirm_host = 0;
-        ctx->solve_seq = 0;
+        ctx->solve_seq = 0; ctx->publish_seq = 0;
     }
     const int seq = ++ctx->solve_seq;
     const Options asked = ctx->opt;

@@ -250,6 +250,7 @@ int launch_pyrup_inject(rtdd_ctx *ctx, const float *src, size_t sp, int rows, in
     static const PyrupBatch one;
     const PyrupBatch &Z = pb ? *pb : one;
     int *sw = guard_seq != 0 ? ctx->sync_words : nullptr;
+    if (guard_seq != 0) note_publisher(ctx, guard_seq);
     const int seq = guard_seq;
     if (coarse_out && (drows < 2 * rows || dcols < 2 * cols)) return fail(ctx, RTDD_ERR_INVALID, "pyrUp: the fine level must be at least twice the coarse one");
     const bool doubling = drows == 2 * rows && dcols == 2 * cols && dcols % 4 == 0 && rows >= 2 && cols >= 2;

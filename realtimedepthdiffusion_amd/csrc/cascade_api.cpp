@@ -493,7 +493,7 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
     RTDD_HIP(ctx, hipStreamSynchronize(v->up));
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
-    ctx->persistent_used = true;
+    note_status_writer(ctx);
     const int rc = check_persistent_status(ctx);
     if (rc != RTDD_OK) return rc;
     for (unsigned long long f = v->waited; f < v->submitted; f++) {

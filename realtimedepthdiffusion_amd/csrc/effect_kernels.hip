@@ -383,13 +383,17 @@ constexpr int kLk2Rows = 2;                                         // rows per 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ orig, size_t op, const float *__restrict__ depth, size_t dp,
                                                   const u64 *__restrict__ Tpad, int tpitch, uint8_t *__restrict__ art, size_t ap,
-                                                  int rows, int cols, int kernelSize, int gx, int ntiles, int xcd_tiles) {
+                                                  int rows, int cols, int kernelSize, int gx, int ntiles, int xcd_tiles,
+                                                  int row0, int row1, int trow0, int trows, int *__restrict__ nonlocal_word) {
+    // Round 6, BANDED tables (launch_defocus): this launch writes output rows [row0, row1) and the table holds image rows
+    // [trow0, trow0 + trows) with its origin at row trow0 -- rectangle sums are differences, so any origin above the window serves.  The
+    // whole image in one launch: row0 = trow0 = 0, row1 = trows = rows.
     const int p = blockIdx.x;
     const int tile = xcd_tiles > 0 ? (p & 7) * xcd_tiles + (p >> 3) : p;
     if (tile >= ntiles) return;
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int x0 = (tile % gx) * 64, yw = (tile / gx) * (4 * kLk2Rows) + wv * kLk2Rows;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Tpad, 0, (int)((uint32_t)(rows + 1) * (uint32_t)tpitch * 8u), 0x00020000);
+    const int x0 = (tile % gx) * 64, yw = row0 + (tile / gx) * (4 * kLk2Rows) + wv * kLk2Rows;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Tpad, 0, (int)((uint32_t)(trows + 1) * (uint32_t)tpitch * 8u), 0x00020000);
     const uint32_t pitch8 = (uint32_t)tpitch * 8u;
     const bool whole = VEC && x0 + 64 <= cols;                      // wave-uniform: the output as dwords
     const int x = x0 + lane, xc = min(x, cols - 1), j = lane & 3;
@@ -405,8 +409,8 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
         const int h = half_window(kernelSize, d[i]);                // <= 2^21: y + h stays an int
         ya[i] = max(y - h, 0); yb[i] = min(y + h, rows);
         xa[i] = max(xc - h, 0); xb[i] = min(xc + h, cols);
-        // T(ya - 1, xa - 1) = T'[ya][xa + 3], ...: byte offsets row * pitch8 + 8 * col + 24
-        const uint32_t ra = (uint32_t)__umul24(ya[i], pitch8), rb = (uint32_t)__umul24(yb[i], pitch8);       // both factors < 2^24 and (rows + 1) * pitch8 < 2^32: launch_defocus refuses any larger table
+        // T(ya - 1, xa - 1) = T'[ya][xa + 3], ...: byte offsets row * pitch8 + 8 * col + 24 (rows counted from the table's origin row)
+        const uint32_t ra = (uint32_t)__umul24(ya[i] - trow0, pitch8), rb = (uint32_t)__umul24(yb[i] - trow0, pitch8);       // both factors < 2^24 and (rows + 1) * pitch8 < 2^32: launch_defocus refuses any larger table
         const uint32_t ca = 8u * (uint32_t)xa[i] + 24u, cb = 8u * (uint32_t)xb[i] + 24u;
         C[i][0] = tab_load(rsrc, ra + ca); C[i][1] = tab_load(rsrc, ra + cb); C[i][2] = tab_load(rsrc, rb + ca); C[i][3] = tab_load(rsrc, rb + cb);
         const int wd = xb[i] - xa[i], ht = yb[i] - ya[i];
@@ -432,11 +436,11 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
                 for (int xs = xa[i]; xs < xb[i]; xs += cw) {
                     const int xe = min(xs + cw, xb[i]);
                     const uint32_t cs = 8u * (uint32_t)xs + 24u, ce = 8u * (uint32_t)xe + 24u;
-                    const uint32_t r0 = (uint32_t)ya[i] * pitch8;
+                    const uint32_t r0 = (uint32_t)(ya[i] - trow0) * pitch8;
                     u64 D0 = tab_load(rsrc, r0 + ce) - tab_load(rsrc, r0 + cs);
                     for (int ys = ya[i]; ys < yb[i]; ys += rh) {
                         const int ye = min(ys + rh, yb[i]);
-                        const uint32_t r1 = (uint32_t)ye * pitch8;
+                        const uint32_t r1 = (uint32_t)(ye - trow0) * pitch8;
                         const u64 D1 = tab_load(rsrc, r1 + ce) - tab_load(rsrc, r1 + cs);
                         const u64 Xs = D1 - D0;
                         sb += (uint32_t)(Xs & kSatFieldMask); sg += (uint32_t)((Xs >> 21) & kSatFieldMask); sr += (uint32_t)(Xs >> 42);
@@ -452,13 +456,47 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
                 }
             }
         }
+        // (a banded table) a window that reaches beyond the slice's rows -- a depth above 255: no depth map -- is summed by its wave from
+        // the image, exactly (as k_defocus_tile does with windows beyond its region), and the host is told: this context's later calls
+        // build the one whole-image table again (rtdd_internal.hpp defocus_band_sticky)
+        {
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(cnt[i] != 0u && (ya[i] < trow0 || yb[i] > trow0 + trows));
+            if (__builtin_expect(todo != 0, 0)) {
+                const bool mine = (todo >> lane) & 1ull;
+                if (lane == 0 && nonlocal_word) __hip_atomic_fetch_or(nonlocal_word, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t sb = 0, sg = 0, sr = 0;
+                while (todo) {
+                    const int L = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int wya = __builtin_amdgcn_readlane(ya[i], L), wyb = __builtin_amdgcn_readlane(yb[i], L);
+                    const int wxa = __builtin_amdgcn_readlane(xa[i], L), wxb = __builtin_amdgcn_readlane(xb[i], L);
+                    uint32_t tb = 0, tg = 0, tr = 0;
+                    for (int r = wya; r < wyb; r++) {
+                        const uint8_t *row = orig + (size_t)r * op;
+                        for (int c = wxa + lane; c < wxb; c += 64) { tb += row[3 * (size_t)c]; tg += row[3 * (size_t)c + 1]; tr += row[3 * (size_t)c + 2]; }
+                    }
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) { tb += __shfl_xor(tb, m); tg += __shfl_xor(tg, m); tr += __shfl_xor(tr, m); }
+                    if (lane == L) { sb = tb; sg = tg; sr = tr; }
+                }
+                if (mine) {
+                    if (cnt[i] < 65536u && (sb | sg | sr) < (1u << 24)) {       // exact sums, exact integer quotients
+                        const float rc = __builtin_amdgcn_rcpf((float)cnt[i]);
+                        res = quot_u8(sb, cnt[i], rc) | (quot_u8(sg, cnt[i], rc) << 8) | (quot_u8(sr, cnt[i], rc) << 16);
+                    } else {                                                    // (as the strips above: the reference's own f32 sums round here)
+                        const float count = (float)cnt[i];
+                        res = store_u8((float)sb / count) | (store_u8((float)sg / count) << 8) | (store_u8((float)sr / count) << 16);
+                    }
+                }
+            }
+        }
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt[i] == 0u) != 0, 0)) {   // count == 0 (src/GPUDepthEffect.cu:62-66): the pixel itself
             if (cnt[i] == 0u) {
                 const uint8_t *o = orig + (size_t)yc * op + 3 * (size_t)xc;
                 res = o[0] | (o[1] << 8) | (o[2] << 16);
             }
         }
-        if (y < rows) {                                             // wave-uniform
+        if (y < row1) {                                             // wave-uniform (row1 <= rows: this launch's last output row + 1)
             uint8_t *arow = art + (size_t)y * ap;
             if (whole) {
                 const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)res, 0xF9, 0xF, 0xF, true);   // quad_perm:[1,2,3,3]
@@ -647,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void k_defocus_tile(const uint8_t *__restri
         if (__builtin_expect(todo != 0, 0)) {                       // windows beyond the region: the wave sums them from the image, one pixel at a time
             // (the host hears of it at its next synchronisation and sends this context's later calls to the table: rtdd_internal.hpp
             // defocus_table_sticky -- a window costs its area here, the table a constant)
-            if (lane == 0) __hip_atomic_store(nonlocal_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_fetch_or(nonlocal_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t sb = 0, sg = 0, sr = 0;
             while (todo) {
                 const int L = __builtin_ctzll(todo);
@@ -739,55 +777,84 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
 #undef RTDD_DT_LAUNCH
         RTDD_LAUNCH_CHECK(ctx, "k_defocus_tile");
         ctx->defocus_last_path = 2;
-        ctx->persistent_used = true;                 // (the next synchronising call reads the control words: check_persistent_status)
+        note_status_writer(ctx);                     // (kSyncNonLocal: the next synchronising call reads the control words, check_persistent_status)
         return RTDD_OK;
     }
     const int tp = (cols + 3) / 4 * 4;                                  // entries the build writes per row: 32-byte aligned groups of four
     // the table is padded -- one zero row above, four zero entries left of every row (k_defocus): T'[r + 1][c + 4] = T(r, c)
     const int tpitch = tp + 4;
+    // Round 6, BANDED tables.  A whole-image table is 8 bytes per pixel: 66 MB at 4K, 265 MB at 8K -- more than the 256 MiB Infinity
+    // Cache, so every corner of an 8K lookup was a gather from HBM (729 us smooth, 2.9 ms with a random depth per pixel).  Rectangle sums
+    // are differences, so a table with its origin at any row above the window serves: the image is cut into horizontal slices of output
+    // rows, each slice builds the table of ITS rows plus the tallest nominal window's reach (kernelSize / 2 rows above and below: a
+    // depth map is <= 255) -- into the same buffer, which therefore stays in the Infinity Cache -- and looks its pixels up in it.  A
+    // window that reaches further (a depth above 255) is summed from the image by its wave and reported (k_defocus); the context then
+    // goes back to one whole-image table (defocus_band_sticky).  Same integer sums, same quotients: bit-identical.
+    const int reach = kernelSize / 2;
+    const size_t slice_budget = (size_t)ctx->opt.defocus_slice_mb << 20;          // RTDD_OPT_DEFOCUS_SLICE_MB (default 64; 0: never band)
+    const size_t row_bytes = (size_t)tpitch * sizeof(u64);
+    int slice_rows = rows;                                              // output rows per slice
+    const bool want_bands = slice_budget > 0 && !ctx->defocus_band_sticky && ctx->opt.defocus_path != 1 &&
+                            ((size_t)rows + 1) * row_bytes > 2 * slice_budget;       // (a table that fits the cache twice over is left whole: 4K)
+    if (want_bands) {
+        const long fit = (long)(slice_budget / row_bytes) - 2L * reach - 1;
+        slice_rows = fit >= 64 ? (int)fit : 64;
+        slice_rows = slice_rows / 8 * 8;                                // whole lookup tiles (8 rows)
+        if (slice_rows >= rows) slice_rows = rows;
+    }
+    const int nslices = (rows + slice_rows - 1) / slice_rows;
+    const int trows_max = nslices == 1 ? rows : (slice_rows + 2 * reach < rows ? slice_rows + 2 * reach : rows);
     // band height: one workgroup per band builds the table, so enough bands to occupy the chip (270 / 135 / 135 workgroups of 8 / 16 / 16
     // waves at 1080p / 4K / 8K); a band costs 8 B per column three times over (colsum, its scan, the build's read)
     static const int rb_env = getenv("RTDD_DEFOCUS_BAND") ? atoi(getenv("RTDD_DEFOCUS_BAND")) : 0;
-    const int RB = rb_env >= 4 && rb_env <= 32 && rb_env % 4 == 0 ? rb_env : rows <= 1536 ? 4 : rows <= 3072 ? 16 : 32;
-    const int nbands = (rows + RB - 1) / RB;
-    const size_t table_entries = ((size_t)rows + 1) * tpitch;
+    const int RB = rb_env >= 4 && rb_env <= 32 && rb_env % 4 == 0 ? rb_env : trows_max <= 1536 ? 4 : trows_max <= 3072 ? 16 : 32;
+    const int nbands_max = (trows_max + RB - 1) / RB;
+    const size_t table_entries = ((size_t)trows_max + 1) * tpitch;
     // k_defocus addresses the padded table with 32-bit BYTE offsets (one 24-bit multiply per corner row) through a buffer resource whose
     // num_records is a 32-bit byte count: the table must stay below 4 GiB and both factors of that multiply below 2^24.  check_effect
     // only bounds rows^2 + cols^2 < 2^31, which admits rows x cols up to 2^30 -- an 8.6 GB table whose offsets would wrap and read zeros.
-    if (table_entries * sizeof(u64) >= (1ull << 32) || (size_t)tpitch * sizeof(u64) >= (1u << 24) || (size_t)rows + 1 >= (1u << 24))
+    if (table_entries * sizeof(u64) >= (1ull << 32) || (size_t)tpitch * sizeof(u64) >= (1u << 24) || (size_t)trows_max + 1 >= (1u << 24))
         return fail(ctx, RTDD_ERR_INVALID, "image too large for the defocus table (its 8 bytes per pixel must stay below 4 GiB: about 536 million pixels)");
-    const size_t need = ((table_entries + (size_t)nbands * tp) * sizeof(u64) + 256) / sizeof(uint32_t);   // padded table + band bases, in u32 words
+    const size_t need = ((table_entries + (size_t)nbands_max * tp) * sizeof(u64) + 256) / sizeof(uint32_t);   // padded table + band bases, in u32 words
     if (ctx->sat_elems < need) {
         if (ctx->sat) { RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream)); RTDD_HIP(ctx, hipFree(ctx->sat)); ctx->sat = nullptr; ctx->sat_elems = 0; }
         RTDD_HIP(ctx, hipMalloc((void **)&ctx->sat, need * sizeof(uint32_t)));
         ctx->sat_elems = need; ctx->sat_rows = ctx->sat_cols = 0;
     }
     u64 *Tpad = (u64 *)ctx->sat, *T = Tpad + tpitch + 4, *base = Tpad + table_entries;
-    if (ctx->sat_rows != rows || ctx->sat_cols != cols) {              // another geometry: the padding lies elsewhere -- zero the table once (the build never writes the padding)
+    if (ctx->sat_rows != trows_max || ctx->sat_cols != cols) {          // another geometry: the padding lies elsewhere -- zero the table once (the build never writes the padding)
         RTDD_HIP(ctx, hipMemsetAsync(Tpad, 0, table_entries * sizeof(u64), ctx->stream));
-        ctx->sat_rows = rows; ctx->sat_cols = cols;
+        ctx->sat_rows = trows_max; ctx->sat_cols = cols;
     }
     const bool vin = (uintptr_t)orig % 4 == 0 && op % 4 == 0, vout = vin && (uintptr_t)art % 4 == 0 && ap % 4 == 0;
-    const dim3 g1((tp / 4 + 255) / 256, nbands);
-    if (vin) hipLaunchKernelGGL(k_sat_colsum<true>, g1, dim3(256), 0, ctx->stream, orig, op, base, tp, rows, cols, RB);
-    else hipLaunchKernelGGL(k_sat_colsum<false>, g1, dim3(256), 0, ctx->stream, orig, op, base, tp, rows, cols, RB);
-    RTDD_LAUNCH_CHECK(ctx, "k_sat_colsum");
-    int scan_waves = (nbands + 3) / 4; if (scan_waves > 16) scan_waves = 16;
-    hipLaunchKernelGGL(k_sat_colbase, dim3((tp + 63) / 64), dim3(64 * scan_waves), 0, ctx->stream, base, tp, nbands);
-    RTDD_LAUNCH_CHECK(ctx, "k_sat_colbase");
-    int build_waves = (tp / 4 + 63) / 64; if (build_waves > 16) build_waves = 16;
-    if (vin) hipLaunchKernelGGL(k_sat_build<true>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, orig, op, base, T, tp, rows, cols, RB, tpitch);
-    else hipLaunchKernelGGL(k_sat_build<false>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, orig, op, base, T, tp, rows, cols, RB, tpitch);
-    RTDD_LAUNCH_CHECK(ctx, "k_sat_build");
-    {
-        const int gx2 = (cols + 63) / 64, gy2 = (rows + 4 * kLk2Rows - 1) / (4 * kLk2Rows), nt2 = gx2 * gy2;
+    for (int sl = 0; sl < nslices; sl++) {
+        const int row0 = sl * slice_rows, row1 = row0 + slice_rows < rows ? row0 + slice_rows : rows;
+        const int trow0 = nslices == 1 ? 0 : (row0 - reach > 0 ? row0 - reach : 0);
+        const int trow1 = nslices == 1 ? rows : (row1 + reach < rows ? row1 + reach : rows);
+        const int trows = trow1 - trow0, nbands = (trows + RB - 1) / RB;
+        const uint8_t *o_sl = orig + (size_t)trow0 * op;               // the slice's rows of the image: the table's origin is its first row
+        const dim3 g1((tp / 4 + 255) / 256, nbands);
+        if (vin) hipLaunchKernelGGL(k_sat_colsum<true>, g1, dim3(256), 0, ctx->stream, o_sl, op, base, tp, trows, cols, RB);
+        else hipLaunchKernelGGL(k_sat_colsum<false>, g1, dim3(256), 0, ctx->stream, o_sl, op, base, tp, trows, cols, RB);
+        RTDD_LAUNCH_CHECK(ctx, "k_sat_colsum");
+        int scan_waves = (nbands + 3) / 4; if (scan_waves > 16) scan_waves = 16;
+        hipLaunchKernelGGL(k_sat_colbase, dim3((tp + 63) / 64), dim3(64 * scan_waves), 0, ctx->stream, base, tp, nbands);
+        RTDD_LAUNCH_CHECK(ctx, "k_sat_colbase");
+        int build_waves = (tp / 4 + 63) / 64; if (build_waves > 16) build_waves = 16;
+        if (vin) hipLaunchKernelGGL(k_sat_build<true>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, o_sl, op, base, T, tp, trows, cols, RB, tpitch);
+        else hipLaunchKernelGGL(k_sat_build<false>, dim3(nbands), dim3(64 * build_waves), 0, ctx->stream, o_sl, op, base, T, tp, trows, cols, RB, tpitch);
+        RTDD_LAUNCH_CHECK(ctx, "k_sat_build");
+        const int gx2 = (cols + 63) / 64, gy2 = (row1 - row0 + 4 * kLk2Rows - 1) / (4 * kLk2Rows), nt2 = gx2 * gy2;
         const int xt2 = nt2 >= 64 ? (nt2 + 7) / 8 : 0;
         const dim3 g5(xt2 > 0 ? 8 * xt2 : nt2);
-        if (vout) hipLaunchKernelGGL(k_defocus<true>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2);
-        else hipLaunchKernelGGL(k_defocus<false>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2);
+        int *nlw = nslices > 1 ? ctx->sync_words + kSyncNonLocal : nullptr;
+        if (vout) hipLaunchKernelGGL(k_defocus<true>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2, row0, row1, trow0, trows, nlw);
+        else hipLaunchKernelGGL(k_defocus<false>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2, row0, row1, trow0, trows, nlw);
     }
+    if (nslices > 1) note_status_writer(ctx);                           // (kSyncNonLocal: a window beyond a slice -> the whole-image table from the next synchronisation on)
     RTDD_LAUNCH_CHECK(ctx, "k_defocus");
     ctx->defocus_last_path = 1;
+    ctx->defocus_last_slices = nslices;
     return RTDD_OK;
 }
 

@@ -30,6 +30,12 @@ constexpr int kSyncStatus = 0, kSyncWithhold = 1, kSyncLimit = 2, kSyncNonLocal 
               kSyncConfirmPtr = 6 /* two ints: the device address of the context's page-locked `confirmed sequence number` word */, kSyncFlags = 32, kSyncMaxTiles = 1024, kSyncFlagStride = 64;
 constexpr int kSyncWords = kSyncFlags + kSyncMaxTiles * kSyncFlagStride;              // size of sync_words in ints
 constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: legitimate waits are microseconds
+// Round 6: the FIRST thing a persistent workgroup does is announce itself (its flag := the launch's base value) and wait for its
+// neighbours' announcements -- while its tile loads are in flight -- with THIS bound: on a GPU shared with other work a launch whose
+// workgroups are not all resident is found out here, before any sweep, in a millisecond instead of 200 (profiles/r05_shared_gpu.txt: a
+// 200 ms stall per time-out in a 1 ms frame loop).  A resident launch's workgroups all start within tens of microseconds.  The
+// exchanges behind the first keep the long bound: once every workgroup has been seen running, a long wait is no scheduling accident.
+constexpr unsigned long long kArrivalPollLimit = 100000ull;        // 1 ms
 
 #ifdef __HIPCC__
 // The kernels that publish a solve's result into the caller's buffers call this first (every thread; `first` = one thread of the
@@ -56,7 +62,7 @@ __device__ __forceinline__ bool solve_is_dead(int *sync_words, int seq, bool fir
 // Protocol (cdna_hip_programming.md Guideline 16, R1): write-through (sc1) payload stores; EVERY storing wave drains vmcnt;
 // workgroup barrier; ONE lane stores the flag (agent-scope atomic); 8 lanes poll the neighbours' flags relaxed with s_sleep;
 // ONE agent acquire; barrier; plain vector loads.
-template <bool ACQUIRE = true>
+template <bool ACQUIRE = true, bool ARRIVAL = false>
 __device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, int tid, int tile_id, int bx, int by, int gx, int gy, int value, int tile_base = 0) {
     int *flags = sync_words + kSyncFlags + tile_base * kSyncFlagStride;      // (tile_base: a batched launch gives every image's tiles flags of their own)
     if (tid == 0 && __hip_atomic_load(&sync_words[kSyncWithhold], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tile_id + 1)
@@ -79,6 +85,7 @@ __device__ __forceinline__ bool exchange_wait(int *sync_words, int *dead_lds, in
                         t0 = now;
                         const int l = __hip_atomic_load(&sync_words[kSyncLimit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         limit = l > 0 ? (unsigned long long)l : kDefaultPollLimit;
+                        if (ARRIVAL && limit > kArrivalPollLimit) limit = kArrivalPollLimit;
                     }
                     const bool failed = __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                     if (failed || now - t0 > limit) {

@@ -74,8 +74,12 @@ __global__ __launch_bounds__(NT, 4) void k_rbgs_blocked(float *X, float *Y, cons
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
     if (tid < NT / 64) published[tid] = 0;
     if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
-    __syncthreads();
-    if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
+    if (PERSIST) {
+        // arrival, as in k_sweep_blocked: announce, see the 8 neighbours announce within a millisecond, or leave before any sweep
+        if (exchange_wait<false, true>(sync_words, &dead_s, tid, by * gx + bx, bx, by, gx, gy, flag_base)) return;
+    } else {
+        __syncthreads();
+    }
 
     const int lx = tid % LX, tr = tid / LX;
     const int ntr = (int)blockDim.x / LX, eh = ntr * G;
@@ -350,7 +354,7 @@ int launch_rbgs_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int 
         if (persistent) {
             m = n - done;
             { const int rc_ = prepare_persistent_launch(ctx, (m + block_sweeps - 1) / block_sweeps, &flag_base); if (rc_ != RTDD_OK) return rc_; }   // this launch's flag values, debug words
-            ctx->persistent_used = true;
+            note_status_writer(ctx);
         }
         int out = -1;
         for (int i = 0; i < 4; i++) if (i != *plane && i != keep) { out = i; break; }      // `keep`: a plane the caller still needs (-1: none)

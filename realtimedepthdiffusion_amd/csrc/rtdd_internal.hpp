@@ -101,6 +101,8 @@ struct Options {
     int timeout_heal = 1;            // RTDD_OPT_TIMEOUT_HEAL: 1 a timed-out persistent launch is healed (calls logged, run again); 0 it is reported
     int annotation_lds = 1;          // RTDD_OPT_ANNOTATION_LDS: the annotation pyramid's chain of levels in LDS (pyramids of up to 6 levels); 0: through global memory
     int live_zero_copy = 1;          // RTDD_OPT_LIVE_ZERO_COPY: a live frame's u8 map is stored by the copy-back kernel straight into the host's page-locked buffer (0 never, 1 when no other frame is in flight, 2 always)
+    int defocus_slice_mb = 64;       // RTDD_OPT_DEFOCUS_SLICE_MB: a summed-area table of more than twice this is built and looked up in slices of at most this size (0: never)
+    int sync_spin_us = 0;            // RTDD_OPT_SYNC_SPIN_US: rtdd_ctx_synchronize polls the stream (hipStreamQuery) for up to this long before it blocks
     int rearm_after = 64;            // RTDD_OPT_PERSISTENT_REARM_AFTER: solves without persistence after the first heal, doubling with every further one
 };
 
@@ -159,6 +161,8 @@ struct rtdd_ctx {
     float *residual_dev = nullptr;  // extension: residual reduction target
     int *sync_words = nullptr;      // control words of the persistent kernels (persist_sync.hpp); allocated with the context
     int defocus_last_path = 0;           // RTDD_OPT_DEFOCUS_LAST_PATH: what the most recent rtdd_simulate_defocus launched (1 table, 2 tile kernel)
+    int defocus_last_slices = 0;         // ... and, on the table path, how many horizontal slices it built a table for (1: one whole-image table)
+    bool defocus_band_sticky = false;    // a banded-table defocus met windows beyond a slice (depths above 255): one whole-image table from then on
     bool defocus_table_sticky = false;   // a tile-kernel defocus met out-of-range depths (seen at a synchronisation): automatic choice = the table from then on
     int flag_epoch = 0;             // the per-tile flags of the persistent kernels only ever grow: base value of the next persistent launch (api.cpp)
     int sync_header[2] = {0, 0};    // what sync_words[kSyncWithhold], [kSyncLimit] currently hold on the device
@@ -179,6 +183,12 @@ struct rtdd_ctx {
     int *confirm_host = nullptr;    // page-locked: sequence number of the latest solve whose copy-back kernel published its result (persist_sync.hpp)
     unsigned long long op_counter = 0;
     bool persistent_used = false;   // a launch that can set the status word (sync_words[kSyncStatus]) happened since the last status check
+    // The copy-back kernels report in page-locked memory the sequence number of a solve they published WITH THE STATUS WORD CLEAR
+    // (confirm_host).  If the newest such kernel launched (publish_seq) has reported, and nothing that can set a control word has been
+    // launched behind it (status_writer_behind), a synchronised stream proves the words clear without reading them from the device: the
+    // drop-in shim synchronises behind every pyramid level's solve, and the 32-byte blocking hipMemcpy was most of what that cost it.
+    int publish_seq = 0;
+    bool status_writer_behind = false;
     signed char persist_fit[17][2];  // per (tile id, contraction): does one workgroup of the persistent kernel fit a CU of THIS device (-1 = not asked yet)
     rtdd::Bounce bounce;            // host <-> device 2-D copies with an unaligned host pitch, on ctx->stream (copy_h2d / copy_d2h, cascade_api.cpp)
     uint32_t *sat = nullptr;        // defocus summed-area table scratch
@@ -208,6 +218,10 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 #endif
 
 int fail(rtdd_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
+// a launch that can set one of the control words (sync_words) has been queued: the next synchronising call must look at them
+inline void note_status_writer(rtdd_ctx *ctx) { ctx->persistent_used = true; ctx->status_writer_behind = true; }
+// a guarded copy-back kernel (k_finish, k_pyrup_inject) for solve `seq` has been queued: it reports `seq` if it finds the words clear
+inline void note_publisher(rtdd_ctx *ctx, int seq) { ctx->persistent_used = true; ctx->publish_seq = seq; ctx->status_writer_behind = false; }
 
 #define RTDD_HIP(ctx, call)                                                        \
     do {                                                                           \

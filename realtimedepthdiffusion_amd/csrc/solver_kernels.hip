@@ -472,7 +472,7 @@ int launch_finish(rtdd_ctx *ctx, const Level &L, size_t ip, int src_plane, float
     else
         hipLaunchKernelGGL(k_finish, grid64x4(rows, cols, B.n), dim3(256), 0, ctx->stream, L.P(src_plane, ip), (int)ip, depth, depthPitch,
                            rows, cols, t.u8, t.u8_pitch, ctx->sync_words, seq, zP, B.depth, B.u8, t.u8b, t.u8b_pitch);
-    ctx->persistent_used = true;                  // (the guard may have recorded a failed solve: the next synchronising call looks)
+    note_publisher(ctx, seq);                     // (the guard may have recorded a failed solve: the next synchronising call looks)
     RTDD_LAUNCH_CHECK(ctx, "k_finish");
     return RTDD_OK;
 }

@@ -136,10 +136,27 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     for (int i = tid; i < 257; i += (int)blockDim.x) lut[i] = lut_g[i];
     if (tid <= NT / 64) published[tid] = 0;
     if (tid == 0) { dead_s = PERSIST && __hip_atomic_load(&sync_words[kSyncStatus], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
-    __syncthreads();
-    if (PERSIST && dead_s) return;             // an earlier persistent launch of this context timed out: drain at once
+    const int ntiles = gx * gy, tile_base = (int)blockIdx.z * ntiles, tile_id = by * gx + bx;
+    if (PERSIST) {
+        // Arrival (persist_sync.hpp kArrivalPollLimit): the tile's flag := the launch's base value, then the 8 neighbours' -- while the
+        // tile's loads are in flight.  A workgroup that is not resident never announces itself, its neighbours give up within a
+        // millisecond, the status word is set and every workgroup leaves here, before any sweep (also at once when an earlier
+        // persistent launch of this context has timed out).  Its barrier is also the one the table's staging needs.
+        if (exchange_wait<false, true>(sync_words, &dead_s, tid, tile_id, bx, by, gx, gy, flag_base, tile_base)) return;
+    } else {
+        __syncthreads();
+    }
 
+    RTDD_STAMP_LOADED(4);
+    // wave-uniform (scalar: the tile's coordinates): the whole extended tile, every pixel's right and lower neighbour and the row above the
+    // tile are inside the image -- the setup then needs none of its border selects (sweep_tile_setup.inc)
+    const int tx0 = bx * TW - hx, ty0 = by * TH - hy;
+    const bool tile_inside = tx0 >= 0 && tx0 + EW < cols && ty0 >= 1 && ty0 + eh < rows;
+#ifdef RTDD_SETUP_R5
+#include "sweep_tile_setup_r5.inc"    // (A/B builds: round 5's setup)
+#else
 #include "sweep_tile_setup.inc"       // vxr / vpr / mr / mup -> a, b, weights, divisors, reciprocals
+#endif
 
     RTDD_STAMP(1);
     __builtin_amdgcn_s_setprio(0);
@@ -164,7 +181,6 @@ __global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) vo
     // waves top-down, odd waves bottom-up, every edge row published as soon as it is computed and fetched a step ahead).
 #include "sweep_tile_sweeps.inc"      // publish / await / sweep lambdas
     // (the divide variant is chosen per wave; the neighbour handshake above does not care which one a wave runs)
-    const int ntiles = gx * gy, tile_base = (int)blockIdx.z * ntiles, tile_id = by * gx + bx;
     int s = 0, blk = 0;
     bool odd = false;
     RTDD_XT_BEGIN;
@@ -763,7 +779,7 @@ static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, 
             block_sweeps = T;
             m = n - done;
             { const int rc_ = prepare_persistent_launch(ctx, (m + T - 1) / T, &flag_base); if (rc_ != RTDD_OK) return rc_; }   // this launch's flag values, debug words
-            ctx->persistent_used = true;
+            note_status_writer(ctx);
         }
         // XCD-aware tile placement (RTDD_XCD_REMAP=0 turns it off): +1.5-4 % persistent (strips traded inside one L2), +8 % at 4K
         // launch-per-block (a tile's halo is its neighbours' centre: the same XCD reads both)
@@ -786,7 +802,7 @@ static int launch_sweeps_blocked_impl(rtdd_ctx *ctx, const Level &L, size_t ip, 
 #undef RTDD_TILE_CASE
         // every blocked launch can set the status word (the bounded wait of a wave for its neighbour waves, status 2, exists in
         // the launch-per-block instantiation too): the next synchronising call must read it whatever the mode
-        ctx->persistent_used = true;
+        note_status_writer(ctx);
         if (ctx->opt.debug_force_status) {                          // testing aid (include/rtdd.h): as if a wave of this launch had given up
             RTDD_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->sync_words + kSyncStatus), ctx->opt.debug_force_status == 3 ? 1 : ctx->opt.debug_force_status, 1, ctx->stream));
             ctx->opt.debug_force_status = 0;

@@ -5,19 +5,22 @@
 #pragma once
 
 #ifdef RTDD_STAMPS
-__device__ unsigned long long g_stamps[4096][4];
+__device__ unsigned long long g_stamps[4096][5];
 // k = 0: earliest wave (atomicMin would need init; wave 0 starts first in practice); k >= 1: LATEST wave of the workgroup
 // (atomicMax) -- without a barrier the oldest wave of each SIMD runs ahead, so stamping only wave 0 under-reports.
 #define RTDD_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) { \
         if ((k) == 0) { if (threadIdx.x == 0) g_stamps[blockIdx.y * gridDim.x + blockIdx.x][0] = __builtin_amdgcn_s_memrealtime(); } \
         else atomicMax(&g_stamps[blockIdx.y * gridDim.x + blockIdx.x][k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } while (0)
 #define RTDD_STAMP_LAST(k) do { __builtin_amdgcn_s_waitcnt(0); RTDD_STAMP(k); } while (0)
+// (round 6) the tile's loads have LANDED: a wait the product build does not have at this point, so that the stamp splits `load + setup`
+#define RTDD_STAMP_LOADED(k) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RTDD_STAMP(k); } while (0)
 __device__ unsigned long long g_xphase[4096][6];
 #define RTDD_XT(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); g_xphase[blockIdx.y * gridDim.x + blockIdx.x][k] += t_ - xt_; xt_ = t_; } } while (0)
 #define RTDD_XT_BEGIN unsigned long long xt_ = __builtin_amdgcn_s_memrealtime()
 #else
 #define RTDD_STAMP(k) do {} while (0)
 #define RTDD_STAMP_LAST(k) do {} while (0)
+#define RTDD_STAMP_LOADED(k) do {} while (0)
 #define RTDD_XT(k) do {} while (0)
 #define RTDD_XT_BEGIN do {} while (0)
 #endif

@@ -9,6 +9,7 @@ namespace rtdd {
 int fail(rtdd_ctx *, int s, const char *, hipError_t) { return s; }
 int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
     if (!ctx->sync_words) { (void)hipMalloc((void **)&ctx->sync_words, kSyncWords * sizeof(int)); (void)hipMemset(ctx->sync_words, 0, kSyncWords * sizeof(int)); }
+    if (!ctx->flag_epoch) ctx->flag_epoch = 1;
     *flag_base = ctx->flag_epoch; ctx->flag_epoch += nblocks + 1;
     return 0;
 }

@@ -69,3 +69,59 @@ def test_desaturation_and_haze_4k(ctx, oracle):
             diff = np.abs(got.astype(np.int16) - ref.astype(np.int16))
             assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4, f"haze against libm exp: max {diff.max()}, {(diff != 0).mean():.2e} of values differ"
     ctx.set_option(rt.OPT_FP_CONTRACT, 1)
+
+
+def test_defocus_banded_table_equals_the_whole_table(oracle):
+    """Round 6: beyond ~4K the summed-area table is built and looked up slice by slice (output rows + the tallest nominal window's reach,
+    each slice's table with an origin of its own) so that it stays in the Infinity Cache.  Forced here at 1440p with a 2 MB slice budget
+    (23 slices of 64 rows): a depth MAP (0..255) gives the whole-table result and the independent restatement's, bit for bit; depths
+    above 255 -- windows that reach beyond a slice -- are still answered exactly (summed from the image by their wave), and send the
+    context's later calls back to one whole-image table."""
+    rows, cols = 1440, 2560
+    orig, depth = _inputs(rows, cols, 23)
+    in_range = np.clip(depth, 0.0, 255.0)
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        o = up(orig)
+
+        def run(d, slice_mb):
+            c.set_option(rt.OPT_DEFOCUS_SLICE_MB, slice_mb)
+            art = up(np.zeros_like(orig))
+            c.GPUSimulateDefocus(o, up(d), art, rows, cols)
+            c.synchronize()
+            assert c.get_option(rt.OPT_DEFOCUS_LAST_PATH) == 1
+            return down(art), c.get_option(rt.OPT_DEFOCUS_LAST_SLICES)
+        assert c.get_option(rt.OPT_DEFOCUS_SLICE_MB) == 64
+        whole, n = run(in_range, 0)
+        assert n == 1
+        assert np.array_equal(whole, defocus_by_summed_area_table(orig, in_range))
+        banded, n = run(in_range, 2)
+        assert n == 23, n
+        assert np.array_equal(banded, whole), f"{int((banded != whole).sum())} values differ between the banded and the whole-image table"
+        banded, n = run(in_range, 2)                                 # a depth map never trips the fall-back
+        assert n == 23
+        # depths that are no depths (300: windows 1.18 x the nominal reach; negative: empty windows)
+        want = defocus_by_summed_area_table(orig, depth)
+        whole, n = run(depth, 0)
+        assert np.array_equal(whole, want)
+        banded, n = run(depth, 2)
+        assert n == 23 and np.array_equal(banded, want), f"{int((banded != want).sum())} values differ with out-of-range depths"
+        again, n = run(depth, 2)                                     # ... and the synchronisation behind that call has switched the banding off
+        assert n == 1 and np.array_equal(again, want)
+        c.set_option(rt.OPT_DEFOCUS_PATH, 0)                         # said again: the automatic choice forgets what earlier depths made it choose
+        again, n = run(in_range, 2)
+        assert n == 23 and np.array_equal(again, defocus_by_summed_area_table(orig, in_range))
+        ys = np.array([0, 63, 64, 65, 700, 1439]); xs = np.array([0, 5, 1280, 2559, 31, 2000])
+        assert np.array_equal(again[ys, xs], oracle.defocus_at(orig, in_range, ys, xs))
+
+
+def test_defocus_8k_is_banded_by_default():
+    """The 8K table (265 MB as one) is built in slices of <= 64 MB by default; 4K (66 MB) is left whole."""
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        for rows, cols, slices in ((2160, 3840, 1), (4320, 7680, 5)):
+            orig = np.zeros((rows, cols, 3), np.uint8); depth = np.full((rows, cols), 128.0, np.float32)
+            art = up(np.zeros_like(orig))
+            c.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+            c.synchronize()
+            assert c.get_option(rt.OPT_DEFOCUS_LAST_SLICES) == slices, (rows, c.get_option(rt.OPT_DEFOCUS_LAST_SLICES))

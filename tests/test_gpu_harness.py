@@ -123,6 +123,23 @@ def test_harness_live_frames_are_pipelined_and_each_is_the_oracles(tmp_path):
     assert np.array_equal(_read_pnm(tmp_path / "DepthMap.pgm"), c.depth_u8)
 
 
+@pytest.mark.parametrize("effect", ["defocus", "haze"])
+def test_harness_live_frames_with_a_sticky_effect(tmp_path, effect):
+    """--live 3 --effect X: the reference's frame with a sticky effect (src/main.cpp:190-230 beside :232-295) through
+    rtdd_live_submit_ex, pipelined: the written artistic image is the oracle's effect on the oracle's third warm-started estimate."""
+    g = load(NAMES[0])
+    _write_pnm(tmp_path / "img.ppm", g["bgr"][..., ::-1])
+    _write_pnm(tmp_path / "ann.pgm", g["annotation"])
+    out = subprocess.check_output([BIN, "-i", str(tmp_path / "img.ppm"), "-a", str(tmp_path / "ann.pgm"), "-o", str(tmp_path) + "/", "--live", "3", "--iters", "300",
+                                   "--effect", effect], text=True)
+    assert "Live:" in out and "two frames in flight" in out, out
+    import oracle
+    third = _oracle_cascade(g, estimates=3, iters=300)
+    assert np.array_equal(_read_pnm(tmp_path / "DepthMap.pgm"), third.depth_u8)
+    want = oracle.defocus(g["bgr"], third.depth[0], threads=4) if effect == "defocus" else oracle.haze(g["bgr"], third.depth[0], 1)
+    assert np.array_equal(_read_pnm(tmp_path / "ArtisticEffect.ppm"), want[..., ::-1])
+
+
 def test_harness_painting_into_a_live_view(tmp_path):
     """--live 5 --paint-at 2:... --paint-at 4:...: strokes in front of frames 2 and 4 (main.cpp:46-62: the mouse callback paints the
     device images and downloads them into the host's, the next frame uploads them, :236-237).  Every frame == the oracle cascade with
