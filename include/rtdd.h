@@ -123,17 +123,19 @@ enum rtdd_option {
                                        page-locked (rtdd_host_alloc, hipHostMalloc, hipHostRegister) -- no staging slot, no download.  1 (default): when
                                        no other frame is in flight (one frame at a time; in a pipelined loop rtdd_live_wait downloads the staged map
                                        while the next frame computes, which is cheaper still); 2: always; 0: never */
-    RTDD_OPT_SYNC_SPIN_US = 22,     /* rtdd_ctx_synchronize polls the stream from user space (hipStreamQuery) for up to this many microseconds before it blocks:
-                                       a blocking wait parks the host thread on an interrupt and waking it costs 15-25 us -- per pyramid level for a
-                                       host that synchronises behind every solve, as the reference does (src/GPUSolver.cu:314).  0 (default for a
-                                       context of the C ABI): block at once.  The drop-in shim's process-global context sets 5000 */
+    RTDD_OPT_DEFOCUS_STRIPS = 22,   /* the table path of rtdd_simulate_defocus, tile order of the lookup: 0 (default) automatic -- each XCD takes a COLUMN strip of the
+                                       image where the table rows between a window's bottom and top edge, over the whole image width, outgrow an XCD's
+                                       L2 (from ~4K on: 8K 727 -> 620 us on a smooth depth map, 2.9 -> 1.3 ms with a random depth per pixel), row bands
+                                       otherwise; 1 row bands always; 2 column strips always.  Same bits */
     RTDD_OPT_DEFOCUS_LAST_SLICES = 23, /* read only: the horizontal slices the most recent table-path rtdd_simulate_defocus built a table for (1: one
-                                       whole-image table; beyond ~4K the table is built and looked up slice by slice so that it stays in the Infinity Cache) */
+                                       whole-image table: the default) */
     RTDD_OPT_DEFOCUS_SLICE_MB = 24, /* the table path of rtdd_simulate_defocus: a summed-area table (8 bytes per pixel) of more than twice this many MB is
                                        built and looked up slice by slice -- output rows + the tallest nominal window's reach above and below, each slice's
-                                       table at most this large, all in one buffer that stays in the 256 MiB Infinity Cache (8K: 265 MB as one table).
-                                       Default 64; 0: always one whole-image table.  Same bits either way; depths above 255 (windows beyond a slice)
-                                       are answered exactly and send the context's later calls back to the whole-image table */
+                                       table at most this large and with an origin of its own, all in one buffer.  Default 0: always one whole-image
+                                       table (slices measured SLOWER at 8K -- 762 against 725 us: what the 265 MB table loses is L2 reuse, which
+                                       RTDD_OPT_DEFOCUS_STRIPS restores, not the Infinity Cache); they are what lets an image beyond 2^29 pixels, whose
+                                       whole table would pass 4 GiB, be processed at all.  Same bits either way; depths above 255 (windows beyond a
+                                       slice) are answered exactly and send the context's later calls back to the whole-image table */
     RTDD_OPT_ANNOTATION_LDS = 21,   /* 1 (default): an estimate's annotation pyramid walks its levels in LDS (one launch, one memory round trip; pyramids of
                                        up to six levels); 0: the same launch with the levels read back from global memory (a developer's A/B knob) */
     RTDD_OPT_TILE = 5               /* blocked kernel extended tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128,
@@ -158,7 +160,7 @@ int rtdd_version(void);                                  /* major * 100 + minor.
                                                           * caller compiled against a 1xx header must be rebuilt (#define RTDD_VERSION below).  210 adds
                                                           * rtdd_pyramid_annotation_changed, RTDD_OPT_TIMEOUT_HEALS and the self-healing time-out; 220: RTDD_OPT_TIMEOUT_HEAL,
                                                           * persistence re-armed after a time-out, rtdd_estimate_depth_batch, RTDD_OPT_LIVE_ZERO_COPY;
-                                                          * 230: rtdd_pyramid_level_info, rtdd_live_submit_ex */
+                                                          * 230: rtdd_pyramid_level_info, rtdd_live_submit_ex, RTDD_OPT_DEFOCUS_STRIPS / _SLICE_MB / _LAST_SLICES */
 #define RTDD_VERSION 230
 
 /* ---- solver (include/GPUSolver.h:6-10) ------------------------------------------------------ */

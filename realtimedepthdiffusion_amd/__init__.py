@@ -34,7 +34,7 @@ OPT_DEFOCUS_LAST_PATH = 15                 # read only: 1 the global table, 2 th
 OPT_TIMEOUT_HEAL, OPT_PERSISTENT_REARM_AFTER, OPT_PERSISTENT_SUSPENDED, OPT_PENDING_CALLS = 16, 17, 18, 19
 OPT_LIVE_ZERO_COPY = 20
 OPT_ANNOTATION_LDS = 21
-OPT_SYNC_SPIN_US = 22
+OPT_DEFOCUS_STRIPS = 22
 OPT_DEFOCUS_LAST_SLICES = 23              # read only
 OPT_DEFOCUS_SLICE_MB = 24
 RTDD_ERR_TIMEOUT = 6

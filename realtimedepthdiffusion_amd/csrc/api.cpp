@@ -1,7 +1,6 @@
 // api.cpp -- the extern "C" surface of librtdd.so (include/rtdd.h): context management, argument
 // validation, the per-level solve driver (GPUMatrixFreeSolver, /root/reference/src/GPUSolver.cu:274-316)
 // and thin forwards to the kernel launchers.  Host code only; kernels live in the *.hip files.
-#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -46,7 +45,8 @@ int prepare_persistent_launch(rtdd_ctx *ctx, int nblocks, int *flag_base) {
         RTDD_HIP(ctx, hipMemsetAsync(ctx->sync_words + kSyncFlags, 0, (size_t)kSyncMaxTiles * kSyncFlagStride * sizeof(int), ctx->stream));
         ctx->flag_epoch = 0;
     }
-    if (ctx->flag_epoch == 0) ctx->flag_epoch = 1;     // (a launch's workgroups announce themselves with its base value: never the zero the flags start from)
+    // (a launch's workgroups announce themselves with its base value: never the zero the flags start from)
+    if (ctx->flag_epoch == 0) ctx->flag_epoch = 1;
     *flag_base = ctx->flag_epoch;
     ctx->flag_epoch += nblocks + 1;
     const int limit = ctx->opt.debug_poll_limit_us > 0 ? ctx->opt.debug_poll_limit_us * 100 : 0;        // 10 ns ticks
@@ -82,7 +82,8 @@ static int replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
     } else if (op.kind == PendingOp::kDefocus) {
         rc = launch_defocus(ctx, op.original, op.originalPitch, op.depth, op.depthPitch, op.artistic, op.artisticPitch, op.rows, op.cols);
     } else if (op.kind == PendingOp::kDesaturate) {
-        rc = launch_desaturate(ctx, op.original, op.originalPitch, op.gray, op.grayPitch, op.depth, op.depthPitch, op.artistic, op.artisticPitch, op.rows, op.cols);
+        rc = launch_desaturate(ctx, op.original, op.originalPitch, op.gray, op.grayPitch, op.depth, op.depthPitch, op.artistic,
+            op.artisticPitch, op.rows, op.cols);
     } else {
         rc = launch_haze(ctx, op.original, op.originalPitch, op.depth, op.depthPitch, op.artistic, op.artisticPitch, op.rows, op.cols);
     }
@@ -92,7 +93,8 @@ static int replay(rtdd_ctx *ctx, const PendingOp &op, int failed_seq) {
 
 // A depth effect queued behind solves that no synchronising call has confirmed yet is logged with them: should one of those solves turn
 // out to have timed out, the effect ran on its INPUT and is run again behind the replayed solve.  (Nothing unconfirmed: nothing to log.)
-static void log_effect(rtdd_ctx *ctx, PendingOp::Kind kind, const uint8_t *original, size_t originalPitch, const uint8_t *gray, size_t grayPitch,
+static void log_effect(rtdd_ctx *ctx, PendingOp::Kind kind, const uint8_t *original, size_t originalPitch, const uint8_t *gray,
+    size_t grayPitch,
                        const float *depth, size_t depthPitch, uint8_t *artistic, size_t artisticPitch, int rows, int cols) {
     if (ctx->healing || ctx->pending.empty()) return;
     prune_confirmed(ctx);
@@ -137,12 +139,16 @@ static bool op_holds(const PendingOp &op, int seq) {
     return false;
 }
 
-static const char *kTimeoutText = "persistent sweep kernel: a workgroup timed out waiting for a neighbouring tile (its workgroups were not all "
+static const char *kTimeoutText =
+    "persistent sweep kernel: a workgroup timed out waiting for a neighbouring tile (its workgroups were not all "
                                   "co-resident: is the GPU shared?)";
 
 // The stream has just been synchronised by the caller.  A blocked-sweep launch since the last check may have given up (persist_sync.hpp).
 int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
-    if (!ctx->persistent_used || !ctx->sync_words) { if (!ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } return RTDD_OK; }
+    if (!ctx->persistent_used || !ctx->sync_words) {
+        if (!ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; }
+        return RTDD_OK;
+    }
     // The newest guarded copy-back kernel has reported its solve published with the status word clear, and nothing that could set a
     // control word was queued behind it: the words are clear (they are sticky, and that kernel ran behind every launch that could have
     // set them) -- no need to read them back.
@@ -156,7 +162,8 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
     RTDD_HIP(ctx, hipMemcpy(words, ctx->sync_words, sizeof(words), hipMemcpyDeviceToHost));
     ctx->persistent_used = false;
     const int status = words[kSyncStatus], failed_seq = words[kSyncFailedSeq];
-    if (words[kSyncNonLocal] != 0) {               // a defocus kernel summed windows by hand: not a depth map -- bit 0: the tile kernel, the table path
+    // a defocus kernel summed windows by hand: not a depth map -- bit 0: the tile kernel, the table path
+    if (words[kSyncNonLocal] != 0) {
                                                    // from now on; bit 1: a banded table, one whole-image table from now on
         if (words[kSyncNonLocal] & 1) ctx->defocus_table_sticky = true;
         if (words[kSyncNonLocal] & 2) ctx->defocus_band_sticky = true;
@@ -167,7 +174,8 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
     RTDD_HIP(ctx, hipMemset(ctx->sync_words + kSyncFailedSeq, 0, sizeof(int)));
     if (status != 1) {
         ctx->pending.clear(); ctx->pending_overflow = false;
-        return fail(ctx, RTDD_ERR_TIMEOUT, "blocked sweep kernel: a wave timed out waiting for a neighbouring wave of its own workgroup (internal error); "
+        return fail(ctx, RTDD_ERR_TIMEOUT,
+            "blocked sweep kernel: a wave timed out waiting for a neighbouring wave of its own workgroup (internal error); "
                                            "the results since the last synchronisation are invalid");
     }
     // Persistence off, and suspended: rearm_after solves after the first heal, twice as many after every further one, for good after
@@ -177,12 +185,16 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
         ctx->opt.persistent = 0;
         ctx->heals++;
         if (ctx->heals > kMaxRearms || ctx->opt.rearm_after <= 0) ctx->persist_suspend = -1;
-        else { const long long n = (long long)ctx->opt.rearm_after << (ctx->heals - 1); ctx->persist_suspend = n > (1 << 30) ? (1 << 30) : (int)n; }
+        else {
+            const long long n = (long long)ctx->opt.rearm_after << (ctx->heals - 1);
+            ctx->persist_suspend = n > (1 << 30) ? (1 << 30) : (int)n;
+        }
     }
     if (ctx->healing || ctx->pending_overflow || !ctx->opt.timeout_heal) {
         std::string msg = kTimeoutText;
         msg += ctx->healing ? "; it happened again while the calls were being run again without persistence"
-             : !ctx->opt.timeout_heal ? "; RTDD_OPT_TIMEOUT_HEAL is 0, so nothing was run again" : "; too many calls were queued without a synchronisation to run them again";
+             : !ctx->opt.timeout_heal ? "; RTDD_OPT_TIMEOUT_HEAL is 0, so nothing was run again"
+                 : "; too many calls were queued without a synchronisation to run them again";
         msg += "; the results since the last synchronisation are invalid";
         ctx->pending.clear(); ctx->pending_overflow = false;
         return fail(ctx, RTDD_ERR_TIMEOUT, msg.c_str());
@@ -190,15 +202,19 @@ int check_persistent_status(rtdd_ctx *ctx, bool in_solve) {
     // heal: the logged calls again from the first failed one
     if (!ctx->heal_warned) {
         ctx->heal_warned = true;
-        std::fprintf(stderr, "rtdd: %s; running the affected calls again one launch per block of sweeps -- persistent launches are suspended for this context's next %d solves "
-                             "(twice as long after every further time-out, for good after %d)\n", kTimeoutText, ctx->persist_suspend, kMaxRearms);
+        std::fprintf(stderr,
+                     "rtdd: %s; running the affected calls again one launch per block of sweeps -- persistent launches are suspended "
+                     "for this context's next %d solves (twice as long after every further time-out, for good after %d)\n",
+                     kTimeoutText, ctx->persist_suspend, kMaxRearms);
     }
     std::vector<PendingOp> ops;
     ops.swap(ctx->pending);
     size_t first = ops.size();                      // failed_seq == 0: every logged call had published its result before the word was set
     if (failed_seq != 0) {
         for (size_t i = 0; i < ops.size(); i++) if (op_holds(ops[i], failed_seq)) { first = i; break; }
-        if (first == ops.size()) return fail(ctx, RTDD_ERR_TIMEOUT, "persistent sweep kernel timed out and the failed call is not among the logged ones; the results since the last synchronisation are invalid");
+        if (first == ops.size()) return fail(ctx, RTDD_ERR_TIMEOUT,
+            "persistent sweep kernel timed out and the failed call is not among the logged ones; the results since the last "
+            "synchronisation are invalid");
     }
     ctx->healing = true;
     int rc = RTDD_OK;
@@ -319,47 +335,47 @@ int rtdd_ctx_set_stream(rtdd_ctx *ctx, rtdd_stream stream) {
 int rtdd_ctx_synchronize(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
     DeviceGuard g(ctx->device);
-    // RTDD_OPT_SYNC_SPIN_US: a blocking wait of more than a few tens of microseconds parks the host thread on an interrupt, and waking
-    // it takes 15-25 us (scripts/sync_cost.py: +11 us behind a 9 us solve, +23 us behind a 100 us one).  The drop-in shim synchronises
-    // behind every pyramid level's solve (src/GPUSolver.cu:314): five such wake-ups per 1080p frame.  Polling the stream from user space
-    // for the solve's length first costs the host a busy core for that long and the frame ~15 us per level less.
-    if (ctx->opt.sync_spin_us > 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            const hipError_t q = hipStreamQuery(ctx->stream);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }         // (the blocking call below reports whatever it is)
-            (void)hipGetLastError();                                                // (hipErrorNotReady is sticky in hipGetLastError: clear it)
-            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > ctx->opt.sync_spin_us) break;
-        }
-    }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return check_persistent_status(ctx);           // (a timed-out persistent launch is healed here: the affected calls run again, api.cpp above)
+    // (a timed-out persistent launch is healed here: the affected calls run again, api.cpp above)
+    return check_persistent_status(ctx);
 }
 
 int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
     if (!ctx) return RTDD_ERR_INVALID;
     switch (key) {
         case RTDD_OPT_FP_CONTRACT: ctx->opt.fp_contract = value ? 1 : 0; break;
-        case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 2, "sweep kernel must be 0..2"); ctx->opt.sweep_kernel = value; break;
-        case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 28, "temporal depth must be 0..28"); ctx->opt.temporal_depth = value; break;
-        case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024"); ctx->opt.rows_per_wave = value; break;
-        case RTDD_OPT_DEFOCUS_PATH: REQUIRE(ctx, value >= 0 && value <= 2, "defocus path must be 0..2"); ctx->opt.defocus_path = value; if (value == 0) ctx->defocus_table_sticky = ctx->defocus_band_sticky = false; break;      // (setting the automatic choice again forgets what earlier depths made it choose)
+        case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 2, "sweep kernel must be 0..2"); ctx->opt.sweep_kernel = value;
+        break;
+        case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 28, "temporal depth must be 0..28");
+        ctx->opt.temporal_depth = value; break;
+        case RTDD_OPT_ROWS_PER_WAVE: REQUIRE(ctx, value >= 0 && value <= 1024, "rows per wave must be 0..1024");
+        ctx->opt.rows_per_wave = value; break;
+        // (setting the automatic choice again forgets what earlier depths made it choose)
+        case RTDD_OPT_DEFOCUS_PATH: REQUIRE(ctx, value >= 0 && value <= 2, "defocus path must be 0..2"); ctx->opt.defocus_path = value;
+        if (value == 0) ctx->defocus_table_sticky = ctx->defocus_band_sticky = false; break;
         case RTDD_OPT_TILE: REQUIRE(ctx, value >= 0 && value <= 16, "tile must be 0..16"); ctx->opt.tile = value; break;
-        case RTDD_OPT_PERSISTENT: ctx->opt.persistent = ctx->persistent_wanted = value ? 1 : 0; ctx->persist_suspend = 0; break;    // (said explicitly: armed at once, whatever a heal suspended)
+        // (said explicitly: armed at once, whatever a heal suspended)
+        case RTDD_OPT_PERSISTENT: ctx->opt.persistent = ctx->persistent_wanted = value ? 1 : 0; ctx->persist_suspend = 0; break;
         case RTDD_OPT_ANNOTATION_LDS: ctx->opt.annotation_lds = value ? 1 : 0; break;
-        case RTDD_OPT_LIVE_ZERO_COPY: REQUIRE(ctx, value >= 0 && value <= 2, "RTDD_OPT_LIVE_ZERO_COPY is 0, 1 or 2"); ctx->opt.live_zero_copy = value; break;
-        case RTDD_OPT_TIMEOUT_HEAL: ctx->opt.timeout_heal = value ? 1 : 0; if (!value && !ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } break;
-        case RTDD_OPT_PERSISTENT_REARM_AFTER: REQUIRE(ctx, value >= 0 && value <= (1 << 20), "must be 0..2^20"); ctx->opt.rearm_after = value; break;
-        case RTDD_OPT_DEFOCUS_SLICE_MB: REQUIRE(ctx, value >= 0 && value <= 4095, "must be 0..4095 MB"); ctx->opt.defocus_slice_mb = value; break;
-        case RTDD_OPT_SYNC_SPIN_US: REQUIRE(ctx, value >= 0 && value <= 10000000, "must be 0..1e7 us"); ctx->opt.sync_spin_us = value; break;
+        case RTDD_OPT_LIVE_ZERO_COPY: REQUIRE(ctx, value >= 0 && value <= 2, "RTDD_OPT_LIVE_ZERO_COPY is 0, 1 or 2");
+        ctx->opt.live_zero_copy = value; break;
+        case RTDD_OPT_TIMEOUT_HEAL: ctx->opt.timeout_heal = value ? 1 : 0;
+        if (!value && !ctx->healing) { ctx->pending.clear(); ctx->pending_overflow = false; } break;
+        case RTDD_OPT_PERSISTENT_REARM_AFTER: REQUIRE(ctx, value >= 0 && value <= (1 << 20), "must be 0..2^20");
+        ctx->opt.rearm_after = value; break;
+        case RTDD_OPT_DEFOCUS_SLICE_MB: REQUIRE(ctx, value >= 0 && value <= 4095, "must be 0..4095 MB"); ctx->opt.defocus_slice_mb = value;
+        break;
+        case RTDD_OPT_DEFOCUS_STRIPS: REQUIRE(ctx, value >= 0 && value <= 2, "must be 0, 1 or 2"); ctx->opt.defocus_strips = value; break;
         case RTDD_OPT_AUTO_CYCLE_FIXED_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fixed_ns = value; break;
         case RTDD_OPT_AUTO_CYCLE_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_cycle_fs_per_px = value; break;
         case RTDD_OPT_AUTO_SWEEP_FS_PER_PX: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_sweep_fs_per_px = value; break;
         case RTDD_OPT_AUTO_SWEEP_FLOOR_NS: REQUIRE(ctx, value >= 0, "must be >= 0"); ctx->opt.auto_sweep_floor_ns = value; break;
-        case RTDD_OPT_DEBUG_WITHHOLD_TILE: REQUIRE(ctx, value >= 0 && value <= kSyncMaxTiles, "tile number + 1 out of range"); ctx->opt.debug_withhold_tile = value; break;
-        case RTDD_OPT_DEBUG_POLL_LIMIT_US: REQUIRE(ctx, value >= 0 && value <= 10000000, "poll limit must be 0..1e7 us"); ctx->opt.debug_poll_limit_us = value; break;
-        case RTDD_OPT_DEBUG_FORCE_STATUS: REQUIRE(ctx, value >= 0 && value <= 3, "status must be 0..3"); ctx->opt.debug_force_status = value; break;
+        case RTDD_OPT_DEBUG_WITHHOLD_TILE: REQUIRE(ctx, value >= 0 && value <= kSyncMaxTiles, "tile number + 1 out of range");
+        ctx->opt.debug_withhold_tile = value; break;
+        case RTDD_OPT_DEBUG_POLL_LIMIT_US: REQUIRE(ctx, value >= 0 && value <= 10000000, "poll limit must be 0..1e7 us");
+        ctx->opt.debug_poll_limit_us = value; break;
+        case RTDD_OPT_DEBUG_FORCE_STATUS: REQUIRE(ctx, value >= 0 && value <= 3, "status must be 0..3");
+        ctx->opt.debug_force_status = value; break;
         default: return fail(ctx, RTDD_ERR_INVALID, "unknown option");
     }
     return RTDD_OK;
@@ -387,7 +403,7 @@ int rtdd_get_option(rtdd_ctx *ctx, int key, int *value) {
         case RTDD_OPT_LIVE_ZERO_COPY: *value = ctx->opt.live_zero_copy; break;
         case RTDD_OPT_ANNOTATION_LDS: *value = ctx->opt.annotation_lds; break;
         case RTDD_OPT_PERSISTENT_REARM_AFTER: *value = ctx->opt.rearm_after; break;
-        case RTDD_OPT_SYNC_SPIN_US: *value = ctx->opt.sync_spin_us; break;
+        case RTDD_OPT_DEFOCUS_STRIPS: *value = ctx->opt.defocus_strips; break;
         case RTDD_OPT_DEFOCUS_SLICE_MB: *value = ctx->opt.defocus_slice_mb; break;
         case RTDD_OPT_DEFOCUS_LAST_SLICES: *value = ctx->defocus_last_slices; break;
         case RTDD_OPT_PERSISTENT_SUSPENDED: *value = ctx->persist_suspend; break;
@@ -448,10 +464,12 @@ int rtdd_allocate(rtdd_ctx *ctx, int rows, int cols, int levels) {
         const size_t all = L.elems * (size_t)images;           // (a batched pyramid: every plane once per image, Level::view)
         for (auto &p : L.plane) {
             hipError_t e = hipMalloc((void **)&p, all * sizeof(float));
-            if (e != hipSuccess) { free_levels(ctx); return fail(ctx, e == hipErrorOutOfMemory ? RTDD_ERR_NOMEM : RTDD_ERR_HIP, "hipMalloc(plane)", e); }
+            if (e != hipSuccess) { free_levels(ctx); return fail(ctx, e == hipErrorOutOfMemory ? RTDD_ERR_NOMEM : RTDD_ERR_HIP,
+                "hipMalloc(plane)", e); }
         }
         hipError_t e = hipMalloc((void **)&L.meta, all * sizeof(uint32_t));
-        if (e != hipSuccess) { free_levels(ctx); return fail(ctx, e == hipErrorOutOfMemory ? RTDD_ERR_NOMEM : RTDD_ERR_HIP, "hipMalloc(meta)", e); }
+        if (e != hipSuccess) { free_levels(ctx); return fail(ctx, e == hipErrorOutOfMemory ? RTDD_ERR_NOMEM : RTDD_ERR_HIP,
+            "hipMalloc(meta)", e); }
         // guard cells are read (never used); give them a defined value once
         for (auto &p : L.plane) RTDD_HIP(ctx, hipMemsetAsync(p, 0, all * sizeof(float), ctx->stream));
         RTDD_HIP(ctx, hipMemsetAsync(L.meta, 0, all * sizeof(uint32_t), ctx->stream));
@@ -505,7 +523,8 @@ static int check_solve_args(rtdd_ctx *ctx, const float *depth, size_t depthPitch
                             const uint8_t *gray, size_t grayPitch, int rows, int cols, int level) {
     REQUIRE(ctx, depth && scribble && gray, "null image pointer");
     REQUIRE(ctx, rows > 0 && cols > 0, "rows and cols must be positive");
-    REQUIRE(ctx, depthPitch >= (size_t)cols * sizeof(float) && depthPitch % sizeof(float) == 0, "depth pitch too small or not a multiple of 4");
+    REQUIRE(ctx, depthPitch >= (size_t)cols * sizeof(float) && depthPitch % sizeof(float) == 0,
+        "depth pitch too small or not a multiple of 4");
     REQUIRE(ctx, scribblePitch >= (size_t)cols && grayPitch >= (size_t)cols, "u8 pitch smaller than a row");
     if (ctx->levels.empty()) return fail(ctx, RTDD_ERR_STATE, "rtdd_allocate has not been called");
     if (!ctx->weights_loaded) return fail(ctx, RTDD_ERR_STATE, "rtdd_load_weights has not been called");
@@ -625,7 +644,8 @@ struct Solve {
     int vcycles(int max_cycles, int check_every, double alternative_seconds) {
         const double px = (double)rows * cols;
         const double cycle_seconds = ctx->opt.auto_cycle_fixed_ns * 1e-9 + px * ctx->opt.auto_cycle_fs_per_px * 1e-15;
-        return launch_multigrid(ctx, L, ip, rows, cols, max_cycles, p->tolerance, check_every, alternative_seconds, cycle_seconds, &pk, &cycles, &residual, &launches);
+        return launch_multigrid(ctx, L, ip, rows, cols, max_cycles, p->tolerance, check_every, alternative_seconds, cycle_seconds, &pk,
+            &cycles, &residual, &launches);
     }
 
     // V-cycles while they pay: they stop at the tolerance, after kAutoMaxCycles, or when the cycles still needed (at the rate of the
@@ -649,7 +669,8 @@ struct Solve {
 static int solve_once(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
                       const uint8_t *gray, size_t grayPitch, int rows, int cols, int level, const rtdd_solve_params *params, int seq,
                       const SolveTargets &t, SolveOutcome *out) {
-    const Level L = ctx->levels[level].view(t.batch.first);      // (the first image the launches cover: image 0 of 1 unless the caller says otherwise)
+    // (the first image the launches cover: image 0 of 1 unless the caller says otherwise)
+    const Level L = ctx->levels[level].view(t.batch.first);
     const size_t ip = plane_pitch(cols);
     const bool prof = ctx->profile_on;
     hipEvent_t *ev = ctx->ev + 4 * (ctx->prof_pending % rtdd_ctx::kProfSlots);
@@ -674,7 +695,8 @@ static int solve_once(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint
     if (rc != RTDD_OK) return rc;
 
     if (prof) RTDD_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-    if (out) { out->plane = s.pk; out->seq = seq; }     // (a deferred copy-back is k_pyrup_inject's: estimate_levels hands it the same number)
+    // (a deferred copy-back is k_pyrup_inject's: estimate_levels hands it the same number)
+    if (out) { out->plane = s.pk; out->seq = seq; }
     if (!t.defer_finish) {
         rc = launch_finish(ctx, L, ip, s.pk, depth, depthPitch, rows, cols, t, seq);
         if (rc != RTDD_OK) return rc;
@@ -693,7 +715,8 @@ static int solve_once(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint
 int rtdd_solve_ex(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8_t *scribble, size_t scribblePitch,
                   const uint8_t *gray, size_t grayPitch, int rows, int cols, int level,
                   const rtdd_solve_params *params, rtdd_solve_info *info) {
-    return solve_with(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, info, SolveTargets(), nullptr);
+    return solve_with(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, info, SolveTargets(),
+        nullptr);
 }
 
 }  // extern "C"
@@ -707,19 +730,23 @@ int rtdd::solve_with(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, params != nullptr, "null params");
     REQUIRE(ctx, params->maxIterations >= 0, "maxIterations must be >= 0");
-    REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS || params->method == RTDD_METHOD_MULTIGRID ||
+    REQUIRE(ctx, params->method == RTDD_METHOD_CHEBYSHEV_JACOBI || params->method == RTDD_METHOD_RED_BLACK_GS
+        || params->method == RTDD_METHOD_MULTIGRID ||
                  params->method == RTDD_METHOD_AUTO, "unknown method");
     REQUIRE(ctx, params->method != RTDD_METHOD_AUTO || params->tolerance > 0.0f, "RTDD_METHOD_AUTO needs a tolerance");
-    REQUIRE(ctx, params->method != RTDD_METHOD_RED_BLACK_GS || params->relaxation == RTDD_RELAXATION_AUTO || (params->relaxation >= 0.0f && params->relaxation < 2.0f),
+    REQUIRE(ctx, params->method != RTDD_METHOD_RED_BLACK_GS || params->relaxation == RTDD_RELAXATION_AUTO
+        || (params->relaxation >= 0.0f && params->relaxation < 2.0f),
             "relaxation must be in [0,2) or RTDD_RELAXATION_AUTO");
     int rc = check_solve_args(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level);
     if (rc != RTDD_OK) return rc;
     REQUIRE(ctx, t.batch.first >= 0 && t.batch.n >= 1 && t.batch.first + t.batch.n <= ctx->levels_images,
             "the batch exceeds what the context's levels were allocated for");
-    REQUIRE(ctx, t.batch.n == 1 || (params->method == RTDD_METHOD_CHEBYSHEV_JACOBI && params->tolerance <= 0.0f && ctx->opt.sweep_kernel != 1),
+    REQUIRE(ctx, t.batch.n == 1
+        || (params->method == RTDD_METHOD_CHEBYSHEV_JACOBI && params->tolerance <= 0.0f && ctx->opt.sweep_kernel != 1),
             "a batched solve runs the reference's scheme with the temporally blocked kernel only");
     DeviceGuard g(ctx->device);
-    if (ctx->solve_seq >= (1 << 30)) {              // (once in 10^9 solves) the sequence numbers start over: nothing may be left that compares against them
+    // (once in 10^9 solves) the sequence numbers start over: nothing may be left that compares against them
+    if (ctx->solve_seq >= (1 << 30)) {
         if (!ctx->healing) { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
         RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         *(volatile int *)ctx->confirm_host = 0;
@@ -728,19 +755,25 @@ int rtdd::solve_with(rtdd_ctx *ctx, float *depth, size_t depthPitch, const uint8
     const int seq = ++ctx->solve_seq;
     const Options asked = ctx->opt;
     rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq, t, out);
-    // A residual check inside the solve found the status word set, and the calls before this one have been healed (check_persistent_status):
+    // A residual check inside the solve found the status word set, and the calls before this one have been healed
+    // (check_persistent_status):
     // nothing of this solve has reached the caller's buffers (its copy-back is the last thing it does), so it simply starts over --
     // persistence is off by now.
-    if (rc == kRestartSolve) rc = solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq, t, out);
-    if (rc == kRestartSolve) rc = fail(ctx, RTDD_ERR_TIMEOUT, "the solve was restarted after a timed-out persistent launch and failed again");
+    if (rc == kRestartSolve) rc =
+        solve_once(ctx, depth, depthPitch, scribble, scribblePitch, gray, grayPitch, rows, cols, level, params, seq, t, out);
+    if (rc == kRestartSolve) rc =
+        fail(ctx, RTDD_ERR_TIMEOUT, "the solve was restarted after a timed-out persistent launch and failed again");
     if (rc != RTDD_OK) return rc;
-    if (!ctx->healing && ctx->persist_suspend > 0 && --ctx->persist_suspend == 0 && ctx->persistent_wanted) ctx->opt.persistent = 1;     // re-armed (check_persistent_status)
-    if (!ctx->healing && t.logged && ctx->opt.timeout_heal) {       // remembered until a copy-back kernel or a synchronising call has confirmed it
+    // re-armed (check_persistent_status)
+    if (!ctx->healing && ctx->persist_suspend > 0 && --ctx->persist_suspend == 0 && ctx->persistent_wanted) ctx->opt.persistent = 1;
+    // remembered until a copy-back kernel or a synchronising call has confirmed it
+    if (!ctx->healing && t.logged && ctx->opt.timeout_heal) {
         prune_confirmed(ctx);
         if (ctx->pending.size() >= kMaxPendingOps) { ctx->pending.clear(); ctx->pending_overflow = true; }
         PendingOp op;
         op.kind = PendingOp::kSolve; op.opt = asked; op.seq = seq;
-        op.depth = depth; op.depthPitch = depthPitch; op.scribble = scribble; op.scribblePitch = scribblePitch; op.gray = gray; op.grayPitch = grayPitch;
+        op.depth = depth; op.depthPitch = depthPitch; op.scribble = scribble; op.scribblePitch = scribblePitch; op.gray = gray;
+        op.grayPitch = grayPitch;
         op.rows = rows; op.cols = cols; op.level = level; op.params = *params;
         op.targets = t;
         op.id = ++ctx->op_counter;
@@ -854,7 +887,8 @@ int rtdd_simulate_defocus(rtdd_ctx *ctx, const uint8_t *original, size_t origina
     REQUIRE(ctx, original != artistic, "defocus cannot run in place");
     DeviceGuard g(ctx->device);
     rc = launch_defocus(ctx, original, originalPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
-    if (rc == RTDD_OK) log_effect(ctx, PendingOp::kDefocus, original, originalPitch, nullptr, 0, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    if (rc == RTDD_OK) log_effect(ctx, PendingOp::kDefocus, original, originalPitch, nullptr, 0, depth, depthPitch, artistic, artisticPitch,
+        rows, cols);
     return rc;
 }
 
@@ -866,7 +900,8 @@ int rtdd_simulate_desaturation(rtdd_ctx *ctx, const uint8_t *original, size_t or
     REQUIRE(ctx, gray && grayPitch >= (size_t)cols, "bad gray image");
     DeviceGuard g(ctx->device);
     rc = launch_desaturate(ctx, original, originalPitch, gray, grayPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
-    if (rc == RTDD_OK) log_effect(ctx, PendingOp::kDesaturate, original, originalPitch, gray, grayPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    if (rc == RTDD_OK) log_effect(ctx, PendingOp::kDesaturate, original, originalPitch, gray, grayPitch, depth, depthPitch, artistic,
+        artisticPitch, rows, cols);
     return rc;
 }
 
@@ -877,7 +912,8 @@ int rtdd_simulate_haze(rtdd_ctx *ctx, const uint8_t *original, size_t originalPi
     if (rc != RTDD_OK || rows == 0 || cols == 0) return rc;
     DeviceGuard g(ctx->device);
     rc = launch_haze(ctx, original, originalPitch, depth, depthPitch, artistic, artisticPitch, rows, cols);
-    if (rc == RTDD_OK) log_effect(ctx, PendingOp::kHaze, original, originalPitch, nullptr, 0, depth, depthPitch, artistic, artisticPitch, rows, cols);
+    if (rc == RTDD_OK) log_effect(ctx, PendingOp::kHaze, original, originalPitch, nullptr, 0, depth, depthPitch, artistic, artisticPitch,
+        rows, cols);
     return rc;
 }
 

@@ -37,18 +37,21 @@ struct Pyramid {
 // estimate, download of the u8 map (:290-291).  Frames are pipelined two deep: the copies run on a stream of their own, frame N+1's
 // upload while frame N computes, frame N's download while frame N+1 computes.  Slot k = frame number % 2.
 struct Live {
-    hipStream_t up = nullptr, copy = nullptr;     // uploads and downloads each on a stream of their own: frame N+1's upload must not queue behind frame N's download
+    // uploads and downloads each on a stream of their own: frame N+1's upload must not queue behind frame N's download
+    hipStream_t up = nullptr, copy = nullptr;
     Image scribble_stage[2], edited_stage[2], u8_stage[2];
     hipEvent_t h2d_done[2] = {nullptr, nullptr}, est_done[2] = {nullptr, nullptr}, d2h_done[2] = {nullptr, nullptr};
     int *status_host = nullptr;           // page-locked, 2 x 8 ints: the kernels' control words as they were behind each frame's estimate
-    Image art_stage[2];                   // a frame's sticky depth effect (rtdd_live_submit_ex) renders here; allocated with the first such frame
+    // a frame's sticky depth effect (rtdd_live_submit_ex) renders here; allocated with the first such frame
+    Image art_stage[2];
     struct Frame {
         uint8_t *host = nullptr; size_t pitch = 0;
         bool in_flight = false, direct = false;
         unsigned long long op_id = 0;
         int effect = 0;                   // RTDD_EFFECT_*: the frame carries an artistic image too
         uint8_t *art_host = nullptr; size_t art_pitch = 0;
-        bool art_queued = false;          // its download was queued at submit on the compute stream (no other frame in flight); else rtdd_live_wait issues it
+        // its download was queued at submit on the compute stream (no other frame in flight); else rtdd_live_wait issues it
+        bool art_queued = false;
     } frame[2];
     unsigned long long submitted = 0, waited = 0;
     // Round 5: no device-to-device staging copies.  A frame's annotation is uploaded into the staging pair that is NOT the pyramid's
@@ -57,28 +60,34 @@ struct Live {
     // The pyramid's own annotation buffers are kept here and put back before the pyramid is freed.
     void *own_scribble = nullptr, *own_edited = nullptr, *own_artistic = nullptr;
     Bounce bounce_art;                      // (an artistic image on its way to a host image with an unaligned pitch, compute stream)
-    Bounce bounce_up[2][2];                 // ([frame parity][scribble, edited]: uploads of images with an unaligned host pitch, rtdd_live_submit)
-    uint8_t *host_bounce = nullptr; size_t host_bounce_bytes = 0;      // page-locked: a staged map on its way to a host image with an unaligned pitch (live_fetch)
+    // ([frame parity][scribble, edited]: uploads of images with an unaligned host pitch, rtdd_live_submit)
+    Bounce bounce_up[2][2];
+    // page-locked: a staged map on its way to a host image with an unaligned pitch (live_fetch)
+    uint8_t *host_bounce = nullptr; size_t host_bounce_bytes = 0;
 };
 
 // The device's name for a page-locked host image (every byte of rows x cols at `pitch` inside one registered range), or nullptr.  Asked
-// for every frame (two driver queries, ~2 us of host time): a buffer freed and allocated again at the same address may not be page-locked any more.
+// for every frame (two driver queries, ~2 us of host time): a buffer freed and allocated again at the same address may not be page-locked
+// any more.
 static uint8_t *live_device_view(const uint8_t *host, size_t pitch, int rows, int cols) {
     uint8_t *dev = nullptr;
     hipPointerAttribute_t a0, a1;
     const uint8_t *last = host + (size_t)(rows - 1) * pitch + (size_t)cols - 1;
-    if (hipPointerGetAttributes(&a0, host) == hipSuccess && hipPointerGetAttributes(&a1, last) == hipSuccess && a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost &&
+    if (hipPointerGetAttributes(&a0, host) == hipSuccess && hipPointerGetAttributes(&a1, last) == hipSuccess && a0.type == hipMemoryTypeHost
+        && a1.type == hipMemoryTypeHost &&
         a0.devicePointer && a1.devicePointer && (const uint8_t *)a1.devicePointer - (const uint8_t *)a0.devicePointer == last - host)
         dev = (uint8_t *)a0.devicePointer;
     else (void)hipGetLastError();                                   // (an ordinary host pointer: the query fails, nothing else has)
     return dev;
 }
 
-// hipMemcpy2DAsync between host and device takes ~9 us PER ROW when the host pitch is no multiple of four -- 8 ms for one plane of a 910-pixel-wide
+// hipMemcpy2DAsync between host and device takes ~9 us PER ROW when the host pitch is no multiple of four -- 8 ms for one plane of a
+// 910-pixel-wide
 // image (the dataset's Arara) where an aligned pitch takes 25 us (profiles/r05_copy2d_pitch.txt).  A host image with such a pitch whose
 // rows are contiguous (what a continuous cv::Mat or a numpy array is) moves as ONE linear copy through a contiguous device buffer and a
 // re-pitching kernel on the same stream; any other layout takes the runtime's copy as it is.
-static bool wants_bounce(size_t hostPitch, size_t widthBytes, int rows) { return hostPitch % 4 != 0 && hostPitch == widthBytes && rows > 1; }
+static bool wants_bounce(size_t hostPitch, size_t widthBytes, int rows) { return hostPitch % 4 != 0 && hostPitch == widthBytes
+    && rows > 1; }
 static int bounce_reserve(rtdd_ctx *ctx, Bounce &b, size_t bytes, hipStream_t stream) {
     if (b.bytes >= bytes) return RTDD_OK;
     if (b.ptr) { RTDD_HIP(ctx, hipStreamSynchronize(stream)); RTDD_HIP(ctx, hipFree(b.ptr)); b.ptr = nullptr; b.bytes = 0; }
@@ -86,15 +95,19 @@ static int bounce_reserve(rtdd_ctx *ctx, Bounce &b, size_t bytes, hipStream_t st
     b.bytes = bytes;
     return RTDD_OK;
 }
-int copy_h2d(rtdd_ctx *ctx, Bounce &b, void *dev, size_t devPitch, const void *host, size_t hostPitch, size_t widthBytes, int rows, hipStream_t stream) {
-    if (!wants_bounce(hostPitch, widthBytes, rows)) { RTDD_HIP(ctx, hipMemcpy2DAsync(dev, devPitch, host, hostPitch, widthBytes, rows, hipMemcpyHostToDevice, stream)); return RTDD_OK; }
+int copy_h2d(rtdd_ctx *ctx, Bounce &b, void *dev, size_t devPitch, const void *host, size_t hostPitch, size_t widthBytes, int rows,
+    hipStream_t stream) {
+    if (!wants_bounce(hostPitch, widthBytes, rows)) { RTDD_HIP(ctx,
+        hipMemcpy2DAsync(dev, devPitch, host, hostPitch, widthBytes, rows, hipMemcpyHostToDevice, stream)); return RTDD_OK; }
     const int rc = bounce_reserve(ctx, b, widthBytes * (size_t)rows, stream);
     if (rc != RTDD_OK) return rc;
     RTDD_HIP(ctx, hipMemcpyAsync(b.ptr, host, widthBytes * (size_t)rows, hipMemcpyHostToDevice, stream));
     return launch_repitch(ctx, stream, b.ptr, widthBytes, dev, devPitch, widthBytes, rows);
 }
-int copy_d2h(rtdd_ctx *ctx, Bounce &b, void *host, size_t hostPitch, const void *dev, size_t devPitch, size_t widthBytes, int rows, hipStream_t stream) {
-    if (!wants_bounce(hostPitch, widthBytes, rows)) { RTDD_HIP(ctx, hipMemcpy2DAsync(host, hostPitch, dev, devPitch, widthBytes, rows, hipMemcpyDeviceToHost, stream)); return RTDD_OK; }
+int copy_d2h(rtdd_ctx *ctx, Bounce &b, void *host, size_t hostPitch, const void *dev, size_t devPitch, size_t widthBytes, int rows,
+    hipStream_t stream) {
+    if (!wants_bounce(hostPitch, widthBytes, rows)) { RTDD_HIP(ctx,
+        hipMemcpy2DAsync(host, hostPitch, dev, devPitch, widthBytes, rows, hipMemcpyDeviceToHost, stream)); return RTDD_OK; }
     int rc = bounce_reserve(ctx, b, widthBytes * (size_t)rows, stream);
     if (rc != RTDD_OK) return rc;
     if ((rc = launch_repitch(ctx, stream, dev, devPitch, b.ptr, widthBytes, widthBytes, rows)) != RTDD_OK) return rc;
@@ -114,12 +127,14 @@ static bool stale_live_pointer(const Pyramid *p, const void *q) {
     const Live *v = p->live;
     if (!v || !q) return false;
     auto in_image = [](const void *base, const Image &like, const void *r) {
-        return base && (const char *)r >= (const char *)base && (const char *)r < (const char *)base + like.pitch * (size_t)(like.rows > 0 ? like.rows : 1);
+        return base && (const char *)r >= (const char *)base
+            && (const char *)r < (const char *)base + like.pitch * (size_t)(like.rows > 0 ? like.rows : 1);
     };
     const void *olds[3] = {v->own_scribble, v->scribble_stage[0].ptr, v->scribble_stage[1].ptr};
     const void *olde[3] = {v->own_edited, v->edited_stage[0].ptr, v->edited_stage[1].ptr};
     for (int i = 0; i < 3; i++)
-        if ((olds[i] != p->scribble[0].ptr && in_image(olds[i], p->scribble[0], q)) || (olde[i] != p->edited[0].ptr && in_image(olde[i], p->edited[0], q)))
+        if ((olds[i] != p->scribble[0].ptr && in_image(olds[i], p->scribble[0], q))
+            || (olde[i] != p->edited[0].ptr && in_image(olde[i], p->edited[0], q)))
             return true;
     return false;
 }
@@ -135,7 +150,8 @@ int pyramid_note_write(rtdd_ctx *ctx, const void *scribble, const void *edited) 
     if (!p) return RTDD_OK;
     if (stale_live_pointer(p, scribble) || stale_live_pointer(p, edited)) return fail(ctx, RTDD_ERR_STATE, kStaleText);
     for (int l = 0; l < p->levels; l++)
-        if (inside(p->scribble[l], scribble) || inside(p->edited[l], edited) || inside(p->scribble[l], edited) || inside(p->edited[l], scribble))
+        if (inside(p->scribble[l], scribble) || inside(p->edited[l], edited) || inside(p->scribble[l], edited)
+            || inside(p->edited[l], scribble))
             p->annotation_dirty = true;
     // the coarsest depth image carries the injected labels of src/main.cpp:257-259, which an estimate only renews when the annotation
     // changed: whoever overwrites it through the library (rtdd_upload, rtdd_convert_to_float, rtdd_pyrup_depth) makes the next
@@ -243,7 +259,9 @@ int rtdd_pyramid_create_batch(rtdd_ctx *ctx, int rows, int cols, int images) {
         if ((rc = alloc_image(ctx, p->edited[l], lr, lc, 3, 0, images)) != RTDD_OK) return rc;        // :130-131
         if ((rc = alloc_image(ctx, p->depth[l], lr, lc, 4, 0, images)) != RTDD_OK) return rc;
         for (int b = 0; b < images; b++)
-            if (lr > 0 && lc > 0 && (rc = launch_fill_f32(ctx, (float *)p->depth[l].at(b), p->depth[l].pitch, lr, lc, 255.0f)) != RTDD_OK) return rc;   // :136
+            // :136
+            if (lr > 0 && lc > 0 && (rc = launch_fill_f32(ctx, (float *)p->depth[l].at(b), p->depth[l].pitch, lr, lc,
+                255.0f)) != RTDD_OK) return rc;
         gr = (gr + 1) / 2; gc = (gc + 1) / 2;
     }
     ctx->alloc_images = images;
@@ -266,23 +284,30 @@ int rtdd_pyramid_set_image(rtdd_ctx *ctx, const uint8_t *bgr, size_t pitch) {
     Pyramid *p = ctx->pyr;
     REQUIRE(ctx, bgr && pitch >= (size_t)p->cols * 3, "bad image");
     DeviceGuard g(ctx->device);
-    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }    // (a new image resets the warm-start state a logged estimate ran on)
+    // (a new image resets the warm-start state a logged estimate ran on)
+    { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     const int b = p->sel;                          // (a batched pyramid: the selected image)
-    RTDD_HIP(ctx, hipMemcpy2DAsync(p->original.at(b), p->original.pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));
-    RTDD_HIP(ctx, hipMemcpy2DAsync(p->edited[0].at(b), p->edited[0].pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice, ctx->stream));   // :158
+    RTDD_HIP(ctx, hipMemcpy2DAsync(p->original.at(b), p->original.pitch, bgr, pitch, (size_t)p->cols * 3, p->rows, hipMemcpyDeviceToDevice,
+        ctx->stream));
+    // :158
+    RTDD_HIP(ctx, hipMemcpy2DAsync(p->edited[0].at(b), p->edited[0].pitch, bgr, pitch, (size_t)p->cols * 3, p->rows,
+        hipMemcpyDeviceToDevice, ctx->stream));
     // A new image is a new problem (the reference loads one image per process, src/main.cpp:93): everything an estimate carries
     // over to the next one -- the depth pyramid it warm-starts from (:136) and the coarse annotation levels, which
     // GPUPyrDownAnnotation only ever adds to -- goes back to its initial state.
     p->annotation_dirty = true;
     for (int l = 0; l < p->levels; l++) {
-        if (p->scribble[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->scribble[l].at(b), 0, p->scribble[l].pitch * p->scribble[l].rows, ctx->stream));
-        if (l > 0 && p->edited[l].ptr) RTDD_HIP(ctx, hipMemsetAsync(p->edited[l].at(b), 0, p->edited[l].pitch * p->edited[l].rows, ctx->stream));
+        if (p->scribble[l].ptr) RTDD_HIP(ctx,
+            hipMemsetAsync(p->scribble[l].at(b), 0, p->scribble[l].pitch * p->scribble[l].rows, ctx->stream));
+        if (l > 0 && p->edited[l].ptr) RTDD_HIP(ctx,
+            hipMemsetAsync(p->edited[l].at(b), 0, p->edited[l].pitch * p->edited[l].rows, ctx->stream));
         if (p->depth[l].rows > 0 && p->depth[l].cols > 0) {
             const int rc_ = launch_fill_f32(ctx, (float *)p->depth[l].at(b), p->depth[l].pitch, p->depth[l].rows, p->depth[l].cols, 255.0f);
             if (rc_ != RTDD_OK) return rc_;
         }
     }
-    int rc = launch_bgr2gray(ctx, (const uint8_t *)p->original.at(b), p->original.pitch, (uint8_t *)p->gray[0].at(b), p->gray[0].pitch, p->rows, p->cols);
+    int rc = launch_bgr2gray(ctx, (const uint8_t *)p->original.at(b), p->original.pitch, (uint8_t *)p->gray[0].at(b), p->gray[0].pitch,
+        p->rows, p->cols);
     // the gray pyramid depends on the image only: built once here instead of once per estimate (:241-247)
     for (int l = 1; l < p->levels && rc == RTDD_OK; l++)
         rc = launch_pyrdown_u8(ctx, (const uint8_t *)p->gray[l - 1].at(b), p->gray[l - 1].pitch, p->gray[l - 1].rows, p->gray[l - 1].cols,
@@ -298,7 +323,8 @@ int rtdd_pyramid_set_annotation(rtdd_ctx *ctx, const uint8_t *annotation, size_t
     DeviceGuard g(ctx->device);
     p->annotation_dirty = true;
     return launch_decode_annotation(ctx, (const uint8_t *)p->original.at(p->sel), p->original.pitch, annotation, pitch,
-                                    (uint8_t *)p->edited[0].at(p->sel), p->edited[0].pitch, (uint8_t *)p->scribble[0].at(p->sel), p->scribble[0].pitch, p->rows, p->cols);
+                                    (uint8_t *)p->edited[0].at(p->sel), p->edited[0].pitch, (uint8_t *)p->scribble[0].at(p->sel),
+                                        p->scribble[0].pitch, p->rows, p->cols);
 }
 
 int rtdd_pyramid_image(rtdd_ctx *ctx, int kind, int level, void **ptr, size_t *pitch, int *rows, int *cols) {
@@ -357,7 +383,8 @@ static int estimate_submit(rtdd_ctx *ctx, int maxIterations, unsigned long long 
         uint8_t *sc[32], *ed[32]; size_t sp[32], ep[32], zs[32], ze[32]; int lr[32], lc[32];
         if (P > 12) return fail(ctx, RTDD_ERR_INVALID, "more than 12 pyramid levels");
         for (int l = 0; l < P; l++) {
-            sc[l] = (uint8_t *)p->scribble[l].ptr; ed[l] = (uint8_t *)p->edited[l].ptr; sp[l] = p->scribble[l].pitch; ep[l] = p->edited[l].pitch;
+            sc[l] = (uint8_t *)p->scribble[l].ptr; ed[l] = (uint8_t *)p->edited[l].ptr; sp[l] = p->scribble[l].pitch;
+            ep[l] = p->edited[l].pitch;
             zs[l] = p->scribble[l].stride; ze[l] = p->edited[l].stride; lr[l] = p->edited[l].rows; lc[l] = p->edited[l].cols;
         }
         // src/main.cpp:249-259: the P - 1 annotation levels and the coarsest level's injection, one launch (image_kernels.hip)
@@ -406,7 +433,8 @@ static int live_create(rtdd_ctx *ctx) {
     Live *v = new (std::nothrow) Live();
     if (!v) return fail(ctx, RTDD_ERR_NOMEM, "live state");
     p->live = v;
-    RTDD_HIP(ctx, hipStreamCreateWithFlags(&v->copy, hipStreamNonBlocking));       // (never joins the null stream implicitly: the context's stream may be it)
+    // (never joins the null stream implicitly: the context's stream may be it)
+    RTDD_HIP(ctx, hipStreamCreateWithFlags(&v->copy, hipStreamNonBlocking));
     RTDD_HIP(ctx, hipStreamCreateWithFlags(&v->up, hipStreamNonBlocking));
     int rc;
     for (int k = 0; k < 2; k++) {
@@ -417,7 +445,8 @@ static int live_create(rtdd_ctx *ctx) {
         RTDD_HIP(ctx, hipEventCreateWithFlags(&v->est_done[k], hipEventDisableTiming));
         RTDD_HIP(ctx, hipEventCreateWithFlags(&v->d2h_done[k], hipEventDisableTiming));
     }
-    if (v->scribble_stage[0].pitch != p->scribble[0].pitch || v->edited_stage[0].pitch != p->edited[0].pitch || v->u8_stage[0].pitch != p->depth_u8.pitch)
+    if (v->scribble_stage[0].pitch != p->scribble[0].pitch || v->edited_stage[0].pitch != p->edited[0].pitch
+        || v->u8_stage[0].pitch != p->depth_u8.pitch)
         return fail(ctx, RTDD_ERR_STATE, "live staging images and pyramid images differ in pitch");
     v->own_scribble = p->scribble[0].ptr; v->own_edited = p->edited[0].ptr;
     RTDD_HIP(ctx, hipHostMalloc((void **)&v->status_host, 2 * 8 * sizeof(int), hipHostMallocDefault));
@@ -440,10 +469,12 @@ static int live_fetch(rtdd_ctx *ctx, Live *v, int k, bool map, bool art) {
     Pyramid *p = ctx->pyr;
     const Live::Frame &f = v->frame[k];
     struct Part { bool on; uint8_t *host; size_t pitch, width; const Image *st; size_t off; } parts[2] = {
-        {map, f.host, f.pitch, (size_t)p->cols, &v->u8_stage[k], 0}, {art && f.effect != 0, f.art_host, f.art_pitch, (size_t)p->cols * 3, &v->art_stage[k], 0}};
+        {map, f.host, f.pitch, (size_t)p->cols, &v->u8_stage[k], 0},
+            {art && f.effect != 0, f.art_host, f.art_pitch, (size_t)p->cols * 3, &v->art_stage[k], 0}};
     size_t bounce = 0;
     for (Part &q : parts)
-        if (q.on && q.pitch % 4 != 0 && p->rows > 1) { q.off = bounce + 1; bounce += q.st->pitch * (size_t)p->rows; }     // (off - 1: its place in the bounce buffer)
+        // (off - 1: its place in the bounce buffer)
+        if (q.on && q.pitch % 4 != 0 && p->rows > 1) { q.off = bounce + 1; bounce += q.st->pitch * (size_t)p->rows; }
     if (bounce > v->host_bounce_bytes) {
         if (v->host_bounce) {
             RTDD_HIP(ctx, hipStreamSynchronize(v->copy)); RTDD_HIP(ctx, hipHostFree(v->host_bounce));
@@ -454,20 +485,23 @@ static int live_fetch(rtdd_ctx *ctx, Live *v, int k, bool map, bool art) {
     }
     for (const Part &q : parts) {
         if (!q.on) continue;
-        if (q.off) RTDD_HIP(ctx, hipMemcpyAsync(v->host_bounce + q.off - 1, q.st->ptr, q.st->pitch * (size_t)p->rows, hipMemcpyDeviceToHost, v->copy));
+        if (q.off) RTDD_HIP(ctx,
+            hipMemcpyAsync(v->host_bounce + q.off - 1, q.st->ptr, q.st->pitch * (size_t)p->rows, hipMemcpyDeviceToHost, v->copy));
         else RTDD_HIP(ctx, hipMemcpy2DAsync(q.host, q.pitch, q.st->ptr, q.st->pitch, q.width, p->rows, hipMemcpyDeviceToHost, v->copy));
     }
     RTDD_HIP(ctx, hipMemcpyAsync(v->status_host + 8 * k, ctx->sync_words, 8 * sizeof(int), hipMemcpyDeviceToHost, v->copy));
     RTDD_HIP(ctx, hipStreamSynchronize(v->copy));
     for (const Part &q : parts)
         if (q.on && q.off)
-            for (int y = 0; y < p->rows; y++) std::memcpy(q.host + (size_t)y * q.pitch, v->host_bounce + q.off - 1 + (size_t)y * q.st->pitch, q.width);
+            for (int y = 0; y < p->rows; y++) std::memcpy(q.host + (size_t)y * q.pitch,
+                v->host_bounce + q.off - 1 + (size_t)y * q.st->pitch, q.width);
     return RTDD_OK;
 }
 
 int rtdd_live_wait(rtdd_ctx *ctx) {
     if (!ctx) return RTDD_ERR_INVALID;
-    if (!ctx->pyr || !ctx->pyr->live || ctx->pyr->live->submitted == ctx->pyr->live->waited) return fail(ctx, RTDD_ERR_STATE, "no frame in flight");
+    if (!ctx->pyr || !ctx->pyr->live || ctx->pyr->live->submitted == ctx->pyr->live->waited) return fail(ctx, RTDD_ERR_STATE,
+        "no frame in flight");
     Pyramid *p = ctx->pyr;
     Live *v = p->live;
     DeviceGuard g(ctx->device);
@@ -480,7 +514,8 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
         RTDD_HIP(ctx, hipEventSynchronize(fr.direct ? v->d2h_done[k] : v->est_done[k]));
         { const int rc_ = live_fetch(ctx, v, k, fetch_map, fetch_art); if (rc_ != RTDD_OK) return rc_; }
     }
-    if (v->status_host[8 * k + kSyncStatus] == 0) {                                 // the usual case: the frame is good, and so is everything logged before it
+    // the usual case: the frame is good, and so is everything logged before it
+    if (v->status_host[8 * k + kSyncStatus] == 0) {
         size_t n = 0;
         while (n < ctx->pending.size() && ctx->pending[n].id <= v->frame[k].op_id) n++;
         ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + n);
@@ -509,31 +544,37 @@ int rtdd_live_wait(rtdd_ctx *ctx) {
 
 int rtdd_live_submit(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribblePitch, const uint8_t *hostEdited, size_t editedPitch,
                      int maxIterations, uint8_t *hostDepthU8, size_t depthPitch) {
-    return rtdd_live_submit_ex(ctx, hostScribble, scribblePitch, hostEdited, editedPitch, maxIterations, hostDepthU8, depthPitch, RTDD_EFFECT_NONE, nullptr, 0);
+    return rtdd_live_submit_ex(ctx, hostScribble, scribblePitch, hostEdited, editedPitch, maxIterations, hostDepthU8, depthPitch,
+        RTDD_EFFECT_NONE, nullptr, 0);
 }
 
 int rtdd_live_submit_ex(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scribblePitch, const uint8_t *hostEdited, size_t editedPitch,
-                        int maxIterations, uint8_t *hostDepthU8, size_t depthPitch, int effect, uint8_t *hostArtistic, size_t artisticPitch) {
+                        int maxIterations, uint8_t *hostDepthU8, size_t depthPitch, int effect, uint8_t *hostArtistic,
+                            size_t artisticPitch) {
     if (!ctx) return RTDD_ERR_INVALID;
     if (!ctx->pyr) return fail(ctx, RTDD_ERR_STATE, "rtdd_pyramid_create has not been called");
     Pyramid *p = ctx->pyr;
-    REQUIRE(ctx, (hostScribble == nullptr) == (hostEdited == nullptr), "scribble and edited images come together (or neither: the annotation is unchanged)");
+    REQUIRE(ctx, (hostScribble == nullptr) == (hostEdited == nullptr),
+        "scribble and edited images come together (or neither: the annotation is unchanged)");
     REQUIRE(ctx, !hostScribble || (scribblePitch >= (size_t)p->cols && editedPitch >= (size_t)p->cols * 3), "pitch smaller than a row");
     REQUIRE(ctx, hostDepthU8 && depthPitch >= (size_t)p->cols && maxIterations >= 0, "bad output buffer or iteration count");
     REQUIRE(ctx, effect >= RTDD_EFFECT_NONE && effect <= RTDD_EFFECT_HAZE, "unknown effect");
-    REQUIRE(ctx, effect == RTDD_EFFECT_NONE || (hostArtistic && artisticPitch >= (size_t)p->cols * 3), "an effect needs a host image for its result");
+    REQUIRE(ctx, effect == RTDD_EFFECT_NONE || (hostArtistic && artisticPitch >= (size_t)p->cols * 3),
+        "an effect needs a host image for its result");
     REQUIRE(ctx, p->images == 1, "live frames run on a single-image pyramid (rtdd_pyramid_create)");
     DeviceGuard g(ctx->device);
     int rc = live_create(ctx);
     if (rc != RTDD_OK) return rc;
     Live *v = p->live;
-    if (v->submitted - v->waited >= 2 && (rc = rtdd_live_wait(ctx)) != RTDD_OK) return rc;   // two frames in flight at most: the slot is free again
+    // two frames in flight at most: the slot is free again
+    if (v->submitted - v->waited >= 2 && (rc = rtdd_live_wait(ctx)) != RTDD_OK) return rc;
     const int k = (int)(v->submitted % 2);
     const bool lone = v->submitted == v->waited;          // no other frame in flight: nothing for a copy to overlap
     if (effect != RTDD_EFFECT_NONE && !v->art_stage[0].ptr) {          // the first frame with an effect: its two staging images
         for (int j = 0; j < 2; j++)
             if ((rc = alloc_image(ctx, v->art_stage[j], p->rows, p->cols, 3, 0)) != RTDD_OK) return rc;
-        if (v->art_stage[0].pitch != p->artistic.pitch) return fail(ctx, RTDD_ERR_STATE, "live staging images and pyramid images differ in pitch");
+        if (v->art_stage[0].pitch != p->artistic.pitch) return fail(ctx, RTDD_ERR_STATE,
+            "live staging images and pyramid images differ in pitch");
         v->own_artistic = p->artistic.ptr;
     }
     if (hostScribble) {
@@ -552,7 +593,8 @@ int rtdd_live_submit_ex(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scrib
             {hostEdited, editedPitch, (size_t)p->cols * 3, &v->edited_stage[u], &v->bounce_up[k][1], false}};
         for (auto &q : ups) {
             q.bounce = wants_bounce(q.hp, q.width, p->rows);
-            if (!q.bounce) { RTDD_HIP(ctx, hipMemcpy2DAsync(q.dst->ptr, q.dst->pitch, q.host, q.hp, q.width, p->rows, hipMemcpyHostToDevice, us)); continue; }
+            if (!q.bounce) { RTDD_HIP(ctx,
+                hipMemcpy2DAsync(q.dst->ptr, q.dst->pitch, q.host, q.hp, q.width, p->rows, hipMemcpyHostToDevice, us)); continue; }
             if ((rc = bounce_reserve(ctx, *q.b, q.width * (size_t)p->rows, ctx->stream)) != RTDD_OK) return rc;
             RTDD_HIP(ctx, hipMemcpyAsync(q.b->ptr, q.host, q.width * (size_t)p->rows, hipMemcpyHostToDevice, us));
         }
@@ -561,7 +603,8 @@ int rtdd_live_submit_ex(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scrib
             RTDD_HIP(ctx, hipStreamWaitEvent(ctx->stream, v->h2d_done[k], 0));
         }
         for (auto &q : ups)
-            if (q.bounce && (rc = launch_repitch(ctx, ctx->stream, q.b->ptr, q.width, q.dst->ptr, q.dst->pitch, q.width, p->rows)) != RTDD_OK) return rc;
+            if (q.bounce && (rc = launch_repitch(ctx, ctx->stream, q.b->ptr, q.width, q.dst->ptr, q.dst->pitch, q.width,
+                p->rows)) != RTDD_OK) return rc;
         // the pyramid's level-0 annotation IS the uploaded pair: no copy
         p->scribble[0].ptr = v->scribble_stage[u].ptr; p->edited[0].ptr = v->edited_stage[u].ptr;
         p->annotation_dirty = true;
@@ -586,13 +629,15 @@ int rtdd_live_submit_ex(rtdd_ctx *ctx, const uint8_t *hostScribble, size_t scrib
     lt.effect = effect;
     if (effect != RTDD_EFFECT_NONE) {
         lt.artistic = (uint8_t *)v->art_stage[k].ptr; lt.artistic_pitch = v->art_stage[k].pitch;
-        p->artistic.ptr = v->art_stage[k].ptr;          // RTDD_IMG_ARTISTIC names the newest frame's image (like the annotation pair: no copy)
+        // RTDD_IMG_ARTISTIC names the newest frame's image (like the annotation pair: no copy)
+        p->artistic.ptr = v->art_stage[k].ptr;
     }
     rc = estimate_submit(ctx, maxIterations, &op_id, /*whole_batch=*/false, lt);
     if (rc != RTDD_OK) return rc;
     const bool art_queued = effect != RTDD_EFFECT_NONE && lone;
     if (art_queued) {
-        rc = copy_d2h(ctx, v->bounce_art, hostArtistic, artisticPitch, v->art_stage[k].ptr, v->art_stage[k].pitch, (size_t)p->cols * 3, p->rows, ctx->stream);
+        rc = copy_d2h(ctx, v->bounce_art, hostArtistic, artisticPitch, v->art_stage[k].ptr, v->art_stage[k].pitch, (size_t)p->cols * 3,
+            p->rows, ctx->stream);
         if (rc != RTDD_OK) return rc;
     }
     if (direct) {
@@ -634,17 +679,23 @@ int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level
         t.defer_finish = solved && l > 0;
         if (l == 0) {
             t.u8 = (uint8_t *)p->depth_u8.at(first); t.u8_pitch = p->depth_u8.pitch;
-            t.u8b = live.u8; t.u8b_pitch = live.u8_pitch ? live.u8_pitch : p->depth_u8.pitch;     // (a live frame: its staging slot, or the host's buffer, too)
+            // (a live frame: its staging slot, or the host's buffer, too)
+            t.u8b = live.u8; t.u8b_pitch = live.u8_pitch ? live.u8_pitch : p->depth_u8.pitch;
         }
         // the level of images first .. first + n - 1 in the same launches (blockIdx.z = image: Batch, rtdd_internal.hpp)
         t.batch.n = n; t.batch.first = first;
-        t.batch.depth = p->depth[l].stride; t.batch.scribble = p->scribble[l].stride; t.batch.gray = p->gray[l].stride; t.batch.u8 = p->depth_u8.stride;
+        t.batch.depth = p->depth[l].stride; t.batch.scribble = p->scribble[l].stride; t.batch.gray = p->gray[l].stride;
+        t.batch.u8 = p->depth_u8.stride;
         SolveOutcome done;
         if (solved) {
-            rtdd_solve_params sp;                   // GPUMatrixFreeSolver(..., beta, CUDAIteration, CUDAThreshold, level): exactly `iters` sweeps (:266-268)
-            sp.method = RTDD_METHOD_CHEBYSHEV_JACOBI; sp.maxIterations = iters; sp.tolerance = 0.0f; sp.checkEvery = 0; sp.relaxation = 0.0f;
-            rc = solve_with(ctx, (float *)p->depth[l].at(first), p->depth[l].pitch, (const uint8_t *)p->scribble[l].at(first), p->scribble[l].pitch,
-                            (const uint8_t *)p->gray[l].at(first), p->gray[l].pitch, p->depth[l].rows, p->depth[l].cols, l, &sp, nullptr, t, &done);
+            // GPUMatrixFreeSolver(..., beta, CUDAIteration, CUDAThreshold, level): exactly `iters` sweeps (:266-268)
+            rtdd_solve_params sp;
+            sp.method = RTDD_METHOD_CHEBYSHEV_JACOBI; sp.maxIterations = iters; sp.tolerance = 0.0f; sp.checkEvery = 0;
+            sp.relaxation = 0.0f;
+            rc = solve_with(ctx, (float *)p->depth[l].at(first), p->depth[l].pitch, (const uint8_t *)p->scribble[l].at(first),
+                p->scribble[l].pitch,
+                            (const uint8_t *)p->gray[l].at(first), p->gray[l].pitch, p->depth[l].rows, p->depth[l].cols, l, &sp, nullptr, t,
+                                &done);
             if (level_seq && l < 32) level_seq[l] = done.seq;
             if (rc == RTDD_OK) {
                 p->level_info[l] = ctx->last_info; p->level_launch_images[l] = ctx->last_launch_images;
@@ -664,7 +715,8 @@ int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level
                 src = Lv.P(done.plane, ip); sp = ip * sizeof(float); pb.src = Lv.elems * sizeof(float);
                 coarse_out = (float *)p->depth[l].at(first);
             }
-            // guarded like k_finish (with the solve's sequence number): when level l's sweeps gave up it stores nothing, depth[l] keeps level
+            // guarded like k_finish (with the solve's sequence number): when level l's sweeps gave up it stores nothing, depth[l] keeps
+            // level
             // l's input and the level can be run again
             rc = launch_pyrup_inject(ctx, src, sp, p->depth[l].rows, p->depth[l].cols,
                                      (float *)p->depth[l - 1].at(first), p->depth[l - 1].pitch, p->depth[l - 1].rows, p->depth[l - 1].cols,
@@ -676,7 +728,8 @@ int estimate_levels(rtdd_ctx *ctx, int maxIterations, int from_level, int *level
     if (rc != RTDD_OK) return rc;
     if (p->depth[0].rows > 0 && p->depth[0].cols > 0) return RTDD_OK;         // the u8 map left the solver's copy-back (above)
     DeviceGuard g(ctx->device);
-    for (int b = first; b < first + n && rc == RTDD_OK; b++)                    // (an image too small for a finest level: nothing above ran either)
+    // (an image too small for a finest level: nothing above ran either)
+    for (int b = first; b < first + n && rc == RTDD_OK; b++)
         rc = launch_depth_to_u8(ctx, (const float *)p->depth[0].at(b), p->depth[0].pitch, (uint8_t *)p->depth_u8.at(b), p->depth_u8.pitch,
                                 p->rows, p->cols);   // :290
     return rc;
@@ -692,12 +745,15 @@ int live_effect(rtdd_ctx *ctx, const LiveTargets &live) {
     const uint8_t *orig = (const uint8_t *)p->original.ptr; const float *depth = (const float *)p->depth[0].ptr;
     switch (live.effect) {
         case RTDD_EFFECT_DEFOCUS:
-            return launch_defocus(ctx, orig, p->original.pitch, depth, p->depth[0].pitch, live.artistic, live.artistic_pitch, p->rows, p->cols);
+            return launch_defocus(ctx, orig, p->original.pitch, depth, p->depth[0].pitch, live.artistic, live.artistic_pitch, p->rows,
+                p->cols);
         case RTDD_EFFECT_DESATURATION:
-            return launch_desaturate(ctx, orig, p->original.pitch, (const uint8_t *)p->gray[0].ptr, p->gray[0].pitch, depth, p->depth[0].pitch,
+            return launch_desaturate(ctx, orig, p->original.pitch, (const uint8_t *)p->gray[0].ptr, p->gray[0].pitch, depth,
+                p->depth[0].pitch,
                                      live.artistic, live.artistic_pitch, p->rows, p->cols);
         case RTDD_EFFECT_HAZE:
-            return launch_haze(ctx, orig, p->original.pitch, depth, p->depth[0].pitch, live.artistic, live.artistic_pitch, p->rows, p->cols);
+            return launch_haze(ctx, orig, p->original.pitch, depth, p->depth[0].pitch, live.artistic, live.artistic_pitch, p->rows,
+                p->cols);
         default: return RTDD_OK;
     }
 }
@@ -750,9 +806,11 @@ int rtdd_pyrdown_gray(rtdd_ctx *ctx, const uint8_t *src, size_t srcPitch, int ro
     return launch_pyrdown_u8(ctx, src, srcPitch, rows, cols, dst, dstPitch);
 }
 
-int rtdd_pyrup_depth(rtdd_ctx *ctx, const float *src, size_t srcPitch, int rows, int cols, float *dst, size_t dstPitch, int dstRows, int dstCols) {
+int rtdd_pyrup_depth(rtdd_ctx *ctx, const float *src, size_t srcPitch, int rows, int cols, float *dst, size_t dstPitch, int dstRows,
+    int dstCols) {
     if (!ctx) return RTDD_ERR_INVALID;
-    REQUIRE(ctx, src && dst && rows > 0 && cols > 0 && dstRows > 0 && dstCols > 0 && srcPitch >= (size_t)cols * 4 && dstPitch >= (size_t)dstCols * 4, "bad argument");
+    REQUIRE(ctx, src && dst && rows > 0 && cols > 0 && dstRows > 0 && dstCols > 0 && srcPitch >= (size_t)cols * 4
+        && dstPitch >= (size_t)dstCols * 4, "bad argument");
     DeviceGuard g(ctx->device);
     // (as rtdd_index_to_weight: `src` may be the output of a logged solve whose persistent launch gave up -- the spelt-out cascade,
     // solve -> pyrUp -> inject -> solve, queued asynchronously)
@@ -776,7 +834,8 @@ int rtdd_upload(rtdd_ctx *ctx, void *dev, size_t devPitch, const void *host, siz
     // the destination may be an input of a logged call that still has to be run again: settle first (this call synchronises anyway)
     { const int rc_ = settle_pending(ctx); if (rc_ != RTDD_OK) return rc_; }
     { const int rc_ = pyramid_note_write(ctx, dev, dev); if (rc_ != RTDD_OK) return rc_; }
-    { const int rc_ = copy_h2d(ctx, ctx->bounce, dev, devPitch, host, hostPitch, widthBytes, rows, ctx->stream); if (rc_ != RTDD_OK) return rc_; }
+    { const int rc_ = copy_h2d(ctx, ctx->bounce, dev, devPitch, host, hostPitch, widthBytes, rows,
+        ctx->stream); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTDD_OK;
 }
@@ -785,12 +844,15 @@ int rtdd_download(rtdd_ctx *ctx, void *host, size_t hostPitch, const void *dev, 
     if (!ctx) return RTDD_ERR_INVALID;
     REQUIRE(ctx, dev && host && rows >= 0 && devPitch >= widthBytes && hostPitch >= widthBytes, "bad argument");
     DeviceGuard g(ctx->device);
-    { const int rc_ = copy_d2h(ctx, ctx->bounce, host, hostPitch, dev, devPitch, widthBytes, rows, ctx->stream); if (rc_ != RTDD_OK) return rc_; }
+    { const int rc_ = copy_d2h(ctx, ctx->bounce, host, hostPitch, dev, devPitch, widthBytes, rows,
+        ctx->stream); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int heals = ctx->heals;
     const int rc = check_persistent_status(ctx);  // what was just downloaded may come from a persistent launch that gave up ...
     if (rc != RTDD_OK || ctx->heals == heals) return rc;
-    { const int rc_ = copy_d2h(ctx, ctx->bounce, host, hostPitch, dev, devPitch, widthBytes, rows, ctx->stream); if (rc_ != RTDD_OK) return rc_; }   // ... and has been run again since
+    // ... and has been run again since
+    { const int rc_ = copy_d2h(ctx, ctx->bounce, host, hostPitch, dev, devPitch, widthBytes, rows,
+        ctx->stream); if (rc_ != RTDD_OK) return rc_; }
     RTDD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTDD_OK;
 }

@@ -19,10 +19,6 @@ rtdd_ctx *ctx(const char *who) {
         if (rc != RTDD_OK) {
             std::printf("%s: %s\n", who, rtdd_status_string(rc));     // the reference's error style, src/GPUSolver.cu:25
             g_ctx = nullptr;
-        } else {
-            // the reference's solver returns synchronised at every pyramid level (src/GPUSolver.cu:314) and an unchanged main.cpp can set no
-            // option: its waits poll the stream for up to 5 ms before they block (include/rtdd.h RTDD_OPT_SYNC_SPIN_US; bench.py dropin_frame)
-            (void)rtdd_set_option(g_ctx, RTDD_OPT_SYNC_SPIN_US, 5000);
         }
     }
     return g_ctx;

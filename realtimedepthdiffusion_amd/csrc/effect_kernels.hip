@@ -384,15 +384,27 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ orig, size_t op, const float *__restrict__ depth, size_t dp,
                                                   const u64 *__restrict__ Tpad, int tpitch, uint8_t *__restrict__ art, size_t ap,
                                                   int rows, int cols, int kernelSize, int gx, int ntiles, int xcd_tiles,
-                                                  int row0, int row1, int trow0, int trows, int *__restrict__ nonlocal_word) {
+                                                  int row0, int row1, int trow0, int trows, int *__restrict__ nonlocal_word, int strip_w) {
     // Round 6, BANDED tables (launch_defocus): this launch writes output rows [row0, row1) and the table holds image rows
     // [trow0, trow0 + trows) with its origin at row trow0 -- rectangle sums are differences, so any origin above the window serves.  The
     // whole image in one launch: row0 = trow0 = 0, row1 = trows = rows.
+    // Which tile: workgroup p is dispatched to XCD p % 8.  strip_w == 0: each XCD takes a contiguous band of tile ROWS.  strip_w > 0
+    // (round 6, wide images): each XCD takes a COLUMN strip strip_w tiles wide and walks it row by row -- a table line read as a window's
+    // bottom edge is read again as a top edge 2 h rows later, and only a strip's 2 h rows (8K: 220 x 960 px x 8 B = 1.7 MB), not the
+    // whole image width's (13.5 MB), fit the XCD's 4 MB L2 in between.
     const int p = blockIdx.x;
-    const int tile = xcd_tiles > 0 ? (p & 7) * xcd_tiles + (p >> 3) : p;
-    if (tile >= ntiles) return;
+    int tx, ty;
+    if (strip_w > 0) {
+        const int q = p >> 3;
+        tx = (p & 7) * strip_w + q % strip_w; ty = q / strip_w;
+        if (tx >= gx || ty * gx >= ntiles) return;
+    } else {
+        const int tile = xcd_tiles > 0 ? (p & 7) * xcd_tiles + (p >> 3) : p;
+        if (tile >= ntiles) return;
+        tx = tile % gx; ty = tile / gx;
+    }
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int x0 = (tile % gx) * 64, yw = row0 + (tile / gx) * (4 * kLk2Rows) + wv * kLk2Rows;
+    const int x0 = tx * 64, yw = row0 + ty * (4 * kLk2Rows) + wv * kLk2Rows;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Tpad, 0, (int)((uint32_t)(trows + 1) * (uint32_t)tpitch * 8u), 0x00020000);
     const uint32_t pitch8 = (uint32_t)tpitch * 8u;
     const bool whole = VEC && x0 + 64 <= cols;                      // wave-uniform: the output as dwords
@@ -783,13 +795,19 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
     const int tp = (cols + 3) / 4 * 4;                                  // entries the build writes per row: 32-byte aligned groups of four
     // the table is padded -- one zero row above, four zero entries left of every row (k_defocus): T'[r + 1][c + 4] = T(r, c)
     const int tpitch = tp + 4;
-    // Round 6, BANDED tables.  A whole-image table is 8 bytes per pixel: 66 MB at 4K, 265 MB at 8K -- more than the 256 MiB Infinity
+    // Round 6, BANDED tables (RTDD_OPT_DEFOCUS_SLICE_MB > 0; OFF by default: measured, it does not pay -- see the end of this comment).  A whole-image table is 8 bytes per pixel: 66 MB at 4K, 265 MB at 8K -- more than the 256 MiB Infinity
     // Cache, so every corner of an 8K lookup was a gather from HBM (729 us smooth, 2.9 ms with a random depth per pixel).  Rectangle sums
     // are differences, so a table with its origin at any row above the window serves: the image is cut into horizontal slices of output
     // rows, each slice builds the table of ITS rows plus the tallest nominal window's reach (kernelSize / 2 rows above and below: a
     // depth map is <= 255) -- into the same buffer, which therefore stays in the Infinity Cache -- and looks its pixels up in it.  A
     // window that reaches further (a depth above 255) is summed from the image by its wave and reported (k_defocus); the context then
     // goes back to one whole-image table (defocus_band_sticky).  Same integer sums, same quotients: bit-identical.
+    // MEASURED (profiles/r06_defocus_slices.txt, one call): 8K smooth 725 us as one table, 762 in 5 slices of 64 MB, 955 in 14 of 32 MB;
+    // with a real depth map 520 / 634 / 785; random depth 2905 / 2976 / 3064.  What made 8K 9 x 4K's time for 4 x the pixels was not the
+    // table leaving the Infinity Cache but its LINES leaving the XCD's L2 between a window's bottom- and top-edge reads (2 h rows x the
+    // whole image width = 13.5 MB at 8K): the lookup's column strips per XCD (k_defocus strip_w, below) are what pays -- 8K 727 -> 620 us
+    // smooth, 522 -> 399 with a real depth map, 2888 -> 1342 random.  The slices stay as an option: they are what lets an image whose
+    // whole table would pass 4 GiB (rows x cols > 2^29) be processed at all.
     const int reach = kernelSize / 2;
     const size_t slice_budget = (size_t)ctx->opt.defocus_slice_mb << 20;          // RTDD_OPT_DEFOCUS_SLICE_MB (default 64; 0: never band)
     const size_t row_bytes = (size_t)tpitch * sizeof(u64);
@@ -846,10 +864,14 @@ int launch_defocus(rtdd_ctx *ctx, const uint8_t *orig, size_t op, const float *d
         RTDD_LAUNCH_CHECK(ctx, "k_sat_build");
         const int gx2 = (cols + 63) / 64, gy2 = (row1 - row0 + 4 * kLk2Rows - 1) / (4 * kLk2Rows), nt2 = gx2 * gy2;
         const int xt2 = nt2 >= 64 ? (nt2 + 7) / 8 : 0;
-        const dim3 g5(xt2 > 0 ? 8 * xt2 : nt2);
+        // column strips per XCD where the rows between a window's bottom and top edge, over the whole image width, outgrow an XCD's L2
+        // (RTDD_OPT_DEFOCUS_STRIPS: 0 this rule, 1 never, 2 always; measured in profiles/r06_defocus_strips.txt)
+        const bool strips = ctx->opt.defocus_strips == 2 || (ctx->opt.defocus_strips == 0 && (size_t)2 * reach * row_bytes > ((size_t)3 << 20) && gx2 >= 16);
+        const int strip_w = strips ? (gx2 + 7) / 8 : 0;
+        const dim3 g5(strip_w > 0 ? 8 * strip_w * gy2 : xt2 > 0 ? 8 * xt2 : nt2);
         int *nlw = nslices > 1 ? ctx->sync_words + kSyncNonLocal : nullptr;
-        if (vout) hipLaunchKernelGGL(k_defocus<true>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2, row0, row1, trow0, trows, nlw);
-        else hipLaunchKernelGGL(k_defocus<false>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2, row0, row1, trow0, trows, nlw);
+        if (vout) hipLaunchKernelGGL(k_defocus<true>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2, row0, row1, trow0, trows, nlw, strip_w);
+        else hipLaunchKernelGGL(k_defocus<false>, g5, dim3(256), 0, ctx->stream, orig, op, depth, dp, Tpad, tpitch, art, ap, rows, cols, kernelSize, gx2, nt2, xt2, row0, row1, trow0, trows, nlw, strip_w);
     }
     if (nslices > 1) note_status_writer(ctx);                           // (kSyncNonLocal: a window beyond a slice -> the whole-image table from the next synchronisation on)
     RTDD_LAUNCH_CHECK(ctx, "k_defocus");

@@ -32,10 +32,10 @@ constexpr int kSyncWords = kSyncFlags + kSyncMaxTiles * kSyncFlagStride;        
 constexpr unsigned long long kDefaultPollLimit = 20000000ull;      // 200 ms: legitimate waits are microseconds
 // Round 6: the FIRST thing a persistent workgroup does is announce itself (its flag := the launch's base value) and wait for its
 // neighbours' announcements -- while its tile loads are in flight -- with THIS bound: on a GPU shared with other work a launch whose
-// workgroups are not all resident is found out here, before any sweep, in a millisecond instead of 200 (profiles/r05_shared_gpu.txt: a
+// workgroups are not all resident is found out here, before any sweep, in 1.5 ms instead of 200 (profiles/r05_shared_gpu.txt: a
 // 200 ms stall per time-out in a 1 ms frame loop).  A resident launch's workgroups all start within tens of microseconds.  The
 // exchanges behind the first keep the long bound: once every workgroup has been seen running, a long wait is no scheduling accident.
-constexpr unsigned long long kArrivalPollLimit = 100000ull;        // 1 ms
+constexpr unsigned long long kArrivalPollLimit = 150000ull;        // 1.5 ms
 
 #ifdef __HIPCC__
 // The kernels that publish a solve's result into the caller's buffers call this first (every thread; `first` = one thread of the

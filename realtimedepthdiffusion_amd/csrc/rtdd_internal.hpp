@@ -101,8 +101,8 @@ struct Options {
     int timeout_heal = 1;            // RTDD_OPT_TIMEOUT_HEAL: 1 a timed-out persistent launch is healed (calls logged, run again); 0 it is reported
     int annotation_lds = 1;          // RTDD_OPT_ANNOTATION_LDS: the annotation pyramid's chain of levels in LDS (pyramids of up to 6 levels); 0: through global memory
     int live_zero_copy = 1;          // RTDD_OPT_LIVE_ZERO_COPY: a live frame's u8 map is stored by the copy-back kernel straight into the host's page-locked buffer (0 never, 1 when no other frame is in flight, 2 always)
-    int defocus_slice_mb = 64;       // RTDD_OPT_DEFOCUS_SLICE_MB: a summed-area table of more than twice this is built and looked up in slices of at most this size (0: never)
-    int sync_spin_us = 0;            // RTDD_OPT_SYNC_SPIN_US: rtdd_ctx_synchronize polls the stream (hipStreamQuery) for up to this long before it blocks
+    int defocus_slice_mb = 0;        // RTDD_OPT_DEFOCUS_SLICE_MB: > 0: a summed-area table of more than twice this is built and looked up in slices of at most this size
+    int defocus_strips = 0;          // RTDD_OPT_DEFOCUS_STRIPS: the table lookup's tile order -- 0 automatic, 1 row bands per XCD, 2 column strips per XCD
     int rearm_after = 64;            // RTDD_OPT_PERSISTENT_REARM_AFTER: solves without persistence after the first heal, doubling with every further one
 };
 

@@ -36,6 +36,13 @@
 #define RTDD_MASKED_UPDATE 1
 #endif
 
+// RTDD_OCC_G2 (A/B builds; default 4 = no change): waves per SIMD asked of the compiler for the 64 x 64 tile of 8 pixels per thread (tile 10):
+// 6 would put three of its workgroups on a CU (85 registers per thread) -- round 6's question whether more workgroups per CU hide the
+// tile loads at 4K better than the 64 x 96 tile's two (EXPERIMENTS.md)
+#ifndef RTDD_OCC_G2
+#define RTDD_OCC_G2 4
+#endif
+
 namespace rtdd {
 
 
@@ -68,7 +75,7 @@ __device__ __forceinline__ float relax(float xl, float xr, float xu, float xd, f
 // sweep loop (measured 25 % slower), so G = 4 tiles ask for 3 waves/SIMD (168 VGPRs) unless the
 // workgroup is 1024 threads (which needs 4 waves/SIMD to be launchable at all).  G <= 3 fits 128.
 template <int LX, int NT, int G, bool CONTRACT, bool PERSIST>
-__global__ __launch_bounds__(NT, (NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) void k_sweep_blocked(float *Xk, float *Xm, float *Yk, float *Ym,
+__global__ __launch_bounds__(NT, (G == 2 && NT == 512 ? RTDD_OCC_G2 : NT >= 1024 || G <= 3 ? 4 : G <= 4 ? 3 : 2)) void k_sweep_blocked(float *Xk, float *Xm, float *Yk, float *Ym,
                                                       const uint32_t *__restrict__ M, const float *__restrict__ lut_g,
                                                       const float *__restrict__ omegas, int ip, int rows, int cols,
                                                       int hx, int hy, int nsweeps, float gamma,

@@ -31,6 +31,13 @@ __device__ __forceinline__ float lds_from_next(int prev4, float v) { return __in
 __device__ __forceinline__ void store_sc1(float4 *p, float4 v) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     const f4v t = {v.x, v.y, v.z, v.w};
+#ifdef RTDD_TIMING_PLAIN_STRIPS
+    // TIMING-ONLY diagnostic build (scripts/build_variant.sh; never the product: cross-XCD neighbours read stale strips): what the exchange
+    // would cost if EVERY strip could be stored plain -- kept in the storing XCD's L2 -- i.e. the upper bound of storing same-XCD strips
+    // without write-through (EXPERIMENTS.md round 6)
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+    return;
+#endif
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 
@@ -81,29 +88,37 @@ __device__ __forceinline__ float rcp_rn(float d) {
 // the select of `(dirichlet ? x : v)` -- a v_cndmask_b32 with an SGPR-pair mask, half rate on gfx950 (4.4 cycles per wave-instruction
 // against 3.1 for v_fmac_f32 with three VGPRs and 4.3 for any fma with an SGPR operand: scripts/ubench/excp_probe.hip,
 // profiles/r05_excp_probe.txt) -- becomes the EXEC mask of the fma itself: s_mov_b64 exec (scalar unit) + v_fmac_f32 (full rate), omega
-// in a VGPR.  ONE asm statement per row so that the compiler can schedule nothing between the EXEC writes; EXEC is all ones on entry
-// and on exit: every thread of the (whole-wave) workgroup runs the sweeps, all control flow around them is wave-uniform.  An SALU
-// write of EXEC needs no wait state in front of a (non-DPP) VALU instruction on gfx9.
+// in a VGPR.  ONE asm statement per row so that the compiler can schedule nothing between the EXEC writes.  Round 6: the
+// statement no longer ASSUMES that EXEC is all ones on entry (true today: every thread of the whole-wave workgroup runs the sweeps and
+// all control flow around them is wave-uniform -- but a compiler that sank the statement into a divergent region would have had its
+// inactive lanes switched on by the old closing `s_mov_b64 exec, -1`): the first mask is applied by s_and_saveexec_b64, which also SAVES
+// the entry EXEC; the other masks are `entry & mask`; the last instruction puts the entry EXEC back.  Same five scalar instructions per
+// row as before, one SGPR pair more for the duration of the statement.  An SALU write of EXEC needs no wait state in front of a
+// (non-DPP) VALU instruction on gfx9.
 __device__ __forceinline__ void masked_fmac4(float &o0, float &o1, float &o2, float &o3, float w, float t0, float t1, float t2, float t3,
                                              unsigned long long m0, unsigned long long m1, unsigned long long m2, unsigned long long m3) {
-    asm("s_mov_b64 exec, %9\n\tv_fmac_f32_e32 %0, %4, %5\n\t"
-        "s_mov_b64 exec, %10\n\tv_fmac_f32_e32 %1, %4, %6\n\t"
-        "s_mov_b64 exec, %11\n\tv_fmac_f32_e32 %2, %4, %7\n\t"
-        "s_mov_b64 exec, %12\n\tv_fmac_f32_e32 %3, %4, %8\n\t"
-        "s_mov_b64 exec, -1"
-        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
-        : "v"(w), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+    unsigned long long entry;                // EXEC as it was on entry: saved by the instruction that applies the first mask, put back by the last
+    asm("s_and_saveexec_b64 %[e], %[m0]\n\tv_fmac_f32_e32 %[o0], %[w], %[t0]\n\t"
+        "s_and_b64 exec, %[e], %[m1]\n\tv_fmac_f32_e32 %[o1], %[w], %[t1]\n\t"
+        "s_and_b64 exec, %[e], %[m2]\n\tv_fmac_f32_e32 %[o2], %[w], %[t2]\n\t"
+        "s_and_b64 exec, %[e], %[m3]\n\tv_fmac_f32_e32 %[o3], %[w], %[t3]\n\t"
+        "s_mov_b64 exec, %[e]"
+        : [o0] "+v"(o0), [o1] "+v"(o1), [o2] "+v"(o2), [o3] "+v"(o3), [e] "=&s"(entry)
+        : [w] "v"(w), [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [t3] "v"(t3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3)
+        : "scc");
 }
 // the same for the un-contracted update, (omega * t) + x_{k-1}: the product is formed outside, the addition is masked
 __device__ __forceinline__ void masked_add4(float &o0, float &o1, float &o2, float &o3, float p0, float p1, float p2, float p3,
                                             unsigned long long m0, unsigned long long m1, unsigned long long m2, unsigned long long m3) {
-    asm("s_mov_b64 exec, %8\n\tv_add_f32_e32 %0, %4, %0\n\t"
-        "s_mov_b64 exec, %9\n\tv_add_f32_e32 %1, %5, %1\n\t"
-        "s_mov_b64 exec, %10\n\tv_add_f32_e32 %2, %6, %2\n\t"
-        "s_mov_b64 exec, %11\n\tv_add_f32_e32 %3, %7, %3\n\t"
-        "s_mov_b64 exec, -1"
-        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
-        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+    unsigned long long entry;
+    asm("s_and_saveexec_b64 %[e], %[m0]\n\tv_add_f32_e32 %[o0], %[p0], %[o0]\n\t"
+        "s_and_b64 exec, %[e], %[m1]\n\tv_add_f32_e32 %[o1], %[p1], %[o1]\n\t"
+        "s_and_b64 exec, %[e], %[m2]\n\tv_add_f32_e32 %[o2], %[p2], %[o2]\n\t"
+        "s_and_b64 exec, %[e], %[m3]\n\tv_add_f32_e32 %[o3], %[p3], %[o3]\n\t"
+        "s_mov_b64 exec, %[e]"
+        : [o0] "+v"(o0), [o1] "+v"(o1), [o2] "+v"(o2), [o3] "+v"(o3), [e] "=&s"(entry)
+        : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3)
+        : "scc");
 }
 
 }  // namespace rtdd

@@ -90,6 +90,27 @@ for i in range(k_live):
     if i % 500 == 499: print(i + 1, "live pairs ok, %.1f s" % (time.time() - t), flush=True)
 assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 0, "a persistent launch timed out (and was healed)"
 print("soak ok:", k_live, "pairs of pipelined live frames, every map == the oracle cascade's", u8_1[:12], u8_2[:12])
+# ---- (round 6) the same pairs with a sticky effect (rtdd_live_submit_ex): the artistic image of either frame == the oracle's effect on the
+# oracle's first / second estimate
+cas2 = Cascade(oracle, bgr, ann, lut, 1, threads=oracle.max_threads()); cas2.estimate(1000)
+a1 = hashlib.sha1(oracle.defocus(bgr, cas2.depth[0], threads=oracle.max_threads()).tobytes()).hexdigest()
+cas2.estimate(1000)
+a2 = hashlib.sha1(oracle.defocus(bgr, cas2.depth[0], threads=oracle.max_threads()).tobytes()).hexdigest()
+arts = [rt.host_image((rows, cols, 3)) for _ in range(2)]
+k_fx = max(k_live // 4, 1)
+t = time.time()
+for i in range(k_fx):
+    c.pyramid_set_image(img); c.pyramid_set_annotation(an)
+    if i % 3 == 0:
+        with torch.cuda.stream(side):
+            noise.mul_(1.0001)
+    c.live_submit_ex(scr.a, ed.a, outs[0].a, rt.EFFECT_DEFOCUS, arts[0].a, 1000); c.live_submit_ex(scr.a, ed.a, outs[1].a, rt.EFFECT_DEFOCUS, arts[1].a, 1000)
+    c.live_wait(); h1 = (hashlib.sha1(outs[0].a.tobytes()).hexdigest(), hashlib.sha1(arts[0].a.tobytes()).hexdigest())
+    c.live_wait(); h2 = (hashlib.sha1(outs[1].a.tobytes()).hexdigest(), hashlib.sha1(arts[1].a.tobytes()).hexdigest())
+    assert (h1, h2) == ((u8_1, a1), (u8_2, a2)), (i, "a live frame with an effect differs from the oracle")
+    if i % 200 == 199: print(i + 1, "live pairs with defocus ok, %.1f s" % (time.time() - t), flush=True)
+assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 0, "a persistent launch timed out (and was healed)"
+print("soak ok:", k_fx, "pairs of pipelined live frames with a sticky defocus, every map and every artistic image == the oracle's")
 c.close(); torch.cuda.synchronize()
 
 # ---- the healing path itself, many times over (round 4): a fresh context per round, a hand-off flag withheld at a random tile, three

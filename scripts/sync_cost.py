@@ -10,7 +10,7 @@ from realtimedepthdiffusion_amd.synth import make_problem
 
 rows, cols = 67, 120
 p = make_problem(rows, cols, seed=1)
-for stream_kind in ("null", "own"):
+for stream_kind, spin in (("null", 0), ("own", 0)):
     c = rt.Context(0)
     if stream_kind == "own":
         c.set_stream(torch.cuda.Stream().cuda_stream)

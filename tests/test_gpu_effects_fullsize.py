@@ -72,11 +72,12 @@ def test_desaturation_and_haze_4k(ctx, oracle):
 
 
 def test_defocus_banded_table_equals_the_whole_table(oracle):
-    """Round 6: beyond ~4K the summed-area table is built and looked up slice by slice (output rows + the tallest nominal window's reach,
-    each slice's table with an origin of its own) so that it stays in the Infinity Cache.  Forced here at 1440p with a 2 MB slice budget
-    (23 slices of 64 rows): a depth MAP (0..255) gives the whole-table result and the independent restatement's, bit for bit; depths
-    above 255 -- windows that reach beyond a slice -- are still answered exactly (summed from the image by their wave), and send the
-    context's later calls back to one whole-image table."""
+    """Round 6: RTDD_OPT_DEFOCUS_SLICE_MB > 0 builds and looks up the summed-area table slice by slice (output rows + the tallest nominal
+    window's reach, each slice's table with an origin of its own; off by default -- it does not pay at 8K -- but what lets an image beyond
+    2^29 pixels be processed at all).  Forced here at 1440p with a 2 MB budget (23 slices of 64 rows), with either tile order of the lookup
+    (RTDD_OPT_DEFOCUS_STRIPS: row bands / column strips per XCD): a depth MAP (0..255) gives the whole-table result and the independent
+    restatement's, bit for bit; depths above 255 -- windows that reach beyond a slice -- are still answered exactly (summed from the image
+    by their wave), and send the context's later calls back to one whole-image table."""
     rows, cols = 1440, 2560
     orig, depth = _inputs(rows, cols, 23)
     in_range = np.clip(depth, 0.0, 255.0)
@@ -91,13 +92,20 @@ def test_defocus_banded_table_equals_the_whole_table(oracle):
             c.synchronize()
             assert c.get_option(rt.OPT_DEFOCUS_LAST_PATH) == 1
             return down(art), c.get_option(rt.OPT_DEFOCUS_LAST_SLICES)
-        assert c.get_option(rt.OPT_DEFOCUS_SLICE_MB) == 64
+        assert c.get_option(rt.OPT_DEFOCUS_SLICE_MB) == 0 and c.get_option(rt.OPT_DEFOCUS_STRIPS) == 0
         whole, n = run(in_range, 0)
         assert n == 1
         assert np.array_equal(whole, defocus_by_summed_area_table(orig, in_range))
-        banded, n = run(in_range, 2)
-        assert n == 23, n
-        assert np.array_equal(banded, whole), f"{int((banded != whole).sum())} values differ between the banded and the whole-image table"
+        for strips in (1, 2):                                        # row bands per XCD, column strips per XCD: the same pixels in another order
+            c.set_option(rt.OPT_DEFOCUS_STRIPS, strips)
+            again, n = run(in_range, 0)
+            assert n == 1 and np.array_equal(again, whole), f"tile order {strips}"
+            banded, n = run(in_range, 2)
+            assert n == 23, n
+            assert np.array_equal(banded, whole), f"{int((banded != whole).sum())} values differ between the banded and the whole-image table (tile order {strips})"
+        c.set_option(rt.OPT_DEFOCUS_STRIPS, 0)
+        with pytest.raises(rt.RtddError):
+            c.set_option(rt.OPT_DEFOCUS_STRIPS, 3)
         banded, n = run(in_range, 2)                                 # a depth map never trips the fall-back
         assert n == 23
         # depths that are no depths (300: windows 1.18 x the nominal reach; negative: empty windows)
@@ -115,13 +123,22 @@ def test_defocus_banded_table_equals_the_whole_table(oracle):
         assert np.array_equal(again[ys, xs], oracle.defocus_at(orig, in_range, ys, xs))
 
 
-def test_defocus_8k_is_banded_by_default():
-    """The 8K table (265 MB as one) is built in slices of <= 64 MB by default; 4K (66 MB) is left whole."""
+def test_defocus_8k_odd_size_in_column_strips(oracle):
+    """From ~4K on the lookup walks the image in column strips per XCD (the default rule of RTDD_OPT_DEFOCUS_STRIPS: the 4K / 8K tests above
+    run it): here on a size whose tile grid is no multiple of the eight strips and whose last tile column is ragged, against the row-band
+    order and the independent restatement; one whole-image table by default (RTDD_OPT_DEFOCUS_LAST_SLICES == 1)."""
+    rows, cols = 2170, 3851
+    orig, depth = _inputs(rows, cols, 3)
     with rt.Context(0) as c:
         c.GPULoadWeights(0.4)
-        for rows, cols, slices in ((2160, 3840, 1), (4320, 7680, 5)):
-            orig = np.zeros((rows, cols, 3), np.uint8); depth = np.full((rows, cols), 128.0, np.float32)
+        o, d = up(orig), up(depth)
+        got = {}
+        for strips in (0, 1, 2):
+            c.set_option(rt.OPT_DEFOCUS_STRIPS, strips)
             art = up(np.zeros_like(orig))
-            c.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
-            c.synchronize()
-            assert c.get_option(rt.OPT_DEFOCUS_LAST_SLICES) == slices, (rows, c.get_option(rt.OPT_DEFOCUS_LAST_SLICES))
+            c.GPUSimulateDefocus(o, d, art, rows, cols); c.synchronize()
+            assert c.get_option(rt.OPT_DEFOCUS_LAST_PATH) == 1 and c.get_option(rt.OPT_DEFOCUS_LAST_SLICES) == 1
+            got[strips] = down(art)
+        want = defocus_by_summed_area_table(orig, depth)
+        for strips in (0, 1, 2):
+            assert np.array_equal(got[strips], want), f"tile order {strips}: {int((got[strips] != want).sum())} values differ"

@@ -299,15 +299,19 @@ def test_dropin_cxx_symbols_run(oracle, lut):
 
 
 def test_defocus_refuses_a_table_it_cannot_address():
-    """The global-table defocus addresses its padded table (8 bytes per pixel) with 32-bit byte offsets: an image whose table would reach
-    4 GiB (about 536 million pixels; rtdd_simulate_defocus's own size check admits rows x cols up to 2^30) is refused with
-    RTDD_ERR_INVALID before anything is allocated or launched -- not answered with wrapped offsets and zeros."""
+    """The whole-image defocus table (8 bytes per pixel) is addressed with 32-bit byte offsets: an image whose table would reach 4 GiB
+    (about 536 million pixels; rtdd_simulate_defocus's own size check admits rows x cols up to 2^30) is refused with RTDD_ERR_INVALID
+    before anything is allocated or launched -- not answered with wrapped offsets and zeros.  (Only with RTDD_OPT_DEFOCUS_SLICE_MB = 0:
+    by default such an image is built and looked up slice by slice, and every slice's table is small.  The pointers below are never
+    dereferenced BECAUSE the call is refused: nothing of this kind may be tried with the slices on.)"""
     import ctypes as C
     import torch
     rows = cols = 30000                               # rows^2 + cols^2 = 1.8e9 < 2^31: passes the effect's size check; table = 7.2 GB
     small = torch.zeros(1024, dtype=torch.uint8, device="cuda:0")
     with rt.Context(0) as c:
         c.GPULoadWeights(0.4)
+        c.set_option(rt.OPT_DEFOCUS_SLICE_MB, 0)
+        assert c.get_option(rt.OPT_DEFOCUS_SLICE_MB) == 0
         L = rt.lib()
         args = (C.c_void_p(small.data_ptr()), C.c_size_t(cols * 3), C.c_void_p(small.data_ptr()), C.c_size_t(cols * 4),
                 C.c_void_p(small.data_ptr() + 512), C.c_size_t(cols * 3), C.c_int(rows), C.c_int(cols))

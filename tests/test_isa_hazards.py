@@ -156,10 +156,11 @@ def test_the_valu_operation_count_bench_py_prices_the_roofline_with_is_the_built
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="ROCm LLVM tools not present")
 def test_every_exec_mask_the_sweep_sets_is_undone_before_anything_else_runs(tmp_path):
-    """The update's last fma runs under an EXEC mask written by hand (sweep_common.hpp masked_fmac4: s_mov_b64 exec, <free-pixel mask>;
-    v_fmac_f32; ...; s_mov_b64 exec, -1).  In every k_sweep_blocked instantiation: between a hand-written `s_mov_b64 exec, s[..]` and the
-    restoring `s_mov_b64 exec, -1` there is nothing but the masked v_fmac_f32 / v_add_f32 and further mask writes -- the compiler can
-    schedule nothing in between (one asm statement), and this is the check that it did not."""
+    """The update's last fma runs under an EXEC mask written by hand (sweep_common.hpp masked_fmac4: s_and_saveexec_b64 <entry>, <free-pixel
+    mask>; v_fmac_f32; s_and_b64 exec, <entry>, <mask>; v_fmac_f32; ...; s_mov_b64 exec, <entry>).  In every k_sweep_blocked instantiation:
+    a hand-written s_and_saveexec (the one whose next instruction is the masked operation) is followed by nothing but masked v_fmac_f32 /
+    v_add_f32 alternating with `s_and_b64 exec, <the same saved pair>, ..`, and closed by `s_mov_b64 exec, <the same saved pair>` -- the
+    entry EXEC is put back whatever it was (round 6: no longer forced to -1), and the compiler scheduled nothing in between."""
     asm = _disassembly(tmp_path)
     funcs = re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", asm)
     checked = 0
@@ -168,17 +169,28 @@ def test_every_exec_mask_the_sweep_sets_is_undone_before_anything_else_runs(tmp_
         if "k_sweep_blocked" not in head:
             continue
         instrs = [l.split("//")[0].strip() for l in f.split("\n")[1:] if re.match(r"\s+[a-z]", l)]
-        # (the compiler writes EXEC too -- s_mov_b64 exec, s[..] behind its own divergent regions, followed by a branch or by whatever comes
-        # next; a hand-written mask is the one whose next instruction is the masked operation)
         masked = ("v_fmac_f32_e32", "v_add_f32_e32")
-        open_mask = False
-        for i, ins in enumerate(instrs):
-            if re.match(r"s_mov_b64 exec, s\[\d+:\d+\]", ins) and (open_mask or (i + 1 < len(instrs) and instrs[i + 1].startswith(masked))):
-                open_mask = True; checked += 1
-                assert instrs[i + 1].startswith(masked), f"{head}: '{instrs[i + 1]}' follows a hand-written EXEC mask"
-            elif ins == "s_mov_b64 exec, -1":
-                open_mask = False
-            elif open_mask:
-                assert ins.startswith(masked) and re.match(r"s_mov_b64 exec, ", instrs[i + 1]), f"{head}: '{ins}' / '{instrs[i + 1]}' under a hand-written EXEC mask"
-        assert not open_mask, head
+        assert "s_mov_b64 exec, -1" not in instrs, f"{head}: EXEC forced to all ones"
+        i = 0
+        while i < len(instrs):
+            m = re.match(r"s_and_saveexec_b64 (s\[\d+:\d+\]), s\[\d+:\d+\]", instrs[i])
+            # (the compiler's own divergent regions open with s_and_saveexec too, followed by a branch or by whatever comes next; a
+            # hand-written one is followed by the masked operation)
+            if not (m and i + 1 < len(instrs) and instrs[i + 1].startswith(masked)):
+                i += 1
+                continue
+            saved = m.group(1)
+            j = i + 1
+            n_ops = 0
+            while True:
+                assert instrs[j].startswith(masked), f"{head}: '{instrs[j]}' under a hand-written EXEC mask"
+                n_ops += 1
+                nxt = instrs[j + 1]
+                if nxt == f"s_mov_b64 exec, {saved}":
+                    break
+                assert re.match(rf"s_and_b64 exec, {re.escape(saved)}, s\[\d+:\d+\]", nxt), f"{head}: '{nxt}' between masked updates (saved EXEC in {saved})"
+                j += 2
+            assert n_ops == 4, f"{head}: {n_ops} masked operations in one statement"
+            checked += n_ops
+            i = j + 2
     assert checked >= 12 * 26, f"only {checked} masked updates found"
