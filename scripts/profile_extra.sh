@@ -11,8 +11,10 @@ rm -rf /tmp/df && rocprofv3 --kernel-trace --stats -d /tmp/df -o df --output-for
 cd $R
 python3 scripts/prof_estimate_report.py $OUT $P/${RD}_estimate || exit 1
 python3 scripts/prof_live_report.py /tmp/lv > $P/${RD}_live_frame_timeline.txt || exit 1
+(cd /tmp && rm -rf /tmp/lvfx && rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/lvfx -o lv --output-format csv -- python3 $R/scripts/prof_live.py defocus > /dev/null 2>&1) || exit 1
+python3 scripts/prof_live_report.py /tmp/lvfx > $P/${RD}_live_frame_defocus_timeline.txt || exit 1
 find /tmp/df -name '*kernel_stats.csv' | head -1 | xargs -I{} sh -c "cut -c1-200 {} | head -12" > $P/${RD}_defocus_kernel_stats.csv
 python3 bench.py --gpus 1 --workload batch64_1080p --steps 2 --warmup 1 --no-cpu-baseline --verify > $P/${RD}_batch64_1080p_n1.json 2>/dev/null || exit 1
-python3 bench.py --gpus 1 --workload batch64_1080p_estimate --steps 3 --warmup 1 --no-cpu-baseline > $P/${RD}_batch64_1080p_estimate_n1.json 2>/dev/null || exit 1
+python3 bench.py --gpus 1 --workload batch64_1080p_estimate --steps 3 --warmup 1 --no-cpu-baseline --verify > $P/${RD}_batch64_1080p_estimate_n1.json 2>/dev/null || exit 1
 python3 bench.py > $P/${RD}_bench_default.json 2>/dev/null || exit 1
 tail -c 400 $P/${RD}_bench_default.json

@@ -509,6 +509,30 @@ def test_persistent_timeout_heals_itself(oracle, lut, capfd):
         assert_bit_equal(down(d3), oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 64, 0, 0, lut, 1, threads=oracle.max_threads()), "solve after a heal")
 
 
+def test_a_launch_that_is_not_resident_is_found_out_at_its_start(oracle, lut):
+    """Round 6: a persistent workgroup's first act is to announce itself and to see its eight neighbours announce themselves, with a bound
+    of 1.5 ms (persist_sync.hpp kArrivalPollLimit), before any sweep -- on a shared GPU a launch that is not fully resident costs that, not
+    the 200 ms an exchange may wait.  With a tile's flag withheld and NO debug poll limit set (the default bounds are in force): the solve's
+    launch, its heal and the replay without persistence together take a few milliseconds."""
+    import time
+    rows, cols = 1080, 1920
+    p = make_problem(rows, cols, seed=6)
+    m, g = up(p["mask"]), up(p["gray"])
+    with rt.Context(0) as c:
+        c.GPUAllocateDeviceMemory(rows, cols, 1); c.GPULoadWeights(0.4)
+        d = up(p["depth"])
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 8, 0.0, 0); c.synchronize()      # (first-call costs out of the way)
+        c.set_option(rt.OPT_DEBUG_WITHHOLD_TILE, 57 + 1)
+        d = up(p["depth"])
+        t0 = time.perf_counter()
+        c.GPUMatrixFreeSolver(d, m, g, rows, cols, 0.4, 200, 0.0, 0)
+        c.synchronize()
+        elapsed = time.perf_counter() - t0
+        assert c.get_option(rt.OPT_TIMEOUT_HEALS) == 1
+        assert elapsed < 0.05, f"{elapsed * 1e3:.1f} ms: the arrival bound is 1.5 ms, the replay of 200 sweeps ~0.5 ms (the old bound alone was 200 ms)"
+        assert_bit_equal(down(d), oracle.solve(p["depth"].copy(), p["mask"], p["gray"], 200, 0, 0, lut, 1, threads=oracle.max_threads()), "healed solve")
+
+
 def test_persistent_timeout_leaves_the_input_until_the_heal(oracle, lut):
     """Between the failed launch and the synchronising call the caller's buffer holds the solve's INPUT (k_finish stores nothing),
     which is what lets the solve run again; rtdd_download heals too and then copies again."""
