@@ -399,7 +399,11 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
         rcp[g] = rcp_rn(cnt[g]);
         unsafe |= cnt[g] < 0x1p-126f;
     }
+#ifdef RTDD_TIMING_ASSUME_SAFE
+    const bool wave_unsafe = false; (void)unsafe;      // (timing-only diagnostic build: sweep_tile_setup.inc)
+#else
     const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
+#endif
     constexpr uint32_t kTinyT = 2u * 0x0D800000u - 1u;
     const int up_w = wv > 0 ? wv - 1 : wv, dn_w = wv < nwv - 1 ? wv + 1 : wv;
     // (the first / last wave reads its own row instead of a missing neighbour: weighted 0 at the image border, discarded halo elsewhere)
