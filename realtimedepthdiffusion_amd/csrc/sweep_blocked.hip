@@ -404,7 +404,11 @@ __global__ __launch_bounds__(1024) void k_sweep_col(const float *__restrict__ Xk
 #else
     const bool wave_unsafe = __builtin_amdgcn_ballot_w64(unsafe) != 0;
 #endif
+#ifdef RTDD_TIMING_NO_TINY
+    constexpr uint32_t kTinyT = 0u;
+#else
     constexpr uint32_t kTinyT = 2u * 0x0D800000u - 1u;
+#endif
     const int up_w = wv > 0 ? wv - 1 : wv, dn_w = wv < nwv - 1 ? wv + 1 : wv;
     // (the first / last wave reads its own row instead of a missing neighbour: weighted 0 at the image border, discarded halo elsewhere)
     const int up_half = wv > 0 ? 1 : 0, dn_half = wv < nwv - 1 ? 0 : 1;        // which (value, tag) pair of the entry: 0 = top, 1 = bottom
