@@ -1,5 +1,5 @@
 # Three harness live loops (three processes, three dataset pairs) on ONE GPU at the same time: frames/s each, what each healed, and that a shared
-# run leaves the same map as a lone one.  usage: bash scripts/share_gpu.sh  (-> profiles/r05_shared_gpu.txt)
+# run leaves the same map as a lone one.  usage: bash scripts/share_gpu.sh  (-> profiles/r06_shared_gpu.txt; round 5: r05_shared_gpu.txt)
 make -s -C harness
 H=harness/rtdd_harness
 I=tests/golden/dataset
