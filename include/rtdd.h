@@ -125,7 +125,7 @@ enum rtdd_option {
                                        while the next frame computes, which is cheaper still); 2: always; 0: never */
     RTDD_OPT_DEFOCUS_STRIPS = 22,   /* the table path of rtdd_simulate_defocus, tile order of the lookup: 0 (default) automatic -- each XCD takes a COLUMN strip of the
                                        image where the table rows between a window's bottom and top edge, over the whole image width, outgrow an XCD's
-                                       L2 (from ~4K on: 8K 727 -> 620 us on a smooth depth map, 2.9 -> 1.3 ms with a random depth per pixel), row bands
+                                       L2 (from ~4K on: 8K 727 -> 620 us on a smooth depth map, 2.9 -> 1.3 ms with a random depth per pixel, before the corner reuse of the same round), row bands
                                        otherwise; 1 row bands always; 2 column strips always.  Same bits */
     RTDD_OPT_DEFOCUS_LAST_SLICES = 23, /* read only: the horizontal slices the most recent table-path rtdd_simulate_defocus built a table for (1: one
                                        whole-image table: the default) */

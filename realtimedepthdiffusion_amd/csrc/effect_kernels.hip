@@ -439,24 +439,43 @@ __global__ __launch_bounds__(256) void k_defocus(const uint8_t *__restrict__ ori
             const uint32_t c = cnt[i] ? cnt[i] : 1u;
             res = quot3_u8(sb, sg, sr, c, __builtin_amdgcn_rcpf((float)c));
         }
-        // windows of more than kSatMaxArea pixels (the packed fields would run into each other) and empty ones: under wave-uniform branches
+        // windows of more than kSatMaxArea pixels (the packed fields would run into each other) and empty ones: under wave-uniform branches.
+        // Such a window is cut into horizontal strips of <= kSatMaxArea pixels that share corner rows.  Round 6: its first and last corner
+        // rows are the four corners already in hand, so n strips cost 2 (n - 1) more loads, not 2 (n + 1) -- two instead of six for the
+        // two strips of a 4K window, ten instead of fourteen for the six of an 8K one; the lookup is bound by the table lines its load
+        // instructions pull through L1 (only the lanes WITH a large window issue them: walking the strips in lock step with loads two
+        // rows ahead, all lanes together, was built and is slower -- 8K random 1342 -> 2104 us -- see EXPERIMENTS.md).  The same strip
+        // sums in the same integer type: bit-identical.
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(cnt[i] > (uint32_t)kSatMaxArea) != 0, 0)) {
-            if (cnt[i] > (uint32_t)kSatMaxArea) {                   // strips of <= kSatMaxArea pixels that share corner rows (columns too, should a row be wider)
+            if (cnt[i] > (uint32_t)kSatMaxArea) {
                 uint32_t sb = 0, sg = 0, sr = 0;
                 const int wd = xb[i] - xa[i];
-                const int cw = min(wd, kSatMaxArea), rh = max(kSatMaxArea / cw, 1);
-                for (int xs = xa[i]; xs < xb[i]; xs += cw) {
-                    const int xe = min(xs + cw, xb[i]);
-                    const uint32_t cs = 8u * (uint32_t)xs + 24u, ce = 8u * (uint32_t)xe + 24u;
-                    const uint32_t r0 = (uint32_t)(ya[i] - trow0) * pitch8;
-                    u64 D0 = tab_load(rsrc, r0 + ce) - tab_load(rsrc, r0 + cs);
-                    for (int ys = ya[i]; ys < yb[i]; ys += rh) {
-                        const int ye = min(ys + rh, yb[i]);
-                        const uint32_t r1 = (uint32_t)(ye - trow0) * pitch8;
+                auto add = [&](u64 Xs) { sb += (uint32_t)(Xs & kSatFieldMask); sg += (uint32_t)((Xs >> 21) & kSatFieldMask); sr += (uint32_t)(Xs >> 42); };
+                if (wd <= kSatMaxArea) {                            // every nominal window: strips of whole rows
+                    const int rh = max(kSatMaxArea / wd, 1);
+                    const uint32_t cs = 8u * (uint32_t)xa[i] + 24u, ce = 8u * (uint32_t)xb[i] + 24u;
+                    u64 Dp = C[i][1] - C[i][0];                     // the first corner row
+                    for (int ys = ya[i] + rh; ys < yb[i]; ys += rh) {            // the rows between the strips
+                        const uint32_t r1 = (uint32_t)(ys - trow0) * pitch8;
                         const u64 D1 = tab_load(rsrc, r1 + ce) - tab_load(rsrc, r1 + cs);
-                        const u64 Xs = D1 - D0;
-                        sb += (uint32_t)(Xs & kSatFieldMask); sg += (uint32_t)((Xs >> 21) & kSatFieldMask); sr += (uint32_t)(Xs >> 42);
-                        D0 = D1;
+                        add(D1 - Dp);
+                        Dp = D1;
+                    }
+                    add((C[i][3] - C[i][2]) - Dp);                  // the strip that ends at the last corner row
+                } else {                                            // a row wider than a strip may be (depths far above 255 only): strips in columns too
+                    const int cw = kSatMaxArea, rh = 1;
+                    for (int xs = xa[i]; xs < xb[i]; xs += cw) {
+                        const int xe = min(xs + cw, xb[i]);
+                        const uint32_t cs = 8u * (uint32_t)xs + 24u, ce = 8u * (uint32_t)xe + 24u;
+                        const uint32_t r0 = (uint32_t)(ya[i] - trow0) * pitch8;
+                        u64 D0 = tab_load(rsrc, r0 + ce) - tab_load(rsrc, r0 + cs);
+                        for (int ys = ya[i]; ys < yb[i]; ys += rh) {
+                            const int ye = min(ys + rh, yb[i]);
+                            const uint32_t r1 = (uint32_t)(ye - trow0) * pitch8;
+                            const u64 D1 = tab_load(rsrc, r1 + ce) - tab_load(rsrc, r1 + cs);
+                            add(D1 - D0);
+                            D0 = D1;
+                        }
                     }
                 }
                 if (cnt[i] < 65536u && (sb | sg | sr) < (1u << 24)) {           // nominal: exact sums, exact integer quotients

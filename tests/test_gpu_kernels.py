@@ -318,3 +318,25 @@ def test_defocus_refuses_a_table_it_cannot_address():
         assert L.rtdd_simulate_defocus(c._h, *args) == 1          # RTDD_ERR_INVALID
         assert b"too large for the defocus table" in L.rtdd_last_error(c._h)
         c.synchronize()
+
+
+def test_defocus_windows_wider_than_a_strip():
+    """A window of more than 8224 pixels is summed in strips that share corner rows (the packed 3 x 21-bit difference holds 8224 x 255);
+    one that is WIDER than 8224 pixels -- an image wider than that and a depth far above 255 -- is cut in columns too: the one branch of
+    the lookup no ordinary image reaches.  Against the independent 64-bit restatement, every pixel."""
+    from effects_ref import defocus_by_summed_area_table
+    rows, cols = 48, 8400
+    rng = np.random.default_rng(4)
+    orig = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    depth = rng.uniform(0, 255, (rows, cols)).astype(np.float32)
+    depth[::7, ::331] = np.float32(40000.0)                          # k/2 far beyond the image: the whole (clipped) image, 8400 pixels wide
+    depth[3::11, 5::977] = np.float32(900.0)                         # 3.5 x the nominal reach
+    with rt.Context(0) as c:
+        c.GPULoadWeights(0.4)
+        art = up(np.zeros_like(orig))
+        c.GPUSimulateDefocus(up(orig), up(depth), art, rows, cols)
+        c.synchronize()
+        assert c.get_option(rt.OPT_DEFOCUS_LAST_PATH) == 1
+        got = down(art)
+    want = defocus_by_summed_area_table(orig, depth)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} values differ"
