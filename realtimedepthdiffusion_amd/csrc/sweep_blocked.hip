@@ -159,11 +159,7 @@ __global__ __launch_bounds__(NT, (G == 2 && NT == 512 ? RTDD_OCC_G2 : NT >= 1024
     // tile are inside the image -- the setup then needs none of its border selects (sweep_tile_setup.inc)
     const int tx0 = bx * TW - hx, ty0 = by * TH - hy;
     const bool tile_inside = tx0 >= 0 && tx0 + EW < cols && ty0 >= 1 && ty0 + eh < rows;
-#ifdef RTDD_SETUP_R5
-#include "sweep_tile_setup_r5.inc"    // (A/B builds: round 5's setup)
-#else
 #include "sweep_tile_setup.inc"       // vxr / vpr / mr / mup -> a, b, weights, divisors, reciprocals
-#endif
 
     RTDD_STAMP(1);
     __builtin_amdgcn_s_setprio(0);
