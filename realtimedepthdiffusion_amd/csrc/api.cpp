@@ -344,7 +344,7 @@ int rtdd_set_option(rtdd_ctx *ctx, int key, int value) {
     if (!ctx) return RTDD_ERR_INVALID;
     switch (key) {
         case RTDD_OPT_FP_CONTRACT: ctx->opt.fp_contract = value ? 1 : 0; break;
-        case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 3, "sweep kernel must be 0..3"); ctx->opt.sweep_kernel = value;
+        case RTDD_OPT_SWEEP_KERNEL: REQUIRE(ctx, value >= 0 && value <= 2, "sweep kernel must be 0..2"); ctx->opt.sweep_kernel = value;
         break;
         case RTDD_OPT_TEMPORAL_DEPTH: REQUIRE(ctx, value >= 0 && value <= 28, "temporal depth must be 0..28");
         ctx->opt.temporal_depth = value; break;
@@ -567,8 +567,7 @@ struct Solve {
         while (done < p->maxIterations) {
             const int n = p->maxIterations - done < chunk ? p->maxIterations - done : chunk;
             int ln = 0;
-            rc = (ctx->opt.sweep_kernel == 3 && images == 1) ? launch_sweeps_stream(ctx, L, ip, rows, cols, omegas_dev + done, n, &pk, &pm, &ln)
-                 : blocked ? launch_sweeps_blocked(ctx, L, ip, rows, cols, omegas_dev + done, n, &pk, &pm, &ln, images)
+            rc = blocked ? launch_sweeps_blocked(ctx, L, ip, rows, cols, omegas_dev + done, n, &pk, &pm, &ln, images)
                          : launch_sweeps(ctx, L, ip, rows, cols, omegas.data() + done, n, &pk, &pm, &ln);
             if (rc != RTDD_OK) return rc;
             done += n; launches += ln;

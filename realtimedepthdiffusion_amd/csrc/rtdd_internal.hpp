@@ -259,8 +259,6 @@ int launch_sweeps(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, 
 // sweep_blocked.hip
 int launch_sweeps_blocked(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n,
                           int *pk, int *pm, int *launches, int images = 1);
-// sweep_stream.hip (RTDD_OPT_SWEEP_KERNEL = 3, experimental): whole launches of 6 sweeps as a stream of rows per wave, the rest blocked
-int launch_sweeps_stream(rtdd_ctx *ctx, const Level &L, size_t ip, int rows, int cols, const float *omegas_dev, int n, int *pk, int *pm, int *launches);
 // (k_finish and k_pyrup_inject store NOTHING when the status word is set: a timed-out solve leaves the caller's buffers as they were;
 // the first of them to find it set records ctx->guard_seq in sync_words[kSyncFailedSeq])
 // (seq: the solve's sequence number, reported by the kernel either as confirmed or as the first failed one; t: the batch and the u8 targets)

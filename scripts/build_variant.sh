@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../realtimedepthdiffusion_amd/csrc"
 make -j4 >/dev/null
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -fvisibility=hidden -I../../include -I."
 OBJS=""
-for f in solver_kernels sweep_blocked sweep_stream rbgs_blocked multigrid image_kernels effect_kernels cascade api cascade_api dropin; do
+for f in solver_kernels sweep_blocked rbgs_blocked multigrid image_kernels effect_kernels cascade api cascade_api dropin; do
     ext=hip; [ -f $f.cpp ] && ext=cpp
     if echo " $FILES " | grep -q " $f.$ext "; then
         /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $DEFS -c $f.$ext -o /tmp/${f}_$NAME.o

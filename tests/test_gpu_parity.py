@@ -861,22 +861,3 @@ def test_set_stream_settles_the_log_on_the_old_stream(oracle, lut):
         assert_bit_equal(down(d), oracle.solve(want, p["mask"], p["gray"], 40, 0, 0, lut, 1, threads=oracle.max_threads()), "next solve on the new stream")
         c.set_stream(0)
 
-
-@pytest.mark.parametrize("contract", [1, 0])
-@pytest.mark.parametrize("shape,iters,level,levels", [((200, 333), 37, 0, 1), ((67, 120), 64, 1, 2), ((300, 130), 24, 0, 2), ((129, 129), 19, 0, 1),
-                                                      ((540, 960), 30, 0, 1), ((33, 700), 12, 0, 1), ((700, 33), 18, 0, 1), ((1080, 1920), 62, 0, 1)])
-def test_stream_kernel_bit_exact(ctx, oracle, lut, shape, iters, level, levels, contract):
-    """RTDD_OPT_SWEEP_KERNEL = 3 (round 6, experimental): the sweeps as a stream of rows per wave -- three rows per iterate and the constants of
-    the six rows in flight in registers, six sweeps per launch, the rest by the blocked kernel.  Only a re-schedule: the oracle's bits, for
-    sizes narrower / lower than a strip or a chunk, ragged last strips, both contractions, gated and un-gated levels."""
-    p = make_problem(shape[0], shape[1], seed=shape[0] * 3 + shape[1])
-    if level != levels - 1:
-        rng = np.random.default_rng(2)
-        free = p["mask"] != 255
-        p["depth"][free] = rng.uniform(0, 255, free.sum()).astype(np.float32)
-    want = oracle.solve(p["depth"].copy(), p["mask"], p["gray"], iters, level, levels - 1, lut, contract, threads=min(8, oracle.max_threads()))
-    got = _solve_gpu(ctx, p, iters, level, levels, contract, opts={rt.OPT_SWEEP_KERNEL: 3})
-    info = ctx.last_solve_info()
-    ctx.set_option(rt.OPT_SWEEP_KERNEL, 0)
-    assert info.kernel == (5 if iters % 6 == 0 else 2) or iters >= 6, info.describe()
-    assert_bit_equal(got, want, f"stream kernel {shape} x {iters} contract {contract}")
